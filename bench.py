@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark: OOV embed lookups+scores per second on the synthetic north-star workload.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json north_star / SURVEY.md section 8d "Config S-lsh"): item features
+f32[N=10M, F=64] row-normalised, planes f32[8,64], OOV bucket table f32[8,64], batch B=65536
+random ids, user rows f32[B,64].  One STEP = one pass of the hot path over one batch:
+    mi_oov_lsh_embed  (fused gather -> 8 sign projections -> masked bucket mean -> [B,64] rows;
+                       the plugin call LSHInductiveEmbedder.embed_item_ids)
+    mi_oov_rowdot     (BPR.predict: one score per lookup)
+Every step uses a fresh id batch (no cache reuse across steps); all inputs are resident in HBM
+before the timed region.  value = lookups (each embedded and scored) per second, whole job.
+
+N > 1: one process per GPU; the 2.56 GB table is REPLICATED (it fits 288 GB HBM 100x over), ranks
+process independent batches and there is no data-path collective -> weak
+scaling.  `--sharded` instead row-shards the table and exchanges ids/rows with RCCL all-to-all.
+
+The JSON line also carries `roofline` (dominant kernel = the fused lsh kernel, HBM-bound,
+algorithmic bytes 8+4F+4D = 520 B per lookup, timed with HIP events on its own stream inside the
+timed region) and, at N=1, `cpu_baseline` (the reference's torch-CPU op sequence on the host).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--items", type=int, default=10_000_000)
+    ap.add_argument("--feat", type=int, default=64)
+    ap.add_argument("--dim", type=int, default=64)
+    ap.add_argument("--hashes", type=int, default=8)
+    ap.add_argument("--batch", type=int, default=65536)
+    ap.add_argument("--sharded", action="store_true", help="row-shard the table + RCCL all-to-all exchange")
+    ap.add_argument("--fused", action="store_true", help="single-launch embed+score kernel instead of two launches")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    return ap.parse_args()
+
+
+def make_inputs(args, dev, rank, n_rows, row_offset=0):
+    """Deterministic synthetic tables, generated on the device in chunks."""
+    g = torch.Generator(device=dev)
+    feat = torch.empty((n_rows, args.feat), dtype=torch.float32, device=dev)
+    chunk = 1 << 20
+    for lo in range(0, n_rows, chunk):
+        hi = min(n_rows, lo + chunk)
+        g.manual_seed(1_000_003 * ((row_offset + lo) // chunk) + 0)
+        x = torch.randn((hi - lo, args.feat), generator=g, device=dev)
+        feat[lo:hi] = torch.nn.functional.normalize(x, dim=-1)
+    g.manual_seed(1)
+    planes = torch.randn((args.hashes, args.feat), generator=g, device=dev)
+    g.manual_seed(2)
+    buckets = torch.randn((args.hashes, args.dim), generator=g, device=dev)
+    return feat, planes, buckets
+
+
+def cpu_baseline(args, feat, planes, buckets, seconds):
+    """The reference's CPU path (torch ops, oracle/ref_torch.py) on a bounded sample of batches."""
+    from oracle import ref_torch
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    f, p, w = feat.cpu(), planes.cpu(), buckets.cpu()
+    g = torch.Generator().manual_seed(7)
+    users = torch.randn((args.batch, args.dim), generator=g)
+    n_done, t_total = 0, 0.0
+    for it in range(1000):
+        ids = torch.randint(0, f.shape[0], (args.batch,), generator=g)
+        t0 = time.perf_counter()
+        e = ref_torch.lsh_embed(ids, f, p, w)
+        s = ref_torch.rowdot(users, e)
+        t1 = time.perf_counter()
+        if it >= 2:  # two untimed warm-up batches
+            n_done += 1
+            t_total += t1 - t0
+        if t_total > seconds:
+            break
+    del s
+    return {"value": n_done * args.batch / t_total, "unit": "lookups/s", "cores": cores, "kind": "port",
+            "sample": f"{n_done} batches of {args.batch} lookups+scores through the reference's torch-CPU op "
+                      f"sequence (oracle/ref_torch.py), {t_total:.1f} s, torch.set_num_threads({cores})"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import mi_oov  # noqa: F401
+    from mi_oov import ops, sharded
+
+    B, D, F, H, N = args.batch, args.dim, args.feat, args.hashes, args.items
+    if args.sharded and world > 1:
+        lo, hi, per = sharded.shard_bounds(N, world, rank)
+        feat, planes, buckets = make_inputs(args, dev, rank, hi - lo, lo)
+        table = sharded.ShardedLSHTable(feat, N)
+        embed = lambda ids: table.embed(ids, planes, buckets)  # noqa: E731
+    else:
+        feat, planes, buckets = make_inputs(args, dev, rank, N)
+        embed = lambda ids: ops.lsh_embed(ids, feat, planes, buckets)  # noqa: E731
+
+    total = args.warmup + args.steps
+    g = torch.Generator(device=dev)
+    g.manual_seed(3 + 1000 * rank)
+    all_ids = torch.randint(0, N, (total, B), generator=g, device=dev)
+    g.manual_seed(4 + 1000 * rank)
+    n_user_bufs = 8
+    users = torch.randn((n_user_bufs, B, D), generator=g, device=dev)
+
+    def step(i, ev=None):
+        ids = all_ids[i]
+        if args.fused and not (args.sharded and world > 1):
+            if ev:
+                ev[0].record()
+            s = ops.lsh_embed_score(ids, feat, planes, buckets, users[i % n_user_bufs])
+            if ev:
+                ev[1].record()
+            return s
+        if ev:
+            ev[0].record()
+        e = embed(ids)
+        if ev:
+            ev[1].record()
+        return ops.rowdot(users[i % n_user_bufs], e)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                  for _ in range(args.steps)]
+        fence()
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(args.warmup + k, events[k])
+        fence()
+        t1 = time.perf_counter()
+
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    kern = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kern, op=dist.ReduceOp.MAX)
+    elapsed_s, kern_ms = float(elapsed.item()), float(kern.item())
+
+    if rank == 0:
+        per_lookup = (16 + 4 * F + 4 * D + 4) if args.fused else (8 + 4 * F + 4 * D)
+        achieved = (B * per_lookup / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else 0.0
+        out = {
+            "metric": "OOV embed lookups+scores/sec",
+            "value": world * B * args.steps / elapsed_s,
+            "unit": "lookups/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed_s / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "synthetic lsh hash-gather-aggregate + pairwise score "
+                                   f"({N}-item x {F}-feature table, {H} hashes/buckets, {D}-d, batch {B} per GPU)",
+                       "items": N, "feat": F, "dim": D, "hashes": H, "batch_per_gpu": B,
+                       "table": "row-sharded + all-to-all" if (args.sharded and world > 1) else "replicated per GPU",
+                       "launches_per_step": "lsh_embed_score" if args.fused else "lsh_embed + rowdot"},
+            "roofline": {"bound": "hbm", "kernel": "lsh_fused_kernel" + (" (+score)" if args.fused else ""),
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "bytes_per_lookup": per_lookup, "lookups_per_launch": B, "avg_launch_us": kern_ms * 1e3,
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, feat, planes, buckets, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,120 @@
+"""ctypes binding of libmi_oov.so (include/mi_oov.h) -- the ONLY compute backend of this package.
+
+There is no CPU or eager-PyTorch fallback: if the shared library is missing, or a tensor is not
+on a ROCm device, the call raises.  PyTorch is used for device memory and streams only; every
+argument crosses the boundary as a raw device pointer / size (no torch types in the C ABI).
+"""
+import ctypes
+import os
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "lib", "libmi_oov.so")
+
+_i64 = ctypes.c_int64
+_vp = ctypes.c_void_p
+
+
+class MiOovError(RuntimeError):
+    """A libmi_oov entry point returned a negative status."""
+
+
+_lib = None
+
+_SIGNATURES = {
+    "mi_oov_version": (ctypes.c_int, []),
+    "mi_oov_strerror": (ctypes.c_char_p, [ctypes.c_int]),
+    "mi_oov_last_hip_error": (ctypes.c_int, []),
+    "mi_oov_lsh_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "mi_oov_lsh_embed_score": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "mi_oov_lsh_lookup": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "mi_oov_slsh_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "mi_oov_siphash24_mod": (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_uint32, _vp, _vp]),
+    "mi_oov_mapper_hash": (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp]),
+    "mi_oov_mapper_map": (ctypes.c_int, [_vp, _i64, ctypes.c_int, _i64, _i64, _vp, _vp]),
+    "mi_oov_gather_mean": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_gather_rows": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_splice_rows": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_col_mean_workspace": (_i64, [_i64, _i64]),
+    "mi_oov_col_mean": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
+    "mi_oov_broadcast_rows": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_rowdot": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_full_sort_scores": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_score_topk_workspace": (_i64, [_i64, _i64, _i64]),
+    "mi_oov_score_topk": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def available() -> bool:
+    return os.path.exists(LIB_PATH)
+
+
+def lib():
+    """Load libmi_oov.so once.  torch is imported first so that the HIP runtime torch already
+    mapped (same SONAME libamdhip64.so.7) is the one our library binds to: streams and device
+    pointers are then shared between torch and the kernels."""
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C "
+                "improving-inductive-oov-recsys_amd/csrc`). There is no CPU fallback.")
+        l = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        l = lib()
+        msg = l.mi_oov_strerror(rc).decode()
+        raise MiOovError(f"{what}: {msg} (code {rc}, hipError {l.mi_oov_last_hip_error()})")
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def dev_tensor(t, dtype, name):
+    """Validate a tensor that is handed to a kernel: ROCm device, dtype, dense row-major."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name} must be a torch.Tensor")
+    if t.device.type != "cuda":
+        raise RuntimeError(f"{name} is on {t.device}: mi_oov kernels run on an MI355X (ROCm) device only; "
+                           "there is no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t
+
+
+def stream_of(t) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class on_device:
+    """Make the tensor's device current for the duration of a launch (no-op when it already is)."""
+
+    def __init__(self, t):
+        self.idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+        self.prev = None
+
+    def __enter__(self):
+        cur = torch.cuda.current_device()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev is not None:
+            torch.cuda.set_device(self.prev)
+        return False

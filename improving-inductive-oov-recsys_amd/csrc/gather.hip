@@ -1,0 +1,290 @@
+// Row movers and small reductions of the path (all HBM-bound, float4 per lane, 16 lanes per row):
+//   gather_rows    nn.Embedding forward                     bpr.py:77-81, single_lsh_embedder.py:100,108
+//   splice_rows    in-vocab U OOV scatter of BPR lookups    bpr.py:62-76,108-123
+//   gather_mean    knn aggregate                            knn_embedder.py:125-126,146-147
+//   col_mean       MeanEmbedder cached mean                 mean_embedder.py:54-56,76-78
+//   broadcast_rows mean.repeat(B,1) / zeros(D).repeat(B,1)  mean_embedder.py:56,78; zero_embedder.py:36-60
+//   rowdot         BPR.predict                              bpr.py:145-149
+#include "common.hpp"
+
+namespace mi_oov {
+
+// One 16-lane group per output row, R rows in flight per group.
+template <bool VEC, int MODE>  // MODE 0: gather_rows, 1: splice_rows
+__global__ __launch_bounds__(kBlock) void row_copy_kernel(const int64_t* __restrict__ ids,
+                                                          const int64_t* __restrict__ rank, int64_t B,
+                                                          const float* __restrict__ W, int64_t N,
+                                                          const float* __restrict__ oov_rows, int64_t n_oov,
+                                                          int64_t D, float* __restrict__ out) {
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+       tile += static_cast<int64_t>(gridDim.x) * 4) {
+    const float* src[R];
+    int64_t row[R];
+    bool live[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      live[r] = row[r] < B;
+      src[r] = nullptr;
+      if (live[r]) {
+        const int64_t id = ids[row[r]];
+        if (MODE == 0 || id < N) {
+          if (static_cast<uint64_t>(id) < static_cast<uint64_t>(N)) src[r] = W + id * D;
+        } else {
+          const int64_t k = rank[row[r]];
+          if (static_cast<uint64_t>(k) < static_cast<uint64_t>(n_oov)) src[r] = oov_rows + k * D;
+        }
+      }
+    }
+    for (int c = 0; c < dchunks; ++c) {
+      const int e = (c * 16 + l16) * 4;
+      float4 v[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        v[r] = src[r] ? load4<VEC>(src[r], e, D) : make_float4(qnan(), qnan(), qnan(), qnan());
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (live[r]) store4<VEC>(out + row[r] * D, e, D, v[r]);
+    }
+  }
+}
+
+// out[o,:] = mean_{t in [o*g, min(M,(o+1)*g))} W[idx[t],:], summed in increasing t.
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void gather_mean_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t g,
+                                                             const float* __restrict__ W, int64_t N, int64_t D,
+                                                             float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t nout = (M + g - 1) / g;
+  const int64_t ntiles = (nout + 3) / 4;
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+       tile += static_cast<int64_t>(gridDim.x) * 4) {
+    const int64_t o = tile * 4 + grp;
+    if (o >= nout) continue;
+    const int64_t t0 = o * g;
+    const int64_t t1 = (t0 + g < M) ? t0 + g : M;
+    const float inv_n = static_cast<float>(t1 - t0);
+    for (int c = 0; c < dchunks; ++c) {
+      const int e = (c * 16 + l16) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      bool ok = true;
+      for (int64_t t = t0; t < t1; ++t) {
+        const int64_t id = idx[t];
+        const bool in = static_cast<uint64_t>(id) < static_cast<uint64_t>(N);
+        ok = ok && in;
+        const float4 v = in ? load4<VEC>(W + id * D, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      acc.x /= inv_n; acc.y /= inv_n; acc.z /= inv_n; acc.w /= inv_n;
+      if (!ok) acc = make_float4(qnan(), qnan(), qnan(), qnan());
+      store4<VEC>(out + o * D, e, D, acc);
+    }
+  }
+}
+
+// ---- column mean -------------------------------------------------------------------------------
+// Partition p owns rows [p*kPartRows, (p+1)*kPartRows); inside it row-group gr (0..15) sums rows
+// gr, gr+16, ... sequentially; the 16 group sums are added in order gr = 0..15; the partition
+// partials are added in order p = 0..P-1 and divided by N.  oracle/oov_oracle.c mirrors this.
+constexpr int kPartRows = 4096;
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void col_partial_kernel(const float* __restrict__ W, int64_t N, int64_t D,
+                                                             float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [16][DP]
+  const int gr = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  const int DP = dchunks * 64;
+  const int64_t P = (N + kPartRows - 1) / kPartRows;
+  for (int64_t part = blockIdx.x; part < P; part += gridDim.x) {
+    const int64_t r0 = part * kPartRows;
+    const int64_t r1 = (r0 + kPartRows < N) ? r0 + kPartRows : N;
+    for (int c = 0; c < dchunks; ++c) {
+      const int e = (c * 16 + l16) * 4;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t r = r0 + gr; r < r1; r += 16) {
+        const float4 v = load4<VEC>(W + r * D, e, D);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+      }
+      *reinterpret_cast<float4*>(red + gr * DP + e) = acc;
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += kBlock) {
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += red[q * DP + d];
+      partial[part * D + d] = s;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void col_final_kernel(const float* __restrict__ partial, int64_t P, int64_t N,
+                                                           int64_t D, float* __restrict__ mean) {
+  const int64_t d = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  if (d >= D) return;
+  float s = 0.f;
+  for (int64_t p = 0; p < P; ++p) s += partial[p * D + d];
+  mean[d] = s / static_cast<float>(N);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void broadcast_kernel(const float* __restrict__ vec, int64_t B, int64_t D,
+                                                           float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  const int64_t ntiles = (B + 3) / 4;
+  for (int c = 0; c < dchunks; ++c) {
+    const int e = (c * 16 + l16) * 4;
+    const float4 v = vec ? load4<false>(vec, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+         tile += static_cast<int64_t>(gridDim.x) * 4) {
+      const int64_t row = tile * 4 + grp;
+      if (row < B) store4<VEC>(out + row * D, e, D, v);
+    }
+  }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void rowdot_kernel(const float* __restrict__ U, const float* __restrict__ E,
+                                                        int64_t B, int64_t D, float* __restrict__ score) {
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+       tile += static_cast<int64_t>(gridDim.x) * 4) {
+    float part[R];
+    int64_t row[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      part[r] = 0.f;
+    }
+    for (int c = 0; c < dchunks; ++c) {
+      const int e = (c * 16 + l16) * 4;
+      float4 u[R], v[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const bool live = row[r] < B;
+        u[r] = live ? load4<VEC>(U + row[r] * D, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[r] = live ? load4<VEC>(E + row[r] * D, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) part[r] = dot4_muladd(u[r], v[r], part[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const float s = row16_sum(part[r]);
+      if (l16 == 0 && row[r] < B) score[row[r]] = s;
+    }
+  }
+}
+
+}  // namespace mi_oov
+
+using namespace mi_oov;
+
+extern "C" int mi_oov_gather_rows(const int64_t* ids, int64_t B, const float* W, int64_t N, int64_t D, float* out,
+                                  void* stream) {
+  if (B < 0 || N <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!ids || !W || !out) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (D % 4 == 0) && aligned16(W) && aligned16(out);
+  const int grid = grid_for(B, 64);
+  if (vec)
+    hipLaunchKernelGGL((row_copy_kernel<true, 0>), dim3(grid), dim3(kBlock), 0, st, ids, nullptr, B, W, N, nullptr, 0, D, out);
+  else
+    hipLaunchKernelGGL((row_copy_kernel<false, 0>), dim3(grid), dim3(kBlock), 0, st, ids, nullptr, B, W, N, nullptr, 0, D, out);
+  return check_launch();
+}
+
+extern "C" int mi_oov_splice_rows(const int64_t* ids, const int64_t* oov_rank, int64_t B, const float* table,
+                                  int64_t n_vocab, const float* oov_rows, int64_t n_oov, int64_t D, float* out,
+                                  void* stream) {
+  if (B < 0 || n_vocab < 0 || n_oov < 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!ids || !oov_rank || !out || (n_vocab > 0 && !table) || (n_oov > 0 && !oov_rows)) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (D % 4 == 0) && (!table || aligned16(table)) && (!oov_rows || aligned16(oov_rows)) && aligned16(out);
+  const int grid = grid_for(B, 64);
+  if (vec)
+    hipLaunchKernelGGL((row_copy_kernel<true, 1>), dim3(grid), dim3(kBlock), 0, st, ids, oov_rank, B, table, n_vocab, oov_rows, n_oov, D, out);
+  else
+    hipLaunchKernelGGL((row_copy_kernel<false, 1>), dim3(grid), dim3(kBlock), 0, st, ids, oov_rank, B, table, n_vocab, oov_rows, n_oov, D, out);
+  return check_launch();
+}
+
+extern "C" int mi_oov_gather_mean(const int64_t* idx, int64_t M, int64_t g, const float* W, int64_t N, int64_t D,
+                                  float* out, void* stream) {
+  if (M < 0 || g <= 0 || N <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (M == 0) return MI_OOV_OK;
+  if (!idx || !W || !out) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (D % 4 == 0) && aligned16(W) && aligned16(out);
+  const int grid = grid_for((M + g - 1) / g, 16);
+  if (vec)
+    hipLaunchKernelGGL(gather_mean_kernel<true>, dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out);
+  else
+    hipLaunchKernelGGL(gather_mean_kernel<false>, dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out);
+  return check_launch();
+}
+
+extern "C" int64_t mi_oov_col_mean_workspace(int64_t N, int64_t D) {
+  if (N <= 0 || D <= 0) return 0;
+  return ((N + kPartRows - 1) / kPartRows) * D;
+}
+
+extern "C" int mi_oov_col_mean(const float* W, int64_t N, int64_t D, float* mean, float* workspace, void* stream) {
+  if (N <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (!W || !mean || !workspace) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t P = (N + kPartRows - 1) / kPartRows;
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  const size_t lds = static_cast<size_t>(16) * dchunks * 64 * sizeof(float);
+  if (lds > 64 * 1024) return MI_OOV_ERR_SHAPE;
+  const int grid = static_cast<int>(P < kMaxGrid ? P : kMaxGrid);
+  const bool vec = (D % 4 == 0) && aligned16(W);
+  if (vec)
+    hipLaunchKernelGGL(col_partial_kernel<true>, dim3(grid), dim3(kBlock), lds, st, W, N, D, workspace);
+  else
+    hipLaunchKernelGGL(col_partial_kernel<false>, dim3(grid), dim3(kBlock), lds, st, W, N, D, workspace);
+  if (int rc = check_launch()) return rc;
+  const int g2 = static_cast<int>((D + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(col_final_kernel, dim3(g2), dim3(kBlock), 0, st, workspace, P, N, D, mean);
+  return check_launch();
+}
+
+extern "C" int mi_oov_broadcast_rows(const float* vec, int64_t B, int64_t D, float* out, void* stream) {
+  if (B < 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!out) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool v = (D % 4 == 0) && aligned16(out);
+  const int grid = grid_for(B, 64);
+  if (v)
+    hipLaunchKernelGGL(broadcast_kernel<true>, dim3(grid), dim3(kBlock), 0, st, vec, B, D, out);
+  else
+    hipLaunchKernelGGL(broadcast_kernel<false>, dim3(grid), dim3(kBlock), 0, st, vec, B, D, out);
+  return check_launch();
+}
+
+extern "C" int mi_oov_rowdot(const float* U, const float* E, int64_t B, int64_t D, float* score, void* stream) {
+  if (B < 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!U || !E || !score) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
+  const int grid = grid_for(B, 64);
+  if (vec)
+    hipLaunchKernelGGL(rowdot_kernel<true>, dim3(grid), dim3(kBlock), 0, st, U, E, B, D, score);
+  else
+    hipLaunchKernelGGL(rowdot_kernel<false>, dim3(grid), dim3(kBlock), 0, st, U, E, B, D, score);
+  return check_launch();
+}

@@ -1,0 +1,493 @@
+// lsh / slsh: fused gather -> sign-random-projection -> bucket aggregate (+ optional score,
+// + optional in-vocabulary splice).  HBM-bound: per lookup one random F-float row read and one
+// D-float row write; planes and bucket rows live in LDS for the whole workgroup.
+//
+// Work decomposition (wave64, gfx950):
+//   * one lookup is owned by a 16-lane DPP row ("group"); a wave owns 4 groups and keeps R
+//     lookups per group in flight, i.e. 4*R independent 16-B loads per lane are issued before
+//     the first use, which is what hides the ~900-cycle HBM miss latency;
+//   * lane l of a group holds elements e with (e/4)%16 == l of the feature row (one
+//     global_load_dwordx4 per 64 floats), the matching slice of every plane comes from LDS
+//     (ds_read_b128, identical address in the 4 groups -> broadcast), the 16 partials are
+//     reduced with 4 DPP adds (no LDS, no ds_bpermute);
+//   * every lane of the group then knows all H bits and accumulates its 4-float slice of the
+//     output row from the LDS-resident bucket rows; the row is stored as 16 x 16 B = one
+//     contiguous 256-B segment per group at D = 64.
+//
+// Reference functions restated: R/inductive/torch_hash.py:55-60, lsh_embedder.py:116-179,
+// single_lsh_embedder.py:82-109, bpr.py:48-125,145-149 (see include/mi_oov.h).
+#include "common.hpp"
+
+namespace mi_oov {
+
+struct LshParams {
+  const int64_t* ids;
+  int64_t B;
+  const float* feat;
+  int64_t N, F;
+  const float* planes;
+  int64_t H;
+  const float* buckets;  // lsh: [H,D]   slsh: [n_buckets,D]
+  int64_t n_buckets;
+  int64_t D;
+  const float* table;  // lookup mode: [n_vocab,D] or nullptr
+  int64_t n_vocab;
+  const float* other;  // score mode: [B,D] or nullptr
+  float* score;
+  float* out;
+  uint8_t* bits;
+  int64_t* idx;  // slsh only
+};
+
+// Stage a [rows, L] matrix into LDS with row stride LP (zero padded).
+__device__ __forceinline__ void stage_padded(float* dst, const float* src, int64_t rows, int64_t L, int LP) {
+  const int64_t total = rows * LP;
+  for (int64_t i = threadIdx.x; i < total; i += kBlock) {
+    const int64_t r = i / LP;
+    const int e = static_cast<int>(i - r * LP);
+    dst[i] = (e < L) ? src[r * L + e] : 0.f;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// lsh: F <= 256 (FC chunks of 64 floats in registers), D <= 256 (DC chunks)
+// ------------------------------------------------------------------------------------------
+template <int FC, int DC, bool VEC, int R>
+__global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int FP = FC * 64, DP = DC * 64;
+  float* sP = smem;
+  float* sW = smem + p.H * FP;
+  stage_padded(sP, p.planes, p.H, p.F, FP);
+  if (p.buckets) stage_padded(sW, p.buckets, p.H, p.D, DP);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int l16 = lane & 15;
+  const int grp = lane >> 4;
+  const int wv = threadIdx.x >> 6;
+  const int64_t ntiles = (p.B + 4 * R - 1) / (4 * R);
+  const int H = static_cast<int>(p.H);
+  const bool want_emb = (p.out != nullptr) || (p.score != nullptr);
+
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+       tile += static_cast<int64_t>(gridDim.x) * 4) {
+    int64_t row[R];
+    int64_t id[R];
+    bool live[R], valid[R], oov[R];
+    float4 x[R][FC];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      live[r] = row[r] < p.B;
+      id[r] = live[r] ? p.ids[row[r]] : -1;
+      oov[r] = (p.table == nullptr) || (id[r] >= p.n_vocab);
+      valid[r] = live[r] && (oov[r] ? (static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(p.N))
+                                    : (id[r] >= 0));
+      const bool ld = valid[r] && oov[r];
+      const float* frow = p.feat + (ld ? id[r] : 0) * p.F;
+#pragma unroll
+      for (int c = 0; c < FC; ++c) {
+        const int e = (c * 16 + l16) * 4;
+        x[r][c] = ld ? load4<VEC>(frow, e, p.F) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+
+    float4 acc[R][DC];
+    float cnt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      cnt[r] = 0.f;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) acc[r][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    for (int h = 0; h < H; ++h) {
+      float4 pw[FC];
+#pragma unroll
+      for (int c = 0; c < FC; ++c)
+        pw[c] = *reinterpret_cast<const float4*>(sP + h * FP + (c * 16 + l16) * 4);
+      float4 bw[DC];
+      if (want_emb) {
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+          bw[c] = *reinterpret_cast<const float4*>(sW + h * DP + (c * 16 + l16) * 4);
+      }
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float part = 0.f;
+#pragma unroll
+        for (int c = 0; c < FC; ++c) part = dot4_fma(x[r][c], pw[c], part);
+        const float s = row16_sum(part);
+        const float bit = (s < 0.f) ? 0.f : 1.f;  // >=0, +-0 and NaN -> 1 (torch_hash.py:57-59)
+        cnt[r] = cnt[r] + bit;
+        if (want_emb) {
+#pragma unroll
+          for (int c = 0; c < DC; ++c) {
+            acc[r][c].x = __builtin_fmaf(bit, bw[c].x, acc[r][c].x);
+            acc[r][c].y = __builtin_fmaf(bit, bw[c].y, acc[r][c].y);
+            acc[r][c].z = __builtin_fmaf(bit, bw[c].z, acc[r][c].z);
+            acc[r][c].w = __builtin_fmaf(bit, bw[c].w, acc[r][c].w);
+          }
+        }
+        if (p.bits && l16 == 0 && live[r])
+          p.bits[row[r] * p.H + h] = valid[r] ? static_cast<uint8_t>(bit) : static_cast<uint8_t>(0xFF);
+      }
+    }
+
+    if (want_emb) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float4 emb[DC];
+#pragma unroll
+        for (int c = 0; c < DC; ++c) {
+          const int e = (c * 16 + l16) * 4;
+          if (oov[r]) {
+            emb[c].x = acc[r][c].x / cnt[r];  // 0/0 -> NaN row, as lsh_embedder.py:178
+            emb[c].y = acc[r][c].y / cnt[r];
+            emb[c].z = acc[r][c].z / cnt[r];
+            emb[c].w = acc[r][c].w / cnt[r];
+          } else {
+            emb[c] = valid[r] ? load4<VEC>(p.table + id[r] * p.D, e, p.D) : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+          if (!valid[r]) emb[c] = make_float4(qnan(), qnan(), qnan(), qnan());
+          if (p.out && live[r]) store4<VEC>(p.out + row[r] * p.D, e, p.D, emb[c]);
+        }
+        if (p.score) {
+          float sp = 0.f;
+          const float* orow = p.other + (live[r] ? row[r] : 0) * p.D;
+#pragma unroll
+          for (int c = 0; c < DC; ++c) {
+            const int e = (c * 16 + l16) * 4;
+            float4 o = live[r] ? load4<VEC>(orow, e, p.D) : make_float4(0.f, 0.f, 0.f, 0.f);
+            // padded tail lanes hold emb = x/cnt of zero-padded acc: force exact zeros there
+            float4 m = emb[c];
+            if (e + 0 >= p.D) m.x = 0.f;
+            if (e + 1 >= p.D) m.y = 0.f;
+            if (e + 2 >= p.D) m.z = 0.f;
+            if (e + 3 >= p.D) m.w = 0.f;
+            sp = dot4_muladd(o, m, sp);
+          }
+          const float s = row16_sum(sp);
+          if (l16 == 0 && live[r]) p.score[row[r]] = s;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// lsh, wide feature rows (F > 256): chunks streamed per block of 8 planes, the row is re-read
+// from L1/L2 for every plane block.  Same canonical order (lane chain over increasing chunk).
+// ------------------------------------------------------------------------------------------
+template <int DC, bool VEC>
+__global__ __launch_bounds__(kBlock) void lsh_wide_kernel(LshParams p, int FP) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int DP = DC * 64;
+  constexpr int HB = 8;
+  float* sP = smem;
+  float* sW = smem + p.H * FP;
+  stage_padded(sP, p.planes, p.H, p.F, FP);
+  if (p.buckets) stage_padded(sW, p.buckets, p.H, p.D, DP);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int l16 = lane & 15;
+  const int grp = lane >> 4;
+  const int wv = threadIdx.x >> 6;
+  const int64_t ntiles = (p.B + 3) / 4;
+  const int H = static_cast<int>(p.H);
+  const int nchunk = FP / 64;
+  const bool want_emb = (p.out != nullptr) || (p.score != nullptr);
+
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+       tile += static_cast<int64_t>(gridDim.x) * 4) {
+    const int64_t row = tile * 4 + grp;
+    const bool live = row < p.B;
+    const int64_t id = live ? p.ids[row] : -1;
+    const bool oov = (p.table == nullptr) || (id >= p.n_vocab);
+    const bool valid = live && (oov ? (static_cast<uint64_t>(id) < static_cast<uint64_t>(p.N)) : (id >= 0));
+    const bool ld = valid && oov;
+    const float* frow = p.feat + (ld ? id : 0) * p.F;
+
+    float4 acc[DC];
+    float cnt = 0.f;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    for (int h0 = 0; h0 < H; h0 += HB) {
+      float part[HB];
+#pragma unroll
+      for (int j = 0; j < HB; ++j) part[j] = 0.f;
+      for (int c = 0; c < nchunk; ++c) {
+        const int e = (c * 16 + l16) * 4;
+        const float4 xv = ld ? load4<VEC>(frow, e, p.F) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          if (h0 + j < H) {
+            const float4 pw = *reinterpret_cast<const float4*>(sP + (h0 + j) * FP + e);
+            part[j] = dot4_fma(xv, pw, part[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+        const int h = h0 + j;
+        const float s = row16_sum(part[j]);
+        if (h < H) {
+          const float bit = (s < 0.f) ? 0.f : 1.f;
+          cnt = cnt + bit;
+          if (want_emb) {
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+              const float4 bw = *reinterpret_cast<const float4*>(sW + h * DP + (c * 16 + l16) * 4);
+              acc[c].x = __builtin_fmaf(bit, bw.x, acc[c].x);
+              acc[c].y = __builtin_fmaf(bit, bw.y, acc[c].y);
+              acc[c].z = __builtin_fmaf(bit, bw.z, acc[c].z);
+              acc[c].w = __builtin_fmaf(bit, bw.w, acc[c].w);
+            }
+          }
+          if (p.bits && l16 == 0 && live)
+            p.bits[row * p.H + h] = valid ? static_cast<uint8_t>(bit) : static_cast<uint8_t>(0xFF);
+        }
+      }
+    }
+
+    if (want_emb) {
+      float4 emb[DC];
+      float sp = 0.f;
+      const float* orow = p.other ? p.other + (live ? row : 0) * p.D : nullptr;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        const int e = (c * 16 + l16) * 4;
+        if (oov) {
+          emb[c].x = acc[c].x / cnt;
+          emb[c].y = acc[c].y / cnt;
+          emb[c].z = acc[c].z / cnt;
+          emb[c].w = acc[c].w / cnt;
+        } else {
+          emb[c] = valid ? load4<VEC>(p.table + id * p.D, e, p.D) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!valid) emb[c] = make_float4(qnan(), qnan(), qnan(), qnan());
+        if (p.out && live) store4<VEC>(p.out + row * p.D, e, p.D, emb[c]);
+        if (p.score) {
+          float4 o = live ? load4<VEC>(orow, e, p.D) : make_float4(0.f, 0.f, 0.f, 0.f);
+          float4 m = emb[c];
+          if (e + 0 >= p.D) m.x = 0.f;
+          if (e + 1 >= p.D) m.y = 0.f;
+          if (e + 2 >= p.D) m.z = 0.f;
+          if (e + 3 >= p.D) m.w = 0.f;
+          sp = dot4_muladd(o, m, sp);
+        }
+      }
+      if (p.score) {
+        const float s = row16_sum(sp);
+        if (l16 == 0 && live) p.score[row] = s;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// slsh: popcount of H = bits_req projections -> bucket index -> single bucket-row gather.
+// Planes in LDS; bucket rows come from HBM (n_buckets may be as large as the catalogue).
+// Chunks of the feature row are streamed (any F).
+// ------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int HB = 8;
+  float* sP = smem;
+  stage_padded(sP, p.planes, p.H, p.F, FP);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const int l16 = lane & 15;
+  const int grp = lane >> 4;
+  const int wv = threadIdx.x >> 6;
+  constexpr int R = 4;
+  const int64_t ntiles = (p.B + 4 * R - 1) / (4 * R);
+  const int H = static_cast<int>(p.H);
+  const int nchunk = FP / 64;
+  const int dchunks = static_cast<int>((p.D + 63) / 64);
+
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+       tile += static_cast<int64_t>(gridDim.x) * 4) {
+    int64_t row[R], id[R];
+    bool live[R], valid[R];
+    int pop[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      live[r] = row[r] < p.B;
+      id[r] = live[r] ? p.ids[row[r]] : -1;
+      valid[r] = live[r] && (static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(p.N));
+      pop[r] = 0;
+    }
+    for (int h0 = 0; h0 < H; h0 += HB) {
+      float part[R][HB];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int j = 0; j < HB; ++j) part[r][j] = 0.f;
+      for (int c = 0; c < nchunk; ++c) {
+        const int e = (c * 16 + l16) * 4;
+        float4 xv[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          xv[r] = valid[r] ? load4<VEC>(p.feat + id[r] * p.F, e, p.F) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < HB; ++j) {
+          if (h0 + j < H) {
+            const float4 pw = *reinterpret_cast<const float4*>(sP + (h0 + j) * FP + e);
+#pragma unroll
+            for (int r = 0; r < R; ++r) part[r][j] = dot4_fma(xv[r], pw, part[r][j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HB; ++j) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const float s = row16_sum(part[r][j]);
+          if (h0 + j < H) pop[r] += (s < 0.f) ? 0 : 1;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      // (2 ** bits).sum(1) = sum of 1 or 2 per plane = H + popcount  (single_lsh_embedder.py:86)
+      const int64_t b = valid[r] ? (static_cast<int64_t>(H) + pop[r]) % p.n_buckets : -1;
+      if (p.idx && l16 == 0 && live[r]) p.idx[row[r]] = b;
+      if (p.out && live[r]) {
+        for (int c = 0; c < dchunks; ++c) {
+          const int e = (c * 16 + l16) * 4;
+          float4 v = valid[r] ? load4<VEC>(p.buckets + b * p.D, e, p.D)
+                              : make_float4(qnan(), qnan(), qnan(), qnan());
+          store4<VEC>(p.out + row[r] * p.D, e, p.D, v);
+        }
+      }
+    }
+  }
+}
+
+template <int FC, int DC, bool VEC>
+static int launch_fused(const LshParams& p, hipStream_t st) {
+  constexpr int R = (FC >= 4 || DC >= 4) ? 2 : 4;
+  const size_t lds = static_cast<size_t>(p.H) * (FC * 64 + DC * 64) * sizeof(float);
+  auto k = lsh_fused_kernel<FC, DC, VEC, R>;
+  if (int rc = set_lds(k, lds)) return rc;
+  const int grid = grid_for(p.B, 16 * R);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p);
+  return check_launch();
+}
+
+template <int DC, bool VEC>
+static int launch_wide(const LshParams& p, int FP, hipStream_t st) {
+  const size_t lds = static_cast<size_t>(p.H) * (FP + DC * 64) * sizeof(float);
+  auto k = lsh_wide_kernel<DC, VEC>;
+  if (int rc = set_lds(k, lds)) return rc;
+  const int grid = grid_for(p.B, 16);
+  hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p, FP);
+  return check_launch();
+}
+
+template <bool VEC>
+static int dispatch_lsh(const LshParams& p, hipStream_t st) {
+  const int fc = static_cast<int>((p.F + 63) / 64);
+  const int dc = static_cast<int>((p.D + 63) / 64);
+  const int fcq = fc <= 1 ? 1 : (fc <= 2 ? 2 : (fc <= 4 ? 4 : 0));
+  const int dcq = dc <= 1 ? 1 : (dc <= 2 ? 2 : 4);
+  const int FPw = fc * 64;
+  const int64_t lds = p.H * ((fcq ? fcq * 64 : FPw) + dcq * 64) * static_cast<int64_t>(sizeof(float));
+  if (lds > kLdsLimit) return MI_OOV_ERR_SHAPE;  // H x (F+D) does not fit the 160 KiB LDS
+#define MI_FUSED(FCV, DCV) \
+  if (fcq == FCV && dcq == DCV) return launch_fused<FCV, DCV, VEC>(p, st);
+  MI_FUSED(1, 1) MI_FUSED(1, 2) MI_FUSED(1, 4)
+  MI_FUSED(2, 1) MI_FUSED(2, 2) MI_FUSED(2, 4)
+  MI_FUSED(4, 1) MI_FUSED(4, 2) MI_FUSED(4, 4)
+#undef MI_FUSED
+  if (dcq == 1) return launch_wide<1, VEC>(p, FPw, st);
+  if (dcq == 2) return launch_wide<2, VEC>(p, FPw, st);
+  return launch_wide<4, VEC>(p, FPw, st);
+}
+
+static int run_lsh(LshParams p, void* stream) {
+  if (p.B < 0 || p.N <= 0 || p.F <= 0 || p.H <= 0) return MI_OOV_ERR_SHAPE;
+  if (p.B == 0) return MI_OOV_OK;
+  if (!p.ids || !p.feat || !p.planes) return MI_OOV_ERR_NULL;
+  const bool want_emb = p.out || p.score;
+  if (want_emb && (!p.buckets || p.D <= 0)) return MI_OOV_ERR_NULL;
+  if (!want_emb && !p.bits) return MI_OOV_ERR_NULL;
+  if (p.score && !p.other) return MI_OOV_ERR_NULL;
+  if (p.table && p.n_vocab < 0) return MI_OOV_ERR_SHAPE;
+  if (p.D > 256) return MI_OOV_ERR_SHAPE;
+  if (p.D <= 0) p.D = 1;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (p.F % 4 == 0) && (p.D % 4 == 0) && aligned16(p.feat) && (!p.out || aligned16(p.out)) &&
+                   (!p.other || aligned16(p.other)) && (!p.table || aligned16(p.table));
+  return vec ? dispatch_lsh<true>(p, st) : dispatch_lsh<false>(p, st);
+}
+
+}  // namespace mi_oov
+
+using mi_oov::LshParams;
+
+extern "C" int mi_oov_lsh_embed(const int64_t* ids, int64_t B, const float* feat, int64_t N, int64_t F,
+                                const float* planes, int64_t H, const float* buckets, int64_t D, float* out,
+                                uint8_t* bits, void* stream) {
+  LshParams p{};
+  p.ids = ids; p.B = B; p.feat = feat; p.N = N; p.F = F; p.planes = planes; p.H = H;
+  p.buckets = buckets; p.n_buckets = H; p.D = D; p.out = out; p.bits = bits;
+  return mi_oov::run_lsh(p, stream);
+}
+
+extern "C" int mi_oov_lsh_embed_score(const int64_t* ids, int64_t B, const float* feat, int64_t N, int64_t F,
+                                      const float* planes, int64_t H, const float* buckets, int64_t D,
+                                      const float* other, float* score, float* out, void* stream) {
+  if (!score) return MI_OOV_ERR_NULL;
+  LshParams p{};
+  p.ids = ids; p.B = B; p.feat = feat; p.N = N; p.F = F; p.planes = planes; p.H = H;
+  p.buckets = buckets; p.n_buckets = H; p.D = D; p.other = other; p.score = score; p.out = out;
+  return mi_oov::run_lsh(p, stream);
+}
+
+extern "C" int mi_oov_lsh_lookup(const int64_t* ids, int64_t B, const float* table, int64_t n_vocab,
+                                 const float* feat, int64_t N, int64_t F, const float* planes, int64_t H,
+                                 const float* buckets, int64_t D, float* out, void* stream) {
+  if (!table || !out) return MI_OOV_ERR_NULL;
+  LshParams p{};
+  p.ids = ids; p.B = B; p.feat = feat; p.N = N; p.F = F; p.planes = planes; p.H = H;
+  p.buckets = buckets; p.n_buckets = H; p.D = D; p.table = table; p.n_vocab = n_vocab; p.out = out;
+  return mi_oov::run_lsh(p, stream);
+}
+
+extern "C" int mi_oov_slsh_embed(const int64_t* ids, int64_t B, const float* feat, int64_t N, int64_t F,
+                                 const float* planes, int64_t H, const float* buckets, int64_t n_buckets,
+                                 int64_t D, float* out, int64_t* idx, void* stream) {
+  using namespace mi_oov;
+  if (B < 0 || N <= 0 || F <= 0 || H <= 0 || n_buckets <= 0) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!ids || !feat || !planes) return MI_OOV_ERR_NULL;
+  if (!out && !idx) return MI_OOV_ERR_NULL;
+  if (out && (!buckets || D <= 0)) return MI_OOV_ERR_NULL;
+  LshParams p{};
+  p.ids = ids; p.B = B; p.feat = feat; p.N = N; p.F = F; p.planes = planes; p.H = H;
+  p.buckets = buckets; p.n_buckets = n_buckets; p.D = D > 0 ? D : 1; p.out = out; p.idx = idx;
+  const int FP = static_cast<int>((F + 63) / 64) * 64;
+  const size_t lds = static_cast<size_t>(H) * FP * sizeof(float);
+  if (static_cast<int64_t>(lds) > kLdsLimit) return MI_OOV_ERR_SHAPE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (F % 4 == 0) && (p.D % 4 == 0) && aligned16(feat) && (!out || (aligned16(out) && aligned16(buckets)));
+  const int grid = grid_for(B, 64);
+  if (vec) {
+    auto k = slsh_kernel<true>;
+    if (int rc = set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p, FP);
+  } else {
+    auto k = slsh_kernel<false>;
+    if (int rc = set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p, FP);
+  }
+  return check_launch();
+}

@@ -1,0 +1,225 @@
+// Full-catalogue scoring: BPR.full_sort_predict / ind_full_sort_predict (bpr.py:151-163) and the
+// row-wise top-k that consumes it (R/evaluator/collector.py:158-167); the same pair serves as the
+// exact neighbour search that stands in for ScaNN (knn_embedder.py:100-102).
+//
+// scores[b,n] = sum_d U[b,d]*E[n,d] is the only dense contraction of the path and runs on the
+// f32 matrix cores: v_mfma_f32_32x32x2_f32 is bit-for-bit an fmaf chain in k order (no reduced
+// precision), so the result equals oracle/oov_oracle.c::oov_full_sort_scores exactly.
+// With K = D = 64 the GEMM is output-bound as much as MFMA-bound (32 flop per stored byte), so the
+// tile is chosen for full-width coalesced stores: 128 x 128 per workgroup, 64 x 64 per wave.
+#include "common.hpp"
+
+namespace mi_oov {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128, BN = 128, KC = 64, LDK = KC + 4;  // LDS row stride 68 floats: b128 reads conflict-free
+
+// Loads 8 consecutive k of one row (guarded), returns them split into even/odd k so that the MFMA
+// lane halves (h = lane>>5 supplies k = 2s+h) read their 4 values with ONE ds_read_b128 and the
+// chain still runs over increasing k.
+template <bool VEC>
+__device__ __forceinline__ void load8_split(const float* M, int64_t row, int64_t nrows, int64_t D, int k0,
+                                            float4& ev, float4& od) {
+  float v[8];
+  if (row < nrows) {
+    const float* src = M + row * D;
+    if (VEC && k0 + 8 <= D) {
+      const float4 a = *reinterpret_cast<const float4*>(src + k0);
+      const float4 b = *reinterpret_cast<const float4*>(src + k0 + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = (k0 + i < D) ? src[k0 + i] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+  }
+  ev = make_float4(v[0], v[2], v[4], v[6]);
+  od = make_float4(v[1], v[3], v[5], v[7]);
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void full_sort_kernel(const float* __restrict__ U, int64_t B,
+                                                           const float* __restrict__ E, int64_t N, int64_t D,
+                                                           float* __restrict__ S, int64_t ldS) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* sA = smem;             // [BM][LDK]
+  float* sB = smem + BM * LDK;  // [BN][LDK]
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int i32 = lane & 31, hh = lane >> 5;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * BN;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.y) * BM;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  for (int kc = 0; kc < D; kc += KC) {
+    if (kc) __syncthreads();
+    // stage: 128 rows x 8 units of 8 floats per operand = 1024 units, 4 per thread per operand
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int u = tid + kBlock * j;
+      const int r = u >> 3, t8 = u & 7;
+      float4 ev, od;
+      load8_split<VEC>(U, b0 + r, B, D, kc + t8 * 8, ev, od);
+      *reinterpret_cast<float4*>(sA + r * LDK + t8 * 8) = ev;
+      *reinterpret_cast<float4*>(sA + r * LDK + t8 * 8 + 4) = od;
+      load8_split<VEC>(E, n0 + r, N, D, kc + t8 * 8, ev, od);
+      *reinterpret_cast<float4*>(sB + r * LDK + t8 * 8) = ev;
+      *reinterpret_cast<float4*>(sB + r * LDK + t8 * 8 + 4) = od;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < KC / 8; ++t) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        a[m] = *reinterpret_cast<const float4*>(sA + (wm * 64 + m * 32 + i32) * LDK + t * 8 + hh * 4);
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+        b[n] = *reinterpret_cast<const float4*>(sB + (wn * 64 + n * 32 + i32) * LDK + t * 8 + hh * 4);
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b[n].x, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b[n].y, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].z, b[n].z, acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].w, b[n].w, acc[m][n], 0, 0, 0);
+        }
+    }
+  }
+
+  // C/D map of the 32x32 shapes: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int64_t col = n0 + wn * 64 + n * 32 + i32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < B && col < N) S[row * ldS + col] = acc[m][n][r];
+      }
+    }
+}
+
+// ---- row-wise top-k over materialised scores ----------------------------------------------------
+// Order: larger value first, NaN above everything (torch.topk), ties -> lower column index.
+__device__ __forceinline__ uint32_t order_key(float v) {
+  const uint32_t u = __float_as_uint(v);
+  if ((u & 0x7FFFFFFFu) > 0x7F800000u) return 0xFFFFFFFFu;  // NaN
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__device__ __forceinline__ uint64_t u64_max(uint64_t a, uint64_t b) { return a > b ? a : b; }
+
+// One workgroup per row; k selection passes, each a max-reduction of (key<<32 | ~col) over the
+// candidates strictly below the previous winner.
+__global__ __launch_bounds__(kBlock) void topk_rows_kernel(const float* __restrict__ S, int64_t rows, int64_t N,
+                                                           int64_t ldS, int64_t k, int64_t n_skip_low,
+                                                           float* __restrict__ vals, int64_t* __restrict__ idx) {
+  __shared__ uint64_t red[kBlock / 64];
+  __shared__ uint64_t winner;
+  const int64_t row = blockIdx.x;
+  if (row >= rows) return;
+  const float* srow = S + row * ldS;
+  uint64_t prev = ~0ULL;
+  for (int64_t t = 0; t < k; ++t) {
+    uint64_t best = 0;
+    for (int64_t c = n_skip_low + threadIdx.x; c < N; c += kBlock) {
+      const uint64_t cand = (static_cast<uint64_t>(order_key(srow[c])) << 32) |
+                            (0xFFFFFFFFu - static_cast<uint32_t>(c));
+      if (t == 0 || cand < prev) best = u64_max(best, cand);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = u64_max(best, __shfl_xor(best, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint64_t b = red[0];
+#pragma unroll
+      for (int w = 1; w < kBlock / 64; ++w) b = u64_max(b, red[w]);
+      winner = b;
+      const int64_t c = 0xFFFFFFFFu - static_cast<uint32_t>(b & 0xFFFFFFFFu);
+      const bool found = (b != 0);
+      vals[row * k + t] = found ? srow[c] : -__builtin_inff();
+      idx[row * k + t] = found ? c : -1;
+    }
+    __syncthreads();
+    prev = winner;  // 0 when exhausted: no candidate is < 0, later passes emit (-inf, -1)
+  }
+}
+
+static size_t full_sort_lds() { return static_cast<size_t>(BM + BN) * LDK * sizeof(float); }
+
+static int launch_full_sort(const float* U, int64_t B, const float* E, int64_t N, int64_t D, float* S, int64_t ldS,
+                            hipStream_t st) {
+  const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
+  const dim3 grid(static_cast<unsigned>((N + BN - 1) / BN), static_cast<unsigned>((B + BM - 1) / BM));
+  const size_t lds = full_sort_lds();
+  if (vec) {
+    auto k = full_sort_kernel<true>;
+    if (int rc = set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, U, B, E, N, D, S, ldS);
+  } else {
+    auto k = full_sort_kernel<false>;
+    if (int rc = set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, U, B, E, N, D, S, ldS);
+  }
+  return check_launch();
+}
+
+constexpr int64_t kTopkChunkBytes = 1LL << 30;  // scores workspace per user chunk
+
+static int64_t topk_chunk_rows(int64_t B, int64_t N) {
+  int64_t rows = kTopkChunkBytes / (N * static_cast<int64_t>(sizeof(float)));
+  if (rows < 1) rows = 1;
+  if (rows > B) rows = B;
+  return rows;
+}
+
+}  // namespace mi_oov
+
+using namespace mi_oov;
+
+extern "C" int mi_oov_full_sort_scores(const float* U, int64_t B, const float* E, int64_t N, int64_t D, float* scores,
+                                       void* stream) {
+  if (B < 0 || N <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!U || !E || !scores) return MI_OOV_ERR_NULL;
+  if ((B + BM - 1) / BM > 65535) return MI_OOV_ERR_SHAPE;
+  return launch_full_sort(U, B, E, N, D, scores, N, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k) {
+  if (B <= 0 || N <= 0 || k <= 0) return 0;
+  return topk_chunk_rows(B, N) * N * static_cast<int64_t>(sizeof(float));
+}
+
+extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                                 int64_t n_skip_low, float* vals, int64_t* idx, void* workspace, void* stream) {
+  if (B < 0 || N <= 0 || D <= 0 || k <= 0 || n_skip_low < 0 || N >= (1LL << 32)) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!U || !E || !vals || !idx || !workspace) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* S = static_cast<float*>(workspace);
+  const int64_t chunk = topk_chunk_rows(B, N);
+  for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+    const int64_t rows = (b0 + chunk <= B) ? chunk : (B - b0);
+    if (int rc = launch_full_sort(U + b0 * D, rows, E, N, D, S, N, st)) return rc;
+    hipLaunchKernelGGL(topk_rows_kernel, dim3(static_cast<unsigned>(rows)), dim3(kBlock), 0, st, S, rows, N, N, k,
+                       n_skip_low, vals + b0 * k, idx + b0 * k);
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
+}

@@ -1,0 +1,178 @@
+"""BPR with the inductive lookup path, the caller of the plugin.
+
+Mirrors, name for name, the parts of the reference model that sit on the hot path:
+    InductiveGeneralRecommender   R/model/abstract_recommender.py:117-163 (OOV bucket tables :134-139,
+                                  set_oov_train/set_oov_eval :147-163)
+    BPR                           R/model/general_recommender/bpr.py:31-163
+Every per-batch tensor op of the reference's get_*_embedding / predict / full_sort_predict is a
+libmi_oov kernel here (gather, splice, lsh, row dot, f32-MFMA scoring).  Training orchestration
+(Trainer, optimisers, samplers) is out of scope and stays whatever drives this module.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .embedders import LSHInductiveEmbedder
+
+
+def xavier_normal_initialization(module):
+    """R/model/init.py: Embedding and Linear weights xavier-normal, Linear bias 0.  Applied with
+    self.apply(), it re-initialises bucket tables and embedder MLPs but never the LSH planes
+    (a ParameterList), exactly as in the reference (bpr.py:46)."""
+    if isinstance(module, nn.Embedding):
+        nn.init.xavier_normal_(module.weight.data)
+    elif isinstance(module, nn.Linear):
+        nn.init.xavier_normal_(module.weight.data)
+        if module.bias is not None:
+            nn.init.constant_(module.bias.data, 0)
+
+
+class BPRLoss(nn.Module):
+    """R/model/loss.py:21-47."""
+
+    def __init__(self, gamma=1e-10):
+        super().__init__()
+        self.gamma = gamma
+
+    def forward(self, pos_score, neg_score):
+        return -torch.log(self.gamma + torch.sigmoid(pos_score - neg_score)).mean()
+
+
+class InductiveGeneralRecommender(nn.Module):
+    def __init__(self, config, dataset, inductive_mapper=None, inductive_embedder=None):
+        super().__init__()
+        self.USER_ID = config["USER_ID_FIELD"]
+        self.ITEM_ID = config["ITEM_ID_FIELD"]
+        self.NEG_ITEM_ID = config["NEG_PREFIX"] + self.ITEM_ID
+        self.n_users = dataset.num(self.USER_ID)
+        self.n_items = dataset.num(self.ITEM_ID)
+        self.device = config["device"]
+
+        self.n_user_oov_buckets = 0
+        self.n_item_oov_buckets = 0
+        self.embedding_size = config["embedding_size"]
+        self.inductive_mapper = inductive_mapper
+        self.inductive_embedder = inductive_embedder
+        self.oov_freeze_embedding = config["oov_freeze_embedding"]
+        self.oov_training = False
+        if self.inductive_mapper is None and self.inductive_embedder is None:
+            raise NotImplementedError("Must provide either self.inductive_mapper or self.inductive_embedder")
+        self.n_new_items = (self.inductive_mapper.n_new_items if self.inductive_mapper
+                            else self.inductive_embedder.n_new_items)
+        if config["add_oov_buckets"]:
+            self.n_user_oov_buckets = config["user_oov_buckets"]
+            self.user_oov_buckets = nn.Embedding(self.n_user_oov_buckets, self.embedding_size)
+            self.n_item_oov_buckets = config["item_oov_buckets"]
+            self.item_oov_buckets = nn.Embedding(self.n_item_oov_buckets, self.embedding_size)
+
+    def set_oov_train(self, no_freeze=False):
+        self.oov_training = True
+        if self.inductive_mapper is not None:
+            self.inductive_mapper.set_train()
+        if self.inductive_embedder is not None:
+            self.inductive_embedder.set_train()
+        if self.oov_freeze_embedding and not no_freeze:
+            self.freeze_non_oov_layers()
+
+    def set_oov_eval(self, no_freeze=False):
+        self.oov_training = False
+        if self.inductive_mapper is not None:
+            self.inductive_mapper.set_eval()
+        if self.inductive_embedder is not None:
+            self.inductive_embedder.set_eval()
+        if self.oov_freeze_embedding and not no_freeze:
+            self.unfreeze_non_oov_layers()
+
+    def freeze_non_oov_layers(self):
+        raise NotImplementedError()
+
+    def unfreeze_non_oov_layers(self):
+        raise NotImplementedError()
+
+
+class BPR(InductiveGeneralRecommender):
+    def __init__(self, config, dataset, inductive_mapper=None, inductive_embedder=None):
+        super().__init__(config, dataset, inductive_mapper, inductive_embedder)
+        self.embedding_size = config["embedding_size"]
+        self.user_embedding = nn.Embedding(self.n_users, self.embedding_size)
+        self.item_embedding = nn.Embedding(self.n_items, self.embedding_size)
+        self.loss = BPRLoss()
+        self.apply(xavier_normal_initialization)
+
+    # ---- lookups (bpr.py:48-125) --------------------------------------------------------------
+    def _lookup(self, ids, side):
+        user = side == "user"
+        table = (self.user_embedding if user else self.item_embedding).weight
+        n_vocab = self.n_users if user else self.n_items
+        if self.inductive_mapper is not None:
+            ids = self.inductive_mapper.map_user_ids(ids) if user else self.inductive_mapper.map_item_ids(ids)
+        emb = self.inductive_embedder
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if isinstance(emb, LSHInductiveEmbedder) and not needs_grad and not emb.training:
+            # one launch: in-vocabulary rows and lsh rows spliced inside the kernel
+            feat = emb.user_feature_mat if user else emb.item_feature_mat
+            planes = (emb.user_lsh if user else emb.item_lsh).uniform_planes[0].data
+            buckets = (self.user_oov_buckets if user else self.item_oov_buckets).weight
+            return ops.lsh_lookup(ids, table, feat, planes, buckets)
+        oov_mask = ids >= n_vocab
+        oov_ids = ids[oov_mask]  # fresh copy: the embedder may strip prime_pad in place
+        if oov_ids.numel() == 0:
+            return ops.gather_rows(ids, table)
+        if emb is not None:
+            oov_rows = emb.embed_user_ids(oov_ids, self) if user else emb.embed_item_ids(oov_ids, self)
+        else:
+            buckets = (self.user_oov_buckets if user else self.item_oov_buckets).weight
+            oov_rows = ops.gather_rows(oov_ids - n_vocab, buckets)
+        return ops.splice_rows(ids, table, oov_rows)
+
+    def get_user_embedding(self, new_user_ids):
+        return self._lookup(new_user_ids, "user")
+
+    def get_item_embedding(self, item):
+        return self._lookup(item, "item")
+
+    def _user_id_lookup(self, user_ids):
+        return ops.gather_rows(user_ids, self.user_embedding.weight)
+
+    def _item_id_lookup(self, item_ids):
+        return ops.gather_rows(item_ids, self.item_embedding.weight)
+
+    def freeze_non_oov_layers(self):
+        self.user_embedding.weight.requires_grad = False
+        self.item_embedding.weight.requires_grad = False
+
+    def unfreeze_non_oov_layers(self):
+        self.user_embedding.weight.requires_grad = True
+        self.item_embedding.weight.requires_grad = True
+
+    def forward(self, user, item):
+        return self.get_user_embedding(user), self.get_item_embedding(item)
+
+    # ---- loss / scoring (bpr.py:132-163) ----------------------------------------------------------
+    def calculate_loss(self, interaction):
+        user = interaction[self.USER_ID]
+        pos_item = interaction[self.ITEM_ID]
+        neg_item = interaction[self.NEG_ITEM_ID]
+        user_e, pos_e = self.forward(user, pos_item)
+        neg_e = self.get_item_embedding(neg_item)
+        return self.loss(ops.rowdot(user_e, pos_e), ops.rowdot(user_e, neg_e))
+
+    def predict(self, interaction):
+        user_e, item_e = self.forward(interaction[self.USER_ID], interaction[self.ITEM_ID])
+        return ops.rowdot(user_e, item_e)
+
+    def ind_full_sort_predict(self, interaction, item_ids):
+        user_e = self.get_user_embedding(interaction[self.USER_ID])
+        all_item_e = self.get_item_embedding(item_ids)
+        return ops.full_sort_scores(user_e, all_item_e).view(-1)
+
+    def full_sort_predict(self, interaction):
+        user_e = self.get_user_embedding(interaction[self.USER_ID])
+        return ops.full_sort_scores(user_e, self.item_embedding.weight).view(-1)
+
+    def full_sort_topk(self, interaction, k, skip_padding=True):
+        """Fused scores + per-user top-k over the in-vocabulary catalogue: what the evaluator does
+        with full_sort_predict's output (trainer.py:541-544 masks item 0, collector.py:158-167 topk)
+        without ever materialising [B, n_items]."""
+        user_e = self.get_user_embedding(interaction[self.USER_ID])
+        return ops.score_topk(user_e, self.item_embedding.weight, k, 1 if skip_padding else 0)

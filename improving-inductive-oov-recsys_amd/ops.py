@@ -1,0 +1,396 @@
+"""Torch-facing operators over the C ABI (include/mi_oov.h).  One function per entry point.
+
+Forward passes are the hand-written HIP kernels.  Where the reference's outputs carry gradients
+(SURVEY.md section 8b "Autograd": bucket tables for lsh/slsh, the item table for knn, both sides for
+the scores) a torch.autograd.Function supplies the backward with device-side torch ops
+(index_add_/matmul on the same ROCm device); hand-written backward kernels are the next row of
+the scope table.  Nothing here ever computes on the CPU.
+"""
+import torch
+
+from . import _cabi as C
+
+HASH_KINDS = {"mod": 0, "fast": 1, "3round": 2, "64bit": 3}
+
+
+def _ids(t, name="ids"):
+    return C.dev_tensor(t, torch.int64, name)
+
+
+def _f32(t, name):
+    return C.dev_tensor(t.detach() if t.requires_grad else t, torch.float32, name)
+
+
+# ------------------------------------------------------------------------------------------
+# raw forwards
+# ------------------------------------------------------------------------------------------
+def _lsh_forward(ids, feat, planes, buckets, want_out=True, want_bits=False):
+    ids, feat, planes = _ids(ids), _f32(feat, "feat"), _f32(planes, "planes")
+    B, (N, F), H = ids.numel(), feat.shape, planes.shape[0]
+    if planes.shape[1] != F:
+        raise ValueError(f"planes have {planes.shape[1]} columns, features have {F}")
+    out = bits = None
+    D = 0
+    if want_out:
+        buckets = _f32(buckets, "buckets")
+        if buckets.shape[0] != H:
+            raise ValueError(f"lsh needs one bucket row per plane: {buckets.shape[0]} vs {H}")
+        D = buckets.shape[1]
+        out = torch.empty((B, D), dtype=torch.float32, device=ids.device)
+    if want_bits:
+        bits = torch.empty((B, H), dtype=torch.uint8, device=ids.device)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_lsh_embed(C.ptr(ids), B, C.ptr(feat), N, F, C.ptr(planes), H,
+                                      C.ptr(buckets) if want_out else None, D, C.ptr(out), C.ptr(bits),
+                                      C.stream_of(ids))
+    C.check(rc, "mi_oov_lsh_embed")
+    return out, bits
+
+
+def lsh_bits(ids, feat, planes):
+    """TorchLSHash.hash_points(planes, feat[ids]) as u8[B,H] (R/inductive/torch_hash.py:55-60)."""
+    return _lsh_forward(ids, feat, planes, None, want_out=False, want_bits=True)[1]
+
+
+class _LshEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, feat, planes, buckets):
+        need_grad = buckets.requires_grad
+        out, bits = _lsh_forward(ids, feat, planes, buckets, want_bits=need_grad)
+        if need_grad:
+            ctx.save_for_backward(bits)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (bits,) = ctx.saved_tensors
+        w = bits.to(torch.float32)
+        w = w / w.sum(dim=1, keepdim=True)  # d/dW of (bits @ W) / bits.sum(1); 0/0 rows stay NaN
+        return None, None, None, w.t() @ g.contiguous()
+
+
+def lsh_embed(ids, feat, planes, buckets):
+    """(bits @ buckets) / popcount for feat[ids] (R/inductive/lsh_embedder.py:116-179)."""
+    if torch.is_grad_enabled() and buckets.requires_grad:
+        return _LshEmbed.apply(ids, feat, planes, buckets)
+    return _lsh_forward(ids, feat, planes, buckets)[0]
+
+
+def lsh_embed_score(ids, feat, planes, buckets, other, want_emb=False):
+    """Fused lsh embedding + BPR.predict row dot (bpr.py:145-149).  Inference only."""
+    ids, feat, planes, buckets, other = (_ids(ids), _f32(feat, "feat"), _f32(planes, "planes"),
+                                         _f32(buckets, "buckets"), _f32(other, "other"))
+    B, (N, F), H, D = ids.numel(), feat.shape, planes.shape[0], buckets.shape[1]
+    if other.shape != (B, D):
+        raise ValueError(f"other must be [{B},{D}], got {tuple(other.shape)}")
+    score = torch.empty((B,), dtype=torch.float32, device=ids.device)
+    out = torch.empty((B, D), dtype=torch.float32, device=ids.device) if want_emb else None
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_lsh_embed_score(C.ptr(ids), B, C.ptr(feat), N, F, C.ptr(planes), H, C.ptr(buckets), D,
+                                            C.ptr(other), C.ptr(score), C.ptr(out), C.stream_of(ids))
+    C.check(rc, "mi_oov_lsh_embed_score")
+    return (score, out) if want_emb else score
+
+
+def lsh_lookup(ids, table, feat, planes, buckets):
+    """BPR.get_*_embedding with an lsh plugin in one launch (bpr.py:48-125).  Inference only."""
+    ids, table, feat, planes, buckets = (_ids(ids), _f32(table, "table"), _f32(feat, "feat"),
+                                         _f32(planes, "planes"), _f32(buckets, "buckets"))
+    B, (N, F), H, D = ids.numel(), feat.shape, planes.shape[0], buckets.shape[1]
+    out = torch.empty((B, D), dtype=torch.float32, device=ids.device)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_lsh_lookup(C.ptr(ids), B, C.ptr(table), table.shape[0], C.ptr(feat), N, F, C.ptr(planes),
+                                       H, C.ptr(buckets), D, C.ptr(out), C.stream_of(ids))
+    C.check(rc, "mi_oov_lsh_lookup")
+    return out
+
+
+def _slsh_forward(ids, feat, planes, buckets, n_buckets, want_out=True):
+    ids, feat, planes = _ids(ids), _f32(feat, "feat"), _f32(planes, "planes")
+    B, (N, F), H = ids.numel(), feat.shape, planes.shape[0]
+    idx = torch.empty((B,), dtype=torch.int64, device=ids.device)
+    out = None
+    D = 0
+    if want_out:
+        buckets = _f32(buckets, "buckets")
+        n_buckets, D = buckets.shape
+        out = torch.empty((B, D), dtype=torch.float32, device=ids.device)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_slsh_embed(C.ptr(ids), B, C.ptr(feat), N, F, C.ptr(planes), H,
+                                       C.ptr(buckets) if want_out else None, n_buckets, D, C.ptr(out), C.ptr(idx),
+                                       C.stream_of(ids))
+    C.check(rc, "mi_oov_slsh_embed")
+    return out, idx
+
+
+def slsh_index(ids, feat, planes, n_buckets):
+    """(2 ** bits).sum(1).long() % n_buckets (R/inductive/single_lsh_embedder.py:82-87)."""
+    return _slsh_forward(ids, feat, planes, None, n_buckets, want_out=False)[1]
+
+
+class _SlshEmbed(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, feat, planes, buckets):
+        out, idx = _slsh_forward(ids, feat, planes, buckets, buckets.shape[0])
+        ctx.save_for_backward(idx)
+        ctx.shape = buckets.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        gw = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        gw.index_add_(0, idx, g.contiguous())
+        return None, None, None, gw
+
+
+def slsh_embed(ids, feat, planes, buckets):
+    if torch.is_grad_enabled() and buckets.requires_grad:
+        return _SlshEmbed.apply(ids, feat, planes, buckets)
+    return _slsh_forward(ids, feat, planes, buckets, buckets.shape[0])[0]
+
+
+def siphash24_mod(ids, keys, mod=16777216):
+    """f32[B,K] of SipHash-2-4(key_j, LE64(id)) % mod (R/inductive/dh_embedder.py:140-170)."""
+    ids = _ids(ids)
+    keys = C.dev_tensor(keys, torch.uint8, "keys")
+    if keys.dim() != 2 or keys.shape[1] != 16:
+        raise ValueError("keys must be u8[K,16]")
+    B, K = ids.numel(), keys.shape[0]
+    out = torch.empty((B, K), dtype=torch.float32, device=ids.device)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_siphash24_mod(C.ptr(ids), B, C.ptr(keys), K, mod, C.ptr(out), C.stream_of(ids))
+    C.check(rc, "mi_oov_siphash24_mod")
+    return out
+
+
+def mapper_hash(ids, kind):
+    ids = _ids(ids)
+    out = torch.empty_like(ids)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_mapper_hash(C.ptr(ids), ids.numel(), HASH_KINDS[kind], C.ptr(out), C.stream_of(ids))
+    C.check(rc, "mi_oov_mapper_hash")
+    return out
+
+
+def mapper_map(ids, kind, n_orig, n_buckets):
+    """RandomOOVInductiveMapper.map_*_ids (R/inductive/random_mapper.py:116-130)."""
+    if kind not in HASH_KINDS:
+        raise ValueError(f"Unknown hash function {kind}")
+    ids = _ids(ids)
+    out = torch.empty_like(ids)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_mapper_map(C.ptr(ids), ids.numel(), HASH_KINDS[kind], int(n_orig), int(n_buckets),
+                                       C.ptr(out), C.stream_of(ids))
+    C.check(rc, "mi_oov_mapper_map")
+    return out
+
+
+def _gather_mean_forward(idx, W, g):
+    idx, W = _ids(idx.reshape(-1), "idx"), _f32(W, "W")
+    M, (N, D) = idx.numel(), W.shape
+    out = torch.empty(((M + g - 1) // g, D), dtype=torch.float32, device=idx.device)
+    with C.on_device(idx):
+        rc = C.lib().mi_oov_gather_mean(C.ptr(idx), M, g, C.ptr(W), N, D, C.ptr(out), C.stream_of(idx))
+    C.check(rc, "mi_oov_gather_mean")
+    return out
+
+
+class _GatherMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, W, g):
+        ctx.save_for_backward(idx.reshape(-1))
+        ctx.g, ctx.shape = g, W.shape
+        return _gather_mean_forward(idx, W, g)
+
+    @staticmethod
+    def backward(ctx, grad):
+        (idx,) = ctx.saved_tensors
+        M, g = idx.numel(), ctx.g
+        grp = torch.arange(M, device=idx.device) // g
+        cnt = torch.bincount(grp, minlength=grad.shape[0]).to(grad.dtype)
+        gw = torch.zeros(ctx.shape, dtype=grad.dtype, device=grad.device)
+        gw.index_add_(0, idx, (grad / cnt[:, None])[grp])
+        return None, gw, None
+
+
+def gather_mean(idx, W, g=2):
+    """vstack(chunk.mean(0) for chunk in W[idx.ravel()].split(g)) (knn_embedder.py:125-126)."""
+    if torch.is_grad_enabled() and W.requires_grad:
+        return _GatherMean.apply(idx, W, g)
+    return _gather_mean_forward(idx, W, g)
+
+
+def _gather_rows_forward(ids, W):
+    ids, W = _ids(ids), _f32(W, "W")
+    out = torch.empty((ids.numel(), W.shape[1]), dtype=torch.float32, device=ids.device)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_gather_rows(C.ptr(ids), ids.numel(), C.ptr(W), W.shape[0], W.shape[1], C.ptr(out),
+                                        C.stream_of(ids))
+    C.check(rc, "mi_oov_gather_rows")
+    return out
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, W):
+        ctx.save_for_backward(ids)
+        ctx.shape = W.shape
+        return _gather_rows_forward(ids, W)
+
+    @staticmethod
+    def backward(ctx, g):
+        (ids,) = ctx.saved_tensors
+        gw = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        gw.index_add_(0, ids, g.contiguous())
+        return None, gw
+
+
+def gather_rows(ids, W):
+    """nn.Embedding forward: W[ids]."""
+    if torch.is_grad_enabled() and W.requires_grad:
+        return _GatherRows.apply(ids, W)
+    return _gather_rows_forward(ids, W)
+
+
+def _splice_forward(ids, rank, table, oov_rows):
+    D = table.shape[1]
+    out = torch.empty((ids.numel(), D), dtype=torch.float32, device=ids.device)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_splice_rows(C.ptr(ids), C.ptr(rank), ids.numel(), C.ptr(table), table.shape[0],
+                                        C.ptr(oov_rows) if oov_rows.numel() else None, oov_rows.shape[0], D,
+                                        C.ptr(out), C.stream_of(ids))
+    C.check(rc, "mi_oov_splice_rows")
+    return out
+
+
+class _Splice(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, rank, table, oov_rows):
+        ctx.save_for_backward(ids, rank)
+        ctx.tshape, ctx.oshape = table.shape, oov_rows.shape
+        return _splice_forward(ids, rank, _f32(table, "table"), _f32(oov_rows, "oov_rows"))
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, rank = ctx.saved_tensors
+        g = g.contiguous()
+        iv = ids < ctx.tshape[0]
+        gt = torch.zeros(ctx.tshape, dtype=g.dtype, device=g.device)
+        gt.index_add_(0, ids[iv], g[iv])
+        go = torch.zeros(ctx.oshape, dtype=g.dtype, device=g.device)
+        go.index_add_(0, rank[~iv], g[~iv])
+        return None, None, gt, go
+
+
+def splice_rows(ids, table, oov_rows):
+    """zeros -> table rows where id < n_vocab -> oov_rows (in order of appearance) elsewhere
+    (bpr.py:62-76,108-123)."""
+    ids = _ids(ids)
+    oov = ids >= table.shape[0]
+    rank = torch.cumsum(oov, 0) - oov.to(torch.int64)
+    if torch.is_grad_enabled() and (table.requires_grad or oov_rows.requires_grad):
+        return _Splice.apply(ids, rank, table, oov_rows)
+    return _splice_forward(ids, rank, _f32(table, "table"), _f32(oov_rows, "oov_rows"))
+
+
+def col_mean(W):
+    """torch.mean(W, dim=0) with a fixed summation order (mean_embedder.py:54-56,76-78)."""
+    W = _f32(W, "W")
+    N, D = W.shape
+    mean = torch.empty((D,), dtype=torch.float32, device=W.device)
+    ws = torch.empty((max(1, C.lib().mi_oov_col_mean_workspace(N, D)),), dtype=torch.float32, device=W.device)
+    with C.on_device(W):
+        rc = C.lib().mi_oov_col_mean(C.ptr(W), N, D, C.ptr(mean), C.ptr(ws), C.stream_of(W))
+    C.check(rc, "mi_oov_col_mean")
+    return mean
+
+
+def broadcast_rows(vec, B, D=None, device=None):
+    """vec.repeat(B, 1); vec=None gives zeros(D).repeat(B, 1) (zero_embedder.py:36-60)."""
+    if vec is not None:
+        vec = _f32(vec, "vec")
+        D, device = vec.numel(), vec.device
+    out = torch.empty((B, D), dtype=torch.float32, device=device)
+    if out.device.type != "cuda":
+        raise RuntimeError("mi_oov kernels run on an MI355X (ROCm) device only; there is no CPU fallback")
+    with C.on_device(out):
+        rc = C.lib().mi_oov_broadcast_rows(C.ptr(vec), B, D, C.ptr(out), C.stream_of(out))
+    C.check(rc, "mi_oov_broadcast_rows")
+    return out
+
+
+def _rowdot_forward(U, E):
+    U, E = _f32(U, "U"), _f32(E, "E")
+    if U.shape != E.shape:
+        raise ValueError(f"shape mismatch {tuple(U.shape)} vs {tuple(E.shape)}")
+    s = torch.empty((U.shape[0],), dtype=torch.float32, device=U.device)
+    with C.on_device(U):
+        rc = C.lib().mi_oov_rowdot(C.ptr(U), C.ptr(E), U.shape[0], U.shape[1], C.ptr(s), C.stream_of(U))
+    C.check(rc, "mi_oov_rowdot")
+    return s
+
+
+class _RowDot(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, E):
+        ctx.save_for_backward(U, E)
+        return _rowdot_forward(U, E)
+
+    @staticmethod
+    def backward(ctx, g):
+        U, E = ctx.saved_tensors
+        return g[:, None] * E, g[:, None] * U
+
+
+def rowdot(U, E):
+    """torch.mul(U, E).sum(dim=1) (bpr.py:145-149)."""
+    if torch.is_grad_enabled() and (U.requires_grad or E.requires_grad):
+        return _RowDot.apply(U, E)
+    return _rowdot_forward(U, E)
+
+
+def _full_sort_forward(U, E):
+    U, E = _f32(U, "U"), _f32(E, "E")
+    if U.shape[1] != E.shape[1]:
+        raise ValueError("embedding widths differ")
+    S = torch.empty((U.shape[0], E.shape[0]), dtype=torch.float32, device=U.device)
+    with C.on_device(U):
+        rc = C.lib().mi_oov_full_sort_scores(C.ptr(U), U.shape[0], C.ptr(E), E.shape[0], U.shape[1], C.ptr(S),
+                                             C.stream_of(U))
+    C.check(rc, "mi_oov_full_sort_scores")
+    return S
+
+
+class _FullSort(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, U, E):
+        ctx.save_for_backward(U, E)
+        return _full_sort_forward(U, E)
+
+    @staticmethod
+    def backward(ctx, g):
+        U, E = ctx.saved_tensors
+        return g @ E, g.t() @ U
+
+
+def full_sort_scores(U, E):
+    """torch.matmul(U, E.T) on the f32 matrix cores (bpr.py:151-163)."""
+    if torch.is_grad_enabled() and (U.requires_grad or E.requires_grad):
+        return _FullSort.apply(U, E)
+    return _full_sort_forward(U, E)
+
+
+def score_topk(U, E, k, n_skip_low=0):
+    """Per-row top-k of U @ E.T without returning the [B,N] matrix.  Returns (vals, idx)."""
+    U, E = _f32(U, "U"), _f32(E, "E")
+    B, N, D = U.shape[0], E.shape[0], U.shape[1]
+    vals = torch.empty((B, k), dtype=torch.float32, device=U.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=U.device)
+    nbytes = C.lib().mi_oov_score_topk_workspace(B, N, k)
+    ws = torch.empty((max(1, nbytes // 4),), dtype=torch.float32, device=U.device)
+    with C.on_device(U):
+        rc = C.lib().mi_oov_score_topk(C.ptr(U), B, C.ptr(E), N, D, k, n_skip_low, C.ptr(vals), C.ptr(idx),
+                                       C.ptr(ws), C.stream_of(U))
+    C.check(rc, "mi_oov_score_topk")
+    return vals, idx

@@ -1,0 +1,194 @@
+/*
+ * mi_oov.h -- C ABI of libmi_oov.so, the MI355X (gfx950) inductive-OOV embedding hot path.
+ *
+ * The reference (snap-research/improving-inductive-oov-recsys) is pure Python and has no FFI;
+ * each entry point below replaces the torch-op sequence of ONE reference function, cited as
+ * R/ = RecBole/recbole/ in the reference tree.  A reference maintainer binds them with the
+ * ctypes stubs shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
+ *   - matrices are dense row-major, float = IEEE binary32, ids = int64 (torch.long);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only
+ *     ENQUEUE work, they never synchronise, allocate or free (graph-capture safe);
+ *   - return value: 0 = MI_OOV_OK, negative = error code (mi_oov_strerror); no C++
+ *     exception crosses the boundary;
+ *   - ids that do not address a row (id < 0 or id >= N) never fault: the row's outputs are
+ *     NaN (floats) / -1 (indices) / 0xFF (bits).  The reference raises IndexError there
+ *     (R/inductive/lsh_embedder.py:129 `feature_mat[nodes]`); the Python host mirror offers
+ *     strict=True to reproduce the exception.
+ *
+ * Deterministic summation order ("canonical order"): a length-L dot
+ * product is split over 16 lanes, lane l owning elements e with (e/4)%16 == l, accumulated
+ * in increasing e; the 16 partials are then summed by a balanced adjacent-pair tree.  The
+ * oracle (oracle/oov_oracle.c) uses the same order, so HIP results are BIT-EXACT against it.
+ */
+#ifndef MI_OOV_H
+#define MI_OOV_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_OOV_VERSION 100 /* 0.1.0 */
+
+enum {
+  MI_OOV_OK = 0,
+  MI_OOV_ERR_NULL = -1,      /* required pointer is NULL                        */
+  MI_OOV_ERR_SHAPE = -2,     /* negative / zero / unsupported dimension         */
+  MI_OOV_ERR_KIND = -3,      /* unknown enum value (hash function ...)          */
+  MI_OOV_ERR_LAUNCH = -4,    /* hipLaunchKernel / hipMemsetAsync reported error */
+  MI_OOV_ERR_ALIGN = -5,     /* pointer not aligned as documented               */
+  MI_OOV_ERR_WORKSPACE = -6  /* workspace too small                             */
+};
+
+int mi_oov_version(void);
+const char* mi_oov_strerror(int code);
+/* last hipError_t (as int) seen by a failing launch on this thread, 0 if none */
+int mi_oov_last_hip_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * lsh: fused gather -> H sign-random-projections -> masked mean of bucket rows.
+ * Replaces LSHInductiveEmbedder._hash_node + embed_user_ids/embed_item_ids
+ *   (R/inductive/lsh_embedder.py:116-179) and TorchLSHash.hash_points (R/inductive/torch_hash.py:55-60):
+ *     x = feat[ids];  bits = !(x @ planes^T < 0);  out = (bits @ buckets) / bits.sum(1)
+ *   bit is 1 for projections that are >= 0, +-0 or NaN (torch_hash.py:57-59);
+ *   an all-zero code gives 0/0 = NaN rows (lsh_embedder.py:178), reproduced.
+ *   ids    i64[B]        feat    f32[N,F]      planes  f32[H,F]    buckets f32[H,D]
+ *   out    f32[B,D] or NULL (hash only; buckets may then be NULL)
+ *   bits   u8[B,H] or NULL  (0/1; 0xFF for invalid ids)
+ * ------------------------------------------------------------------------------------------ */
+int mi_oov_lsh_embed(const int64_t* ids, int64_t B,
+                     const float* feat, int64_t N, int64_t F,
+                     const float* planes, int64_t H,
+                     const float* buckets, int64_t D,
+                     float* out, uint8_t* bits, void* stream);
+
+/* As mi_oov_lsh_embed, fused with the pairwise score of BPR.predict
+ * (R/model/general_recommender/bpr.py:145-149): score[b] = sum_d other[b,d] * emb[b,d],
+ * computed in canonical order with a separate multiply and add (torch.mul(...).sum(1)).
+ *   other  f32[B,D]   the already-embedded opposite side (user rows for item lookups)
+ *   score  f32[B]
+ *   out    f32[B,D] or NULL: the embedding is not materialised when NULL            */
+int mi_oov_lsh_embed_score(const int64_t* ids, int64_t B,
+                           const float* feat, int64_t N, int64_t F,
+                           const float* planes, int64_t H,
+                           const float* buckets, int64_t D,
+                           const float* other, float* score,
+                           float* out, void* stream);
+
+/* BPR.get_user_embedding / get_item_embedding with an lsh plugin, one launch
+ * (R/model/general_recommender/bpr.py:48-125): rows with id < n_vocab are copied from
+ * `table`, the others take the lsh path above on feat[id].
+ *   table  f32[n_vocab,D]                                                            */
+int mi_oov_lsh_lookup(const int64_t* ids, int64_t B,
+                      const float* table, int64_t n_vocab,
+                      const float* feat, int64_t N, int64_t F,
+                      const float* planes, int64_t H,
+                      const float* buckets, int64_t D,
+                      float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * slsh: SingleLSHInductiveEmbedder._hash_node + embed_* (R/inductive/single_lsh_embedder.py:82-109)
+ *     bits as above with H = bits_req planes;  idx = (sum_h 2**bits[h]) % n_buckets
+ *     = (H + popcount(bits)) % n_buckets  (reference quirk, :86);  out = buckets[idx]
+ *   buckets f32[n_buckets,D];  idx i64[B] or NULL;  out f32[B,D] or NULL
+ * ------------------------------------------------------------------------------------------ */
+int mi_oov_slsh_embed(const int64_t* ids, int64_t B,
+                      const float* feat, int64_t N, int64_t F,
+                      const float* planes, int64_t H,
+                      const float* buckets, int64_t n_buckets, int64_t D,
+                      float* out, int64_t* idx, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * dhe: DeepHashEmbedder._get_hashes / _hash_ids (R/inductive/dh_embedder.py:140-170):
+ *     out[b,j] = float( SipHash-2-4(key_j, LE64(ids[b])) mod mod )      (mod = 16777216)
+ *   keys u8[K,16];  out f32[B,K].  SipHash-2-4 is the third-party csiphash==0.0.5
+ *   (RecBole/setup.py:23), restated from the published algorithm.  Bit-exact.
+ *   mod must be a power of two <= 2^24 so the float conversion is exact.
+ * ------------------------------------------------------------------------------------------ */
+int mi_oov_siphash24_mod(const int64_t* ids, int64_t B,
+                         const uint8_t* keys, int64_t K, uint32_t mod,
+                         float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * random mapper: RandomOOVInductiveMapper (R/inductive/random_mapper.py:70-130).
+ *   kind: 0 'mod', 1 'fast' (:70-76), 2 '3round' (:78-86), 3 '64bit' (:95-102)
+ *   mi_oov_mapper_hash : out[b] = hash_kind(ids[b])            (raw signed-int64 mixer, no modulo;
+ *                        for '64bit' and 'mod' the raw value before `% n_buckets`)
+ *   mi_oov_mapper_map  : map_user_ids/map_item_ids (:116-130):
+ *        out[b] = ids[b]                                     if ids[b] <  n_orig
+ *               = pymod(hash(ids[b]-n_orig), n_buckets)+n_orig otherwise
+ *        (signed mixers with arithmetic >>, Python-style non-negative %; '64bit' is uint64)
+ * ------------------------------------------------------------------------------------------ */
+enum { MI_OOV_HASH_MOD = 0, MI_OOV_HASH_FAST = 1, MI_OOV_HASH_3ROUND = 2, MI_OOV_HASH_64BIT = 3 };
+int mi_oov_mapper_hash(const int64_t* ids, int64_t B, int kind, int64_t* out, void* stream);
+int mi_oov_mapper_map(const int64_t* ids, int64_t B, int kind,
+                      int64_t n_orig, int64_t n_buckets, int64_t* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * knn aggregate: KNNInductiveEmbedder.embed_* tail (R/inductive/knn_embedder.py:125-126,146-147):
+ *     rows = W[idx.ravel()];  out = vstack(chunk.mean(0) for chunk in rows.split(g))
+ *   idx i64[M] (flattened [B,k]);  W f32[N,D];  out f32[ceil(M/g), D]; the last group may be
+ *   short and is averaged over its own length (torch.split semantics).  The reference fixes
+ *   g = 2.  Sum in increasing position, then one division.
+ * ------------------------------------------------------------------------------------------ */
+int mi_oov_gather_mean(const int64_t* idx, int64_t M, int64_t g,
+                       const float* W, int64_t N, int64_t D,
+                       float* out, void* stream);
+
+/* nn.Embedding forward (bpr.py:77-81 _user_id_lookup/_item_id_lookup; slsh bucket gather):
+ *   out[b,:] = W[ids[b],:]                                                              */
+int mi_oov_gather_rows(const int64_t* ids, int64_t B,
+                       const float* W, int64_t N, int64_t D,
+                       float* out, void* stream);
+
+/* BPR.get_*_embedding splice for plugins other than lsh (bpr.py:62-76,108-123):
+ *   out[b,:] = table[ids[b],:]              if ids[b] < n_vocab
+ *            = oov_rows[rank(b),:]          otherwise, rank(b) = number of OOV ids before b
+ *   oov_rank i64[B] supplies rank(b) (host mirror computes it with an exclusive scan) */
+int mi_oov_splice_rows(const int64_t* ids, const int64_t* oov_rank, int64_t B,
+                       const float* table, int64_t n_vocab,
+                       const float* oov_rows, int64_t n_oov, int64_t D,
+                       float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * mean / zero: MeanEmbedder (R/inductive/mean_embedder.py:41-87), ZeroEmbedder (zero_embedder.py:36-60)
+ *   mi_oov_col_mean      : mean[d] = (1/N) sum_n W[n,d]   (two-pass, deterministic:
+ *                          fixed row partition, partials summed in partition order)
+ *                          workspace f32[mi_oov_col_mean_workspace(N,D)] scratch
+ *   mi_oov_broadcast_rows: out[b,:] = vec[:]  (vec NULL -> zeros)
+ * ------------------------------------------------------------------------------------------ */
+int64_t mi_oov_col_mean_workspace(int64_t N, int64_t D); /* number of floats */
+int mi_oov_col_mean(const float* W, int64_t N, int64_t D,
+                    float* mean, float* workspace, void* stream);
+int mi_oov_broadcast_rows(const float* vec, int64_t B, int64_t D, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * scoring: BPR.predict (bpr.py:145-149)  score[b] = sum_d (u[b,d]*e[b,d])  (mul, then sum)
+ *          BPR.full_sort_predict / ind_full_sort_predict (bpr.py:151-163)
+ *              scores[b,n] = sum_d U[b,d]*E[n,d]    -> f32[B,N] (caller views it [B*N])
+ *          computed on the f32 MFMA (v_mfma_f32_32x32x2_f32): per element an fmaf chain in
+ *          increasing d starting from +0 (exact f32, no reduced precision).
+ * ------------------------------------------------------------------------------------------ */
+int mi_oov_rowdot(const float* U, const float* E, int64_t B, int64_t D, float* score, void* stream);
+int mi_oov_full_sort_scores(const float* U, int64_t B, const float* E, int64_t N, int64_t D,
+                            float* scores, void* stream);
+
+/* Fused full-sort score + per-row top-k (the [B,N] matrix is never written).  Serves
+ *   - the evaluator's torch.topk(scores, k) (R/evaluator/collector.py:158-167), and
+ *   - the exact kNN search standing in for ScaNN (R/inductive/knn_embedder.py:100-102).
+ *   vals f32[B,k] descending, idx i64[B,k]; ties broken towards the LOWER index.
+ *   n_skip_low: columns [0, n_skip_low) are excluded (the evaluator masks padding item 0).
+ *   workspace: mi_oov_score_topk_workspace(B,N,k) bytes.                               */
+int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k);
+int mi_oov_score_topk(const float* U, int64_t B, const float* E, int64_t N, int64_t D,
+                      int64_t k, int64_t n_skip_low,
+                      float* vals, int64_t* idx, void* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_OOV_H */

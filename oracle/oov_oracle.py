@@ -1,0 +1,201 @@
+"""ctypes front-end of oracle/liboov_oracle.so -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+Inputs and outputs are numpy arrays (C-contiguous); see oov_oracle.c for the reference
+file:line each function restates.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboov_oracle.so")
+
+HASH_KINDS = {"mod": 0, "fast": 1, "3round": 2, "64bit": 3}
+
+
+def build(force=False):
+    """Compile the oracle with gcc (called by __graft_entry__.build())."""
+    src = os.path.join(_HERE, "oov_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B"], stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _lib.oov_siphash24.restype = ctypes.c_uint64
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+_c = ctypes.c_int64
+
+
+def set_threads(n):
+    lib().oov_set_threads(int(n))
+
+
+def max_threads():
+    return int(lib().oov_get_max_threads())
+
+
+def lsh_embed(ids, feat, planes, buckets=None, want_bits=False):
+    ids, feat, planes = _i64(ids), _f32(feat), _f32(planes)
+    B, (N, F), H = ids.shape[0], feat.shape, planes.shape[0]
+    out = bits = None
+    D = 0
+    if buckets is not None:
+        buckets = _f32(buckets)
+        D = buckets.shape[1]
+        out = np.empty((B, D), np.float32)
+    if want_bits:
+        bits = np.empty((B, H), np.uint8)
+    lib().oov_lsh_embed(_p(ids), _c(B), _p(feat), _c(N), _c(F), _p(planes), _c(H), _p(buckets), _c(D), _p(out), _p(bits))
+    if want_bits:
+        return out, bits
+    return out
+
+
+def lsh_embed_score(ids, feat, planes, buckets, other, want_emb=True):
+    ids, feat, planes, buckets, other = _i64(ids), _f32(feat), _f32(planes), _f32(buckets), _f32(other)
+    B, (N, F), H, D = ids.shape[0], feat.shape, planes.shape[0], buckets.shape[1]
+    score = np.empty((B,), np.float32)
+    out = np.empty((B, D), np.float32) if want_emb else None
+    lib().oov_lsh_embed_score(_p(ids), _c(B), _p(feat), _c(N), _c(F), _p(planes), _c(H), _p(buckets), _c(D),
+                              _p(other), _p(score), _p(out))
+    return score, out
+
+
+def lsh_lookup(ids, table, feat, planes, buckets):
+    ids, table, feat, planes, buckets = _i64(ids), _f32(table), _f32(feat), _f32(planes), _f32(buckets)
+    B, (N, F), H, D = ids.shape[0], feat.shape, planes.shape[0], buckets.shape[1]
+    out = np.empty((B, D), np.float32)
+    lib().oov_lsh_lookup(_p(ids), _c(B), _p(table), _c(table.shape[0]), _p(feat), _c(N), _c(F), _p(planes), _c(H),
+                         _p(buckets), _c(D), _p(out))
+    return out
+
+
+def slsh_embed(ids, feat, planes, buckets):
+    ids, feat, planes, buckets = _i64(ids), _f32(feat), _f32(planes), _f32(buckets)
+    B, (N, F), H, (nb, D) = ids.shape[0], feat.shape, planes.shape[0], buckets.shape
+    out = np.empty((B, D), np.float32)
+    idx = np.empty((B,), np.int64)
+    lib().oov_slsh_embed(_p(ids), _c(B), _p(feat), _c(N), _c(F), _p(planes), _c(H), _p(buckets), _c(nb), _c(D),
+                         _p(out), _p(idx))
+    return out, idx
+
+
+def siphash24(key: bytes, msg: bytes) -> int:
+    k = (ctypes.c_uint8 * 16).from_buffer_copy(key)
+    m = (ctypes.c_uint8 * max(1, len(msg))).from_buffer_copy(msg.ljust(1, b"\0"))
+    return int(lib().oov_siphash24(k, m, _c(len(msg))))
+
+
+def siphash24_mod(ids, keys, mod=16777216):
+    ids = _i64(ids)
+    keys = np.ascontiguousarray(keys, dtype=np.uint8).reshape(-1, 16)
+    B, K = ids.shape[0], keys.shape[0]
+    out = np.empty((B, K), np.float32)
+    lib().oov_siphash24_mod(_p(ids), _c(B), _p(keys), _c(K), ctypes.c_uint32(mod), _p(out))
+    return out
+
+
+def mapper_hash(ids, kind):
+    ids = _i64(ids)
+    out = np.empty_like(ids)
+    rc = lib().oov_mapper_hash(_p(ids), _c(ids.shape[0]), ctypes.c_int(HASH_KINDS[kind]), _p(out))
+    assert rc == 0
+    return out
+
+
+def mapper_map(ids, kind, n_orig, n_buckets):
+    ids = _i64(ids)
+    out = np.empty_like(ids)
+    rc = lib().oov_mapper_map(_p(ids), _c(ids.shape[0]), ctypes.c_int(HASH_KINDS[kind]), _c(n_orig), _c(n_buckets),
+                              _p(out))
+    assert rc == 0
+    return out
+
+
+def gather_mean(idx, W, g=2):
+    idx, W = _i64(idx).ravel(), _f32(W)
+    M, (N, D) = idx.shape[0], W.shape
+    out = np.empty(((M + g - 1) // g, D), np.float32)
+    lib().oov_gather_mean(_p(idx), _c(M), _c(g), _p(W), _c(N), _c(D), _p(out))
+    return out
+
+
+def gather_rows(ids, W):
+    ids, W = _i64(ids), _f32(W)
+    out = np.empty((ids.shape[0], W.shape[1]), np.float32)
+    lib().oov_gather_rows(_p(ids), _c(ids.shape[0]), _p(W), _c(W.shape[0]), _c(W.shape[1]), _p(out))
+    return out
+
+
+def splice_rows(ids, table, oov_rows):
+    ids, table, oov_rows = _i64(ids), _f32(table), _f32(oov_rows)
+    n_vocab, D = table.shape
+    rank = np.cumsum(ids >= n_vocab) - (ids >= n_vocab)
+    rank = _i64(rank)
+    out = np.empty((ids.shape[0], D), np.float32)
+    lib().oov_splice_rows(_p(ids), _p(rank), _c(ids.shape[0]), _p(table), _c(n_vocab), _p(oov_rows),
+                          _c(oov_rows.shape[0]), _c(D), _p(out))
+    return out
+
+
+def col_mean(W):
+    W = _f32(W)
+    mean = np.empty((W.shape[1],), np.float32)
+    lib().oov_col_mean(_p(W), _c(W.shape[0]), _c(W.shape[1]), _p(mean))
+    return mean
+
+
+def broadcast_rows(vec, B, D):
+    vec = None if vec is None else _f32(vec)
+    out = np.empty((B, D), np.float32)
+    lib().oov_broadcast_rows(_p(vec), _c(B), _c(D), _p(out))
+    return out
+
+
+def rowdot(U, E):
+    U, E = _f32(U), _f32(E)
+    out = np.empty((U.shape[0],), np.float32)
+    lib().oov_rowdot(_p(U), _p(E), _c(U.shape[0]), _c(U.shape[1]), _p(out))
+    return out
+
+
+def full_sort_scores(U, E):
+    U, E = _f32(U), _f32(E)
+    out = np.empty((U.shape[0], E.shape[0]), np.float32)
+    lib().oov_full_sort_scores(_p(U), _c(U.shape[0]), _p(E), _c(E.shape[0]), _c(U.shape[1]), _p(out))
+    return out
+
+
+def score_topk(U, E, k, n_skip_low=0):
+    U, E = _f32(U), _f32(E)
+    vals = np.empty((U.shape[0], k), np.float32)
+    idx = np.empty((U.shape[0], k), np.int64)
+    lib().oov_score_topk(_p(U), _c(U.shape[0]), _p(E), _c(E.shape[0]), _c(U.shape[1]), _c(k), _c(n_skip_low),
+                         _p(vals), _p(idx))
+    return vals, idx

@@ -1,0 +1,207 @@
+"""-m gpu: the HIP path (through the C ABI) against the oracle and the reference-generated golden
+fixtures.  Integer/index/bit outputs must be identical; float outputs are BIT-EXACT against the
+oracle (same canonical summation order) and within 1e-5 relative of the reference's own outputs
+(BASELINE.json north_star tolerance)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5  # north_star: "aggregated embeddings and scores match within 1e-5 rel fp32"
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def rel_err(a, b):
+    m = ~(np.isnan(a) | np.isnan(b))
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    return float(np.abs(a[m] - b[m]).max() / max(1e-30, np.abs(b[m]).max())) if m.any() else 0.0
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mi_oov
+    from mi_oov import ops as _ops
+    assert mi_oov.available(), "libmi_oov.so missing on the GPU box"
+    return _ops
+
+
+@pytest.mark.parametrize("case", ["f64", "mixed", "global", "wide"])
+@pytest.mark.parametrize("side", ["user", "item"])
+def test_lsh_golden(case, side, golden, oracle, ops, dev):
+    z = golden(f"lsh_{case}.npz")
+    ids, feat, planes, buckets = z[side + "_ids"], z[side + "_feat"], z[side + "_planes"], z[side + "_buckets"]
+    emb = ops.lsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(buckets, dev)).cpu().numpy()
+    bits = ops.lsh_bits(T(ids, dev), T(feat, dev), T(planes, dev)).cpu().numpy()
+    o_emb, o_bits = oracle.lsh_embed(ids, feat, planes, buckets, want_bits=True)
+    assert np.array_equal(bits, o_bits)
+    assert bits_equal(emb, o_emb)
+    # reference: bits on margin-safe rows (all rows of these fixtures agree), floats within 1e-5
+    marg = z[side + "_margin"]
+    safe = (marg > 1e-5) | (marg == 0)
+    assert np.array_equal(bits[safe], z[side + "_bits"][safe])
+    assert safe.mean() > 0.99
+    assert rel_err(emb[safe], z[side + "_emb"][safe]) <= RTOL
+
+
+@pytest.mark.parametrize("case", ["b8", "b1000"])
+@pytest.mark.parametrize("side", ["user", "item"])
+def test_slsh_golden(case, side, golden, oracle, ops, dev):
+    z = golden(f"slsh_{case}.npz")
+    ids, feat, planes, buckets = z[side + "_ids"], z[side + "_feat"], z[side + "_planes"], z[side + "_buckets"]
+    emb = ops.slsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(buckets, dev)).cpu().numpy()
+    idx = ops.slsh_index(T(ids, dev), T(feat, dev), T(planes, dev), buckets.shape[0]).cpu().numpy()
+    o_emb, o_idx = oracle.slsh_embed(ids, feat, planes, buckets)
+    assert np.array_equal(idx, o_idx) and bits_equal(emb, o_emb)
+    assert np.array_equal(idx, z[side + "_idx"])
+    assert bits_equal(emb, z[side + "_emb"])
+
+
+def test_mapper_golden(golden, ops, dev):
+    m = golden("mapper.json")
+    ids = T(np.array(m["ids"], dtype=np.int64), dev)
+    for c in m["cases"]:
+        out = ops.mapper_map(ids, c["hash"], c["n_orig"], c["n_buckets"]).cpu().tolist()
+        assert out == c["map_item"], c["hash"]
+    raw = T(np.array(m["raw_in"], dtype=np.int64), dev)
+    assert ops.mapper_hash(raw, "fast").cpu().tolist() == m["raw_fast"]
+    assert ops.mapper_hash(raw, "3round").cpu().tolist() == m["raw_3round"]
+    for nb in (8, 1000, 2 ** 31 + 11):
+        assert ops.mapper_map(raw, "64bit", 0, nb).cpu().tolist() == m[f"raw_64bit_mod_{nb}"]
+
+
+def test_siphash_golden(golden, oracle, ops, dev):
+    s = golden("siphash.json")
+    keys = np.frombuffer(b"".join(bytes.fromhex(k) for k in s["dhe_keys"]), dtype=np.uint8).reshape(-1, 16).copy()
+    out = ops.siphash24_mod(T(np.array(s["dhe_ids"], dtype=np.int64), dev), T(keys, dev)).cpu().numpy()
+    assert out.astype(np.int64).tolist() == s["dhe_hashes"]
+    k4 = np.stack([np.arange(j, j + 16, dtype=np.uint8) for j in range(4)])
+    out = ops.siphash24_mod(T(np.array([0, 1, 2, 112062759516], dtype=np.int64), dev), T(k4, dev)).cpu().numpy()
+    assert out.astype(np.int64).tolist() == s["survey_k4"]
+    # bulk: random ids x 1024 keys against the oracle
+    rng = np.random.default_rng(5)
+    keys = rng.integers(0, 256, size=(1024, 16), dtype=np.uint8)
+    ids = rng.integers(-2 ** 62, 2 ** 62, size=300, dtype=np.int64)
+    got = ops.siphash24_mod(T(ids, dev), T(keys, dev)).cpu().numpy()
+    assert np.array_equal(got, oracle.siphash24_mod(ids, keys))
+
+
+def test_knn_mean_golden(golden, oracle, ops, dev):
+    z = golden("knn.npz")
+    for side in ("user", "item"):
+        got = ops.gather_mean(T(z[side + "_idx"], dev), T(z[side + "_table"], dev), 2).cpu().numpy()
+        assert bits_equal(got, oracle.gather_mean(z[side + "_idx"], z[side + "_table"], 2))
+        assert rel_err(got, z[side + "_emb"]) <= RTOL
+    z = golden("mean.npz")
+    for side in ("user", "item"):
+        W = z[side + "_table"]
+        mean = ops.col_mean(T(W, dev))
+        assert bits_equal(mean.cpu().numpy(), oracle.col_mean(W))
+        got = ops.broadcast_rows(mean, len(z[side + "_ids"])).cpu().numpy()
+        assert rel_err(got, z[side + "_emb"]) <= RTOL
+    zero = ops.broadcast_rows(None, 7, 16, dev).cpu().numpy()
+    assert zero.shape == (7, 16) and not zero.any()
+
+
+def test_bpr_golden(golden, oracle, ops, dev):
+    z = golden("bpr_lsh.npz")
+    n_users, n_items = int(z["n_users"]), int(z["n_items"])
+    for side, n_vocab, ids in (("user", n_users, z["users"]), ("item", n_items, z["items"])):
+        args = [z[side + "_table"], z[side + "_feat"], z[side + "_planes"], z[side + "_buckets"]]
+        got = ops.lsh_lookup(T(ids, dev), *[T(a, dev) for a in args]).cpu().numpy()
+        assert bits_equal(got, oracle.lsh_lookup(ids, *args))
+        assert rel_err(got, z[side + "_e"]) <= RTOL
+    score = ops.rowdot(T(z["user_e"], dev), T(z["item_e"], dev)).cpu().numpy()
+    assert bits_equal(score, oracle.rowdot(z["user_e"], z["item_e"]))
+    m = ~np.isnan(z["predict"])
+    assert np.allclose(score[m], z["predict"][m], rtol=RTOL, atol=1e-6)
+    ue = z["user_e"][:40]
+    ok = ~np.isnan(ue).any(1)
+    fs = ops.full_sort_scores(T(ue[ok], dev), T(z["item_table"], dev)).cpu().numpy()
+    assert bits_equal(fs, oracle.full_sort_scores(ue[ok], z["item_table"]))
+    ref = z["full_sort"].reshape(40, -1)[ok]
+    assert np.allclose(fs, ref, rtol=RTOL, atol=1e-6)
+
+
+@pytest.mark.parametrize("B,N,F,H,D", [(1, 7, 64, 8, 64), (63, 100, 64, 8, 64), (4097, 3000, 64, 8, 64),
+                                       (500, 400, 22, 8, 64), (333, 200, 4, 3, 1), (257, 150, 128, 16, 128),
+                                       (100, 90, 200, 9, 36), (129, 77, 301, 40, 50), (64, 50, 640, 12, 256)])
+def test_lsh_shapes_vs_oracle(B, N, F, H, D, oracle, ops, dev):
+    rng = np.random.default_rng(B * 31 + F)
+    feat = rng.standard_normal((N, F), dtype=np.float32)
+    feat[0] = 0
+    planes = rng.standard_normal((H, F), dtype=np.float32)
+    buckets = rng.standard_normal((H, D), dtype=np.float32)
+    other = rng.standard_normal((B, D), dtype=np.float32)
+    ids = rng.integers(0, N, size=B, dtype=np.int64)
+    ids[0] = 0
+    if B > 5:
+        ids[3] = N + 5   # out of range -> NaN row / 0xFF bits, never a fault
+        ids[4] = -1
+    emb = ops.lsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(buckets, dev)).cpu().numpy()
+    bits = ops.lsh_bits(T(ids, dev), T(feat, dev), T(planes, dev)).cpu().numpy()
+    o_emb, o_bits = oracle.lsh_embed(ids, feat, planes, buckets, want_bits=True)
+    assert np.array_equal(bits, o_bits)
+    assert bits_equal(emb, o_emb)
+    score, emb2 = ops.lsh_embed_score(T(ids, dev), T(feat, dev), T(planes, dev), T(buckets, dev), T(other, dev),
+                                      want_emb=True)
+    o_score, _ = oracle.lsh_embed_score(ids, feat, planes, buckets, other)
+    assert bits_equal(emb2.cpu().numpy(), o_emb)
+    assert bits_equal(score.cpu().numpy(), o_score)
+    score_only = ops.lsh_embed_score(T(ids, dev), T(feat, dev), T(planes, dev), T(buckets, dev), T(other, dev))
+    assert bits_equal(score_only.cpu().numpy(), o_score)
+    # slsh on the same inputs with a large bucket table
+    nb = 37
+    big = rng.standard_normal((nb, D), dtype=np.float32)
+    s_emb = ops.slsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(big, dev)).cpu().numpy()
+    o_s_emb, o_idx = oracle.slsh_embed(ids, feat, planes, big)
+    assert bits_equal(s_emb, o_s_emb)
+    assert np.array_equal(ops.slsh_index(T(ids, dev), T(feat, dev), T(planes, dev), nb).cpu().numpy(), o_idx)
+
+
+def test_empty_batches(ops, dev):
+    ids = torch.empty((0,), dtype=torch.int64, device=dev)
+    feat = torch.randn(10, 8, device=dev)
+    planes = torch.randn(4, 8, device=dev)
+    buckets = torch.randn(4, 16, device=dev)
+    assert ops.lsh_embed(ids, feat, planes, buckets).shape == (0, 16)
+    assert ops.gather_rows(ids, buckets).shape == (0, 16)
+    assert ops.mapper_map(ids, "3round", 5, 3).shape == (0,)
+    assert ops.rowdot(torch.empty(0, 16, device=dev), torch.empty(0, 16, device=dev)).shape == (0,)
+
+
+@pytest.mark.parametrize("B,N,D,k", [(5, 300, 64, 10), (130, 1000, 64, 20), (33, 257, 22, 2), (200, 5000, 128, 7)])
+def test_scores_topk_vs_oracle(B, N, D, k, oracle, ops, dev):
+    rng = np.random.default_rng(N + D)
+    U = rng.standard_normal((B, D), dtype=np.float32)
+    E = rng.standard_normal((N, D), dtype=np.float32)
+    E[5] = E[9]  # exact ties -> lower index first
+    S = ops.full_sort_scores(T(U, dev), T(E, dev)).cpu().numpy()
+    assert bits_equal(S, oracle.full_sort_scores(U, E))
+    vals, idx = ops.score_topk(T(U, dev), T(E, dev), k, 1)
+    o_vals, o_idx = oracle.score_topk(U, E, k, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    assert bits_equal(vals.cpu().numpy(), o_vals)
+
+
+def test_gather_splice_vs_oracle(oracle, ops, dev):
+    rng = np.random.default_rng(11)
+    for D in (64, 1, 50, 200):
+        table = rng.standard_normal((300, D), dtype=np.float32)
+        ids = rng.integers(0, 400, size=1000, dtype=np.int64)
+        n_oov = int((ids >= 300).sum())
+        oov_rows = rng.standard_normal((n_oov, D), dtype=np.float32)
+        got = ops.splice_rows(T(ids, dev), T(table, dev), T(oov_rows, dev)).cpu().numpy()
+        assert bits_equal(got, oracle.splice_rows(ids, table, oov_rows))
+        iv = ids[ids < 300]
+        assert bits_equal(ops.gather_rows(T(iv, dev), T(table, dev)).cpu().numpy(), table[iv])
+        idx = rng.integers(0, 300, size=(77, 3), dtype=np.int64)
+        for g in (2, 3, 5):
+            got = ops.gather_mean(T(idx, dev), T(table, dev), g).cpu().numpy()
+            assert bits_equal(got, oracle.gather_mean(idx, table, g))
