@@ -26,22 +26,26 @@ inline int check_launch() {
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // ---- DPP row (16-lane) all-reduce -----------------------------------------------------------
-// Balanced adjacent-pair tree over the 16 lanes of a DPP row; every lane receives the sum.
-// Steps: xor 1, xor 2 (quad_perm), then row_half_mirror and row_mirror, which at that point
-// pair equal-valued quads/octets, i.e. they are the xor-4 and xor-8 butterflies.  IEEE add is
-// commutative, so all 16 lanes hold bit-identical results and the value equals
-//   ((p0+p1)+(p2+p3)) + ((p4+p5)+(p6+p7)) + ... summed pairwise in natural order,
-// which is what oracle/oov_oracle.c::tree16 computes.
+// Stride-halving tree over the 16 lanes of a DPP row; every lane receives the sum.
+//   level 1: q_l = p_l + p_(l+8)   (l = 0..7)      row_ror:8
+//   level 2: r_l = q_l + q_(l+4)   (l = 0..3)      row_ror:4   (q has period 8 by then)
+//   level 3: s_l = r_l + r_(l+2)   (l = 0,1)       row_ror:2
+//   level 4: s_0 + s_1                             row_ror:1
+// After each level the values are periodic in the lane index, so a rotation by the stride
+// delivers the xor-partner's value in both directions; IEEE add is commutative, hence all 16
+// lanes hold bit-identical results, equal to oracle/oov_oracle.c::tree16.  This order (largest
+// stride first) is what lets a kernel keep only ONE lane's share of H sums alive per level with
+// bank-masked DPP adds (rows of 16 split into banks of 4 lanes).
 template <int CTRL>
 __device__ __forceinline__ float dpp_f32(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
 }
 
 __device__ __forceinline__ float row16_sum(float v) {
-  v = v + dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = v + dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = v + dpp_f32<0x141>(v);  // row_half_mirror
-  v = v + dpp_f32<0x140>(v);  // row_mirror
+  v = v + dpp_f32<0x128>(v);  // row_ror:8
+  v = v + dpp_f32<0x124>(v);  // row_ror:4
+  v = v + dpp_f32<0x122>(v);  // row_ror:2
+  v = v + dpp_f32<0x121>(v);  // row_ror:1
   return v;
 }
 

@@ -16,6 +16,8 @@
 //
 // Reference functions restated: R/inductive/torch_hash.py:55-60, lsh_embedder.py:116-179,
 // single_lsh_embedder.py:82-109, bpr.py:48-125,145-149 (see include/mi_oov.h).
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mi_oov {
@@ -76,11 +78,16 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
     int64_t id[R];
     bool live[R], valid[R], oov[R];
     float4 x[R][FC];
+    // ids first, then every row gather back-to-back on clamped (always valid) addresses: no wait
+    // and no branch sits between two gathers, so a tile costs ONE HBM round trip, not R.
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       row[r] = tile * (4 * R) + r * 4 + grp;
       live[r] = row[r] < p.B;
-      id[r] = live[r] ? p.ids[row[r]] : -1;
+      id[r] = p.ids[live[r] ? row[r] : p.B - 1];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
       oov[r] = (p.table == nullptr) || (id[r] >= p.n_vocab);
       valid[r] = live[r] && (oov[r] ? (static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(p.N))
                                     : (id[r] >= 0));
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
 #pragma unroll
       for (int c = 0; c < FC; ++c) {
         const int e = (c * 16 + l16) * 4;
-        x[r][c] = ld ? load4<VEC>(frow, e, p.F) : make_float4(0.f, 0.f, 0.f, 0.f);
+        x[r][c] = load4<VEC>(frow, e, p.F);
       }
     }
 
@@ -412,6 +419,18 @@ static int dispatch_lsh(const LshParams& p, hipStream_t st) {
   return launch_wide<4, VEC>(p, FPw, st);
 }
 
+// lsh64.hip: lane-owns-lookup kernel for the hot shape F = D = 64
+int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes, int H,
+                 const float* buckets, const float* other, float* score, float* out, hipStream_t st);
+
+static bool lsh64_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MI_OOV_LSH64");  // developer A/B knob; default on
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 static int run_lsh(LshParams p, void* stream) {
   if (p.B < 0 || p.N <= 0 || p.F <= 0 || p.H <= 0) return MI_OOV_ERR_SHAPE;
   if (p.B == 0) return MI_OOV_OK;
@@ -426,6 +445,10 @@ static int run_lsh(LshParams p, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = (p.F % 4 == 0) && (p.D % 4 == 0) && aligned16(p.feat) && (!p.out || aligned16(p.out)) &&
                    (!p.other || aligned16(p.other)) && (!p.table || aligned16(p.table));
+  if (vec && p.F == 64 && p.D == 64 && p.H <= 8 && want_emb && !p.table && !p.bits && aligned16(p.planes) &&
+      aligned16(p.buckets) && lsh64_enabled())
+    return launch_lsh64(p.ids, p.B, p.feat, p.N, p.planes, static_cast<int>(p.H), p.buckets, p.other, p.score, p.out,
+                        st);
   return vec ? dispatch_lsh<true>(p, st) : dispatch_lsh<false>(p, st);
 }
 

@@ -20,7 +20,8 @@
  *
  * Deterministic summation order ("canonical order"): a length-L dot
  * product is split over 16 lanes, lane l owning elements e with (e/4)%16 == l, accumulated
- * in increasing e; the 16 partials are then summed by a balanced adjacent-pair tree.  The
+ * in increasing e; the 16 partials are then summed by a stride-halving tree (l with l+8, then
+ * stride 4, 2, 1).  The
  * oracle (oracle/oov_oracle.c) uses the same order, so HIP results are BIT-EXACT against it.
  */
 #ifndef MI_OOV_H

@@ -1,0 +1,160 @@
+// Developer microbenchmark (not part of the product): what does a 65536-row random gather of
+// 256-B rows cost on MI355X as a function of loads in flight, store policy and access pattern?
+//   hipcc -O3 --offload-arch=gfx950 tools/microbench.hip -o tools/microbench && tools/microbench
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+#include "mi_oov.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__global__ void empty_kernel(int* p) { if (p && threadIdx.x == 9999) p[0] = 1; }
+
+// MODE 0: copy rows to out (plain stores)   1: copy with nontemporal stores
+// MODE 2: read only (reduce each row to one float per row)  3: read only, no id indirection (row = b)
+template <int R, int MODE>
+__global__ __launch_bounds__(256) void gather_kernel(const int64_t* __restrict__ ids, int64_t B,
+                                                     const float* __restrict__ feat, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    int64_t row[R], id[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      if (row[r] >= B) row[r] = B - 1;
+      id[r] = (MODE == 3) ? row[r] * 151 % 10000000 : ids[row[r]];
+    }
+    float4 x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const float4*>(feat + id[r] * 64 + l16 * 4);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      if (MODE == 0) *reinterpret_cast<float4*>(out + row[r] * 64 + l16 * 4) = x[r];
+      if (MODE == 1) {
+        typedef float v4f __attribute__((ext_vector_type(4)));
+        v4f v = {x[r].x, x[r].y, x[r].z, x[r].w};
+        __builtin_nontemporal_store(v, reinterpret_cast<v4f*>(out + row[r] * 64 + l16 * 4));
+      }
+      if (MODE >= 2) {
+        float s = x[r].x + x[r].y + x[r].z + x[r].w;
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        if (l16 == 0) out[row[r]] = s;
+      }
+    }
+  }
+}
+
+// copy + WORK x 4 dependent-chain FMAs per round: how much VALU work hides under the gather?
+template <int R, int WORK, bool DPP>
+__global__ __launch_bounds__(256) void work_kernel(const int64_t* __restrict__ ids, int64_t B,
+                                                   const float* __restrict__ feat, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    int64_t row[R], id[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      if (row[r] >= B) row[r] = B - 1;
+      id[r] = ids[row[r]];
+    }
+    float4 x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const float4*>(feat + id[r] * 64 + l16 * 4);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float4 a = x[r];
+#pragma unroll
+      for (int i = 0; i < WORK; ++i) {
+        a.x = __builtin_fmaf(a.x, 1.0001f, a.y);
+        a.y = __builtin_fmaf(a.y, 0.9999f, a.z);
+        a.z = __builtin_fmaf(a.z, 1.0002f, a.w);
+        if (DPP) a.w = a.w + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(a.x), 0x128, 0xF, 0xF, false));
+        else a.w = __builtin_fmaf(a.w, 0.9998f, a.x);
+      }
+      *reinterpret_cast<float4*>(out + row[r] * 64 + l16 * 4) = a;
+    }
+  }
+}
+
+template <typename F>
+static float time_it(F launch, int iters) {
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  for (int i = 0; i < 10; ++i) launch(i);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(a, 0));
+  for (int i = 0; i < iters; ++i) launch(10 + i);
+  CK(hipEventRecord(b, 0));
+  CK(hipEventSynchronize(b));
+  float ms; CK(hipEventElapsedTime(&ms, a, b));
+  return ms * 1e3f / iters;
+}
+
+int main(int argc, char** argv) {
+  const int64_t N = 10000000, B = argc > 1 ? atoll(argv[1]) : 65536;
+  const int iters = 200, nb = iters + 10;
+  float *feat, *out; int64_t* ids;
+  CK(hipMalloc(&feat, N * 64 * 4)); CK(hipMalloc(&out, B * 64 * 4)); CK(hipMalloc(&ids, nb * B * 8));
+  CK(hipMemset(feat, 0, N * 64 * 4));
+  std::vector<int64_t> h(nb * B);
+  uint64_t s = 88172645463325252ULL;
+  for (auto& v : h) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (int64_t)(s % N); }
+  CK(hipMemcpy(ids, h.data(), h.size() * 8, hipMemcpyHostToDevice));
+  printf("B=%lld rows of 256 B, table %.2f GB\n", (long long)B, N * 256 / 1e9);
+  if (getenv("MB_LIB_ONLY")) goto lib_cases;
+  printf("%-44s %8.2f us\n", "empty kernel, 1024 blocks", time_it([&](int) { hipLaunchKernelGGL(empty_kernel, dim3(1024), dim3(256), 0, 0, nullptr); }, iters));
+#define RUN(R, MODE, NAME, BLOCKS)                                                                        \
+  {                                                                                                       \
+    int64_t tiles = (B + 4 * R - 1) / (4 * R);                                                            \
+    int grid = (int)((tiles + 3) / 4); if (BLOCKS > 0 && grid > BLOCKS) grid = BLOCKS;                    \
+    float us = time_it([&](int i) { hipLaunchKernelGGL((gather_kernel<R, MODE>), dim3(grid), dim3(256), 0, 0, ids + (int64_t)i * B, B, feat, out); }, iters); \
+    double bytes = (MODE >= 2) ? B * (8.0 + 256 + 4) : B * (8.0 + 512);                                   \
+    printf("%-44s %8.2f us  %7.1f GB/s  grid %d\n", NAME, us, bytes / us / 1e3, grid);                    \
+  }
+  RUN(1, 0, "copy R=1", 0) RUN(2, 0, "copy R=2", 0) RUN(4, 0, "copy R=4", 0) RUN(8, 0, "copy R=8", 0) RUN(16, 0, "copy R=16", 0)
+  RUN(4, 1, "copy nt-store R=4", 0) RUN(8, 1, "copy nt-store R=8", 0)
+  RUN(1, 2, "read-only R=1", 0) RUN(2, 2, "read-only R=2", 0) RUN(4, 2, "read-only R=4", 0) RUN(8, 2, "read-only R=8", 0) RUN(16, 2, "read-only R=16", 0)
+  RUN(4, 3, "read-only no-indirection R=4", 0) RUN(8, 3, "read-only no-indirection R=8", 0)
+  RUN(4, 2, "read-only R=4 grid<=512", 512) RUN(4, 2, "read-only R=4 grid<=256", 256) RUN(8, 2, "read-only R=8 grid<=256", 256)
+  RUN(4, 0, "copy R=4 grid<=512", 512)
+#define RUNW(R, WORK, DPP, NAME)                                                                         \
+  {                                                                                                       \
+    int64_t tiles = (B + 4 * R - 1) / (4 * R);                                                            \
+    int grid = (int)((tiles + 3) / 4);                                                                    \
+    float us = time_it([&](int i) { hipLaunchKernelGGL((work_kernel<R, WORK, DPP>), dim3(grid), dim3(256), 0, 0, ids + (int64_t)i * B, B, feat, out); }, iters); \
+    printf("%-44s %8.2f us  (%d VALU/round)\n", NAME, us, WORK * 4);                                       \
+  }
+  RUNW(4, 0, false, "copy+work R=4 W=0") RUNW(4, 8, false, "copy+work R=4 W=8") RUNW(4, 16, false, "copy+work R=4 W=16")
+  RUNW(4, 32, false, "copy+work R=4 W=32") RUNW(4, 64, false, "copy+work R=4 W=64")
+  RUNW(4, 16, true, "copy+work(dpp) R=4 W=16") RUNW(4, 32, true, "copy+work(dpp) R=4 W=32")
+  RUNW(8, 32, false, "copy+work R=8 W=32") RUNW(2, 32, false, "copy+work R=2 W=32")
+  lib_cases:
+  {
+    // the product kernels through the C ABI (variant chosen by MI_OOV_LSH64_VARIANT)
+    float *planes, *buckets, *users, *score;
+    CK(hipMalloc(&planes, 8 * 64 * 4)); CK(hipMalloc(&buckets, 8 * 64 * 4));
+    CK(hipMalloc(&users, 8 * B * 64 * 4)); CK(hipMalloc(&score, B * 4));
+    std::vector<float> hp(8 * 64), hf(1 << 20);
+    for (auto& v : hp) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (float)((int64_t)(s % 2001) - 1000) / 1000.f; }
+    CK(hipMemcpy(planes, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(buckets, hp.data(), hp.size() * 4, hipMemcpyHostToDevice));
+    for (auto& v : hf) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (float)((int64_t)(s % 2001) - 1000) / 1000.f; }
+    for (int64_t off = 0; off < N * 64; off += (1 << 20)) {
+      int64_t n = N * 64 - off < (1 << 20) ? N * 64 - off : (1 << 20);
+      CK(hipMemcpy(feat + off, hf.data() + (off / (1 << 20)) % 7, (n - 8) * 4, hipMemcpyHostToDevice));
+    }
+    const char* var = getenv("MI_OOV_LSH64_VARIANT");
+    float us = time_it([&](int i) { mi_oov_lsh_embed(ids + (int64_t)i * B, B, feat, N, 64, planes, 8, buckets, 64, out, nullptr, nullptr); }, iters);
+    printf("variant %s: %-32s %8.2f us  %7.1f GB/s\n", var ? var : "0", "mi_oov_lsh_embed", us, B * 520.0 / us / 1e3);
+    us = time_it([&](int i) { mi_oov_lsh_embed_score(ids + (int64_t)i * B, B, feat, N, 64, planes, 8, buckets, 64, users + (int64_t)(i % 8) * B * 64, score, nullptr, nullptr); }, iters);
+    printf("variant %s: %-32s %8.2f us  %7.1f GB/s\n", var ? var : "0", "mi_oov_lsh_embed_score", us, B * 532.0 / us / 1e3);
+    us = time_it([&](int i) { mi_oov_rowdot(users + (int64_t)(i % 8) * B * 64, out, B, 64, score, nullptr); }, iters);
+    printf("%-44s %8.2f us  %7.1f GB/s\n", "mi_oov_rowdot", us, B * 516.0 / us / 1e3);
+  }
+  return 0;
+}
