@@ -6,12 +6,15 @@
 
 Workload (BASELINE.json north_star / SURVEY.md section 8d "Config S-lsh"): item features
 f32[N=10M, F=64] row-normalised, planes f32[8,64], OOV bucket table f32[8,64], batch B=65536
-random ids, user rows f32[B,64].  One STEP = one pass of the hot path over one batch:
-    mi_oov_lsh_embed  (fused gather -> 8 sign projections -> masked bucket mean -> [B,64] rows;
-                       the plugin call LSHInductiveEmbedder.embed_item_ids)
-    mi_oov_rowdot     (BPR.predict: one score per lookup)
-Every step uses a fresh id batch (no cache reuse across steps); all inputs are resident in HBM
-before the timed region.  value = lookups (each embedded and scored) per second, whole job.
+random ids, user rows f32[B,64].  One STEP = one pass of the hot path over one batch = ONE launch of
+    mi_oov_lsh_embed_score  (gather feat[id] -> 8 sign projections -> masked mean of bucket rows ->
+                             dot with the user row -> score[b]; what BPR.predict returns for OOV
+                             items behind LSHInductiveEmbedder.embed_item_ids, embedding never
+                             materialised: 16 + 4F + 4D + 4 = 532 algorithmic bytes per lookup)
+`--unfused` runs the same step as the two launches the plugin boundary implies (mi_oov_lsh_embed
+writing [B,64] rows, then mi_oov_rowdot).  Every step uses a fresh id batch (no cache reuse across
+steps); all inputs are resident in HBM before the timed region.  value = lookups (each embedded
+and scored) per second, whole job.
 
 N > 1: one process per GPU; the 2.56 GB table is REPLICATED (it fits 288 GB HBM 100x over), ranks
 process independent batches and there is no data-path collective -> weak
@@ -46,7 +49,7 @@ def parse():
     ap.add_argument("--hashes", type=int, default=8)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--sharded", action="store_true", help="row-shard the table + RCCL all-to-all exchange")
-    ap.add_argument("--fused", action="store_true", help="single-launch embed+score kernel instead of two launches")
+    ap.add_argument("--unfused", action="store_true", help="two launches (lsh_embed + rowdot) instead of the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
@@ -69,10 +72,23 @@ def make_inputs(args, dev, rank, n_rows, row_offset=0):
     return feat, planes, buckets
 
 
+def host_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup quota (the
+    GPU box exposes 256 logical CPUs but grants 16 per GPU)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(args, feat, planes, buckets, seconds):
     """The reference's CPU path (torch ops, oracle/ref_torch.py) on a bounded sample of batches."""
     from oracle import ref_torch
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     torch.set_num_threads(cores)
     f, p, w = feat.cpu(), planes.cpu(), buckets.cpu()
     g = torch.Generator().manual_seed(7)
@@ -134,15 +150,12 @@ def main():
     n_user_bufs = 8
     users = torch.randn((n_user_bufs, B, D), generator=g, device=dev)
 
+    fused = not args.unfused and not (args.sharded and world > 1)
+
     def step(i, ev=None):
         ids = all_ids[i]
-        if args.fused and not (args.sharded and world > 1):
-            if ev:
-                ev[0].record()
-            s = ops.lsh_embed_score(ids, feat, planes, buckets, users[i % n_user_bufs])
-            if ev:
-                ev[1].record()
-            return s
+        if fused:
+            return ops.lsh_embed_score(ids, feat, planes, buckets, users[i % n_user_bufs])
         if ev:
             ev[0].record()
         e = embed(ids)
@@ -159,17 +172,27 @@ def main():
     with torch.no_grad():
         for i in range(args.warmup):
             step(i)
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                  for _ in range(args.steps)]
+        # HIP events on the launch stream (torch's current stream is the one handed to the C ABI).
+        # Fused: the timed region holds nothing but K launches of the dominant kernel, so one event
+        # pair around the region gives its average launch duration (inter-launch gaps included).
+        # Unfused: one pair around every lsh_embed launch.
+        region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        events = None if fused else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                     for _ in range(args.steps)]
         fence()
         t0 = time.perf_counter()
+        region[0].record()
         for k in range(args.steps):
-            step(args.warmup + k, events[k])
+            step(args.warmup + k, events[k] if events else None)
+        region[1].record()
         fence()
         t1 = time.perf_counter()
 
     elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
-    kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    if fused:
+        kern_ms = region[0].elapsed_time(region[1]) / max(1, args.steps)
+    else:
+        kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
     kern = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
@@ -177,7 +200,7 @@ def main():
     elapsed_s, kern_ms = float(elapsed.item()), float(kern.item())
 
     if rank == 0:
-        per_lookup = (16 + 4 * F + 4 * D + 4) if args.fused else (8 + 4 * F + 4 * D)
+        per_lookup = (16 + 4 * F + 4 * D + 4) if fused else (8 + 4 * F + 4 * D)
         achieved = (B * per_lookup / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else 0.0
         out = {
             "metric": "OOV embed lookups+scores/sec",
@@ -196,8 +219,8 @@ def main():
                                    f"({N}-item x {F}-feature table, {H} hashes/buckets, {D}-d, batch {B} per GPU)",
                        "items": N, "feat": F, "dim": D, "hashes": H, "batch_per_gpu": B,
                        "table": "row-sharded + all-to-all" if (args.sharded and world > 1) else "replicated per GPU",
-                       "launches_per_step": "lsh_embed_score" if args.fused else "lsh_embed + rowdot"},
-            "roofline": {"bound": "hbm", "kernel": "lsh_fused_kernel" + (" (+score)" if args.fused else ""),
+                       "launches_per_step": "lsh_embed_score" if fused else "lsh_embed + rowdot"},
+            "roofline": {"bound": "hbm", "kernel": "lsh_table_kernel<8,SCORE>" if fused else "lsh_table_kernel<8,STORE>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_lookup": per_lookup, "lookups_per_launch": B, "avg_launch_us": kern_ms * 1e3,
                          "traffic": None},

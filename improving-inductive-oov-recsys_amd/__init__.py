@@ -12,7 +12,7 @@ import sys as _sys
 from . import _cabi, ops, embedders, mapper, factory, model, sharded  # noqa: F401
 from ._cabi import LIB_PATH, MiOovError, available  # noqa: F401
 from .embedders import (AbstractInductiveEmbedder, DeepHashEmbedder, DNNEmbedder, FeatDeepHashEmbedder,  # noqa: F401
-                        InductiveFeatureCache, KNNInductiveEmbedder, LSHInductiveEmbedder, MeanEmbedder,
+                        FeatureTable, InductiveFeatureCache, KNNInductiveEmbedder, LSHInductiveEmbedder, MeanEmbedder,
                         SingleLSHInductiveEmbedder, TorchLSHash, ZeroEmbedder)
 from .factory import get_inductive_embedder, get_inductive_mapper  # noqa: F401
 from .mapper import AbstractInductiveMapper, RandomOOVInductiveMapper  # noqa: F401

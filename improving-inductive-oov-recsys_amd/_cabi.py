@@ -87,7 +87,7 @@ def dev_tensor(t, dtype, name):
     """Validate a tensor that is handed to a kernel: ROCm device, dtype, dense row-major."""
     if not isinstance(t, torch.Tensor):
         raise TypeError(f"{name} must be a torch.Tensor")
-    if t.device.type != "cuda":
+    if not t.is_cuda:
         raise RuntimeError(f"{name} is on {t.device}: mi_oov kernels run on an MI355X (ROCm) device only; "
                            "there is no CPU fallback")
     if t.dtype != dtype:
@@ -97,20 +97,31 @@ def dev_tensor(t, dtype, name):
     return t
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_of(t) -> int:
+    """hipStream_t of torch's current stream on the tensor's device, as an int (raw handle)."""
+    idx = t.device.index
+    if _raw_stream is not None and idx is not None:
+        return _raw_stream(idx)
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
 class on_device:
-    """Make the tensor's device current for the duration of a launch (no-op when it already is)."""
+    """Make the tensor's device current for the duration of a launch (no-op when it already is:
+    one process per GPU is the deployment model, so the fast path is a single integer compare)."""
+
+    __slots__ = ("idx", "prev")
 
     def __init__(self, t):
-        self.idx = t.device.index if t.device.index is not None else torch.cuda.current_device()
+        self.idx = t.device.index
         self.prev = None
 
     def __enter__(self):
-        cur = torch.cuda.current_device()
-        if cur != self.idx:
+        cur = _get_device() if _get_device is not None else torch.cuda.current_device()
+        if self.idx is not None and cur != self.idx:
             self.prev = cur
             torch.cuda.set_device(self.idx)
 

@@ -31,6 +31,30 @@ from torch import nn
 from . import ops
 
 
+class FeatureTable:
+    """Minimal stand-in for the RecBole `Interaction` the reference passes as user/item features
+    (R/data/interaction.py): ordered named columns of equal length, column 0 being the id.
+    Anything with `.columns`, `[name] -> Tensor` and `len() -> rows` works; this class lets the
+    package be driven without RecBole's data layer (which is out of scope)."""
+
+    def __init__(self, columns):
+        self._cols = dict(columns)
+        lens = {int(v.shape[0]) for v in self._cols.values()}
+        if len(lens) > 1:
+            raise ValueError(f"columns have different lengths: {sorted(lens)}")
+        self._len = lens.pop() if lens else 0
+
+    @property
+    def columns(self):
+        return list(self._cols.keys())
+
+    def __getitem__(self, name):
+        return self._cols[name]
+
+    def __len__(self):
+        return self._len
+
+
 class AbstractInductiveEmbedder(nn.Module):
     """abstract_embedder.py:5-70: ctor bookkeeping, train/eval toggles, abstract embed methods."""
 

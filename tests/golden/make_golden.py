@@ -166,7 +166,11 @@ def gen_lsh_case(name, n, ucols, icols, norm, n_ub, n_ib, D, B, seed, train):
         user_emb=np_(ue), item_emb=np_(ie),
         user_margin=np_(margins(emb.user_feature_mat, uids, up)),
         item_margin=np_(margins(emb.item_feature_mat, iids, ip)),
-        train=np.array(train), norm=np.array(norm))
+        train=np.array(train), norm=np.array(norm),
+        # raw Interaction columns (small cases only): inputs of the ctor-time feature build
+        **({"ucol_" + c: np_(uf[c]) for c in uf.columns} if name in ("mixed", "global") else {}),
+        **({"icol_" + c: np_(itf[c]) for c in itf.columns} if name in ("mixed", "global") else {}),
+        ucols=np.array(list(uf.columns)), icols=np.array(list(itf.columns)))
     nan_rows = int(torch.isnan(ie).any(1).sum())
     print(f"lsh_{name}.npz  F_u={emb.user_feature_mat.shape[1]} F_i={emb.item_feature_mat.shape[1]} "
           f"H={n_ib} D={D} B={B} nan_rows(item)={nan_rows} min_margin={float(margins(emb.item_feature_mat, iids, ip)[1:].min()):.3e}")
@@ -244,9 +248,9 @@ def gen_siphash_dhe():
     out["survey_k4"] = sv
     assert sv[0] == [7766439, 3375036, 11690175, 4162672], sv
     json.dump(out, open(os.path.join(HERE, "siphash.json"), "w"))
-    sd = {k: np_(v) for k, v in emb.state_dict().items() if k.startswith("item_hash_net") or k.startswith("user_hash_net")}
+    sd = {k: np_(v) for k, v in emb.state_dict().items() if k.startswith("item_hash_net")}
     np.savez_compressed(os.path.join(HERE, "dhe.npz"), ids=np_(ids), hashes=np_(hm), item_pre_sigmoid=np_(pre),
-                        item_out=np_(oute), user_out=np_(outu),
+                        item_out=np_(oute),
                         keys=np.frombuffer(b"".join(keys), dtype=np.uint8).reshape(K, 16),
                         **{k.replace(".", "__"): v for k, v in sd.items()})
     print("siphash.json, dhe.npz  hashes[0,:4] =", hm[0, :4].tolist())
@@ -348,11 +352,11 @@ def main():
     vec64 = [("vec", 64, "float")]
     mixed_u = [("age", 1, "float"), ("gender", 1, "token"), ("occ", 1, "token"), ("zip", 1, "float")]
     mixed_i = [("year", 1, "float"), ("title", 12, "token"), ("genre", 9, "float")]
-    gen_lsh_case("f64", 4096, vec64, vec64, "per-feature", 8, 8, 64, 2048, 100, train=False)
+    gen_lsh_case("f64", 2048, vec64, vec64, "per-feature", 8, 8, 64, 2048, 100, train=False)
     gen_lsh_case("mixed", 1500, mixed_u, mixed_i, "per-feature", 8, 8, 64, 1024, 200, train=True)
     gen_lsh_case("global", 900, [("a", 3, "float"), ("b", 7, "float")], [("c", 2, "float"), ("d", 5, "float"), ("e", 3, "float")],
                  "global", 16, 12, 32, 512, 300, train=False)
-    gen_lsh_case("wide", 700, [("v", 130, "float")], [("w", 300, "float"), ("s", 1, "float")], "none", 5, 40, 50, 384, 400,
+    gen_lsh_case("wide", 400, [("v", 130, "float")], [("w", 300, "float"), ("s", 1, "float")], "none", 5, 40, 50, 384, 400,
                  train=False)
     gen_slsh_case("b8", 1200, mixed_u, vec64, "per-feature", 8, 8, 64, 1024, 500, train=True)
     gen_slsh_case("b1000", 800, [("v", 20, "float")], [("w", 33, "float")], "none", 1000, 777, 24, 512, 600, train=False)

@@ -1,0 +1,43 @@
+"""CPU: the C-ABI shared library loads and exports every symbol include/mi_oov.h declares.
+No compute is launched here (there is no GPU in the build container)."""
+import ctypes
+
+import pytest
+
+import __graft_entry__ as entry
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import mi_oov
+    if not mi_oov.available():
+        entry.build()
+    return mi_oov._cabi.lib()
+
+
+def test_every_header_symbol_is_exported(lib):
+    syms = entry.header_symbols()
+    assert len(syms) >= 20
+    raw = ctypes.CDLL(__import__("mi_oov").LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/mi_oov.h but not exported"
+    from mi_oov import _cabi
+    assert set(_cabi.EXPORTS) == set(syms), "ctypes signature table out of sync with the header"
+
+
+def test_version_and_strerror(lib):
+    assert lib.mi_oov_version() == 100
+    assert lib.mi_oov_strerror(0) == b"ok"
+    for code in range(-6, 0):
+        assert lib.mi_oov_strerror(code) != b"unknown error code"
+    assert lib.mi_oov_strerror(-99) == b"unknown error code"
+
+
+def test_argument_validation_without_gpu(lib):
+    # shape/NULL validation happens before any HIP call, so it is safe on a GPU-less host
+    assert lib.mi_oov_lsh_embed(None, 0, None, 10, 4, None, 2, None, 4, None, None, None) == 0  # empty batch
+    assert lib.mi_oov_lsh_embed(None, 5, None, 10, 4, None, 2, None, 4, None, None, None) == -1  # NULL
+    assert lib.mi_oov_lsh_embed(None, -1, None, 10, 4, None, 2, None, 4, None, None, None) == -2  # shape
+    assert lib.mi_oov_mapper_map(None, 5, 9, 1, 1, None, None) == -3  # unknown hash kind
+    assert lib.mi_oov_siphash24_mod(None, 5, None, 4, 1000, None, None) == -2  # mod not a power of two
+    assert lib.mi_oov_col_mean_workspace(10_000_000, 64) == 2442 * 64

@@ -1,0 +1,267 @@
+"""-m gpu: the host-side plugin mirror driven end to end on the MI355X against what the real
+reference produced for the same inputs (tests/golden), plus autograd and full-size properties."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+PRIME_PAD = 112062759511
+
+
+class Cfg(dict):
+    def __getitem__(self, k):
+        return self.get(k, None)
+
+
+class DS:
+    def __init__(self, n_users, n_items):
+        self.n = {"user_id": n_users, "item_id": n_items}
+
+    def num(self, f):
+        return self.n[f]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def close(a, b, rtol=RTOL):
+    assert np.array_equal(np.isnan(a), np.isnan(b))
+    m = ~np.isnan(b)
+    return np.abs(a[m] - b[m]).max() <= rtol * max(1e-30, np.abs(b[m]).max())
+
+
+@pytest.fixture(scope="module")
+def mi():
+    import mi_oov
+    return mi_oov
+
+
+def test_lsh_embedder_class_train_mode(mi, golden, dev):
+    """LSHInductiveEmbedder built from the raw feature columns, planes loaded like a checkpoint,
+    train mode with prime-padded ids: same embeddings and the same in-place id strip as the
+    reference (lsh_embedder.py:153-155)."""
+    z = golden("lsh_mixed.npz")
+    uf = mi.FeatureTable({c: torch.from_numpy(z["ucol_" + c]) for c in z["ucols"]})
+    itf = mi.FeatureTable({c: torch.from_numpy(z["icol_" + c]) for c in z["icols"]})
+    emb = mi.LSHInductiveEmbedder(uf, itf, 750, 750, 8, 8, 64, dev, PRIME_PAD, "per-feature",
+                                  mi.InductiveFeatureCache())
+    emb.load_state_dict({"user_lsh.uniform_planes.0": T(z["user_planes"], dev),
+                         "item_lsh.uniform_planes.0": T(z["item_planes"], dev)})
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.user_oov_buckets = torch.nn.Embedding.from_pretrained(T(z["user_buckets"], dev), freeze=False)
+            self.item_oov_buckets = torch.nn.Embedding.from_pretrained(T(z["item_buckets"], dev), freeze=False)
+
+    model = M()
+    emb.set_train()
+    for side, fn in (("user", emb.embed_user_ids), ("item", emb.embed_item_ids)):
+        ids = T(z[side + "_ids_in"], dev)
+        with torch.no_grad():
+            out = fn(ids, model)
+        assert np.array_equal(ids.cpu().numpy(), z[side + "_ids_after"])  # mutated in place
+        assert close(out.cpu().numpy(), z[side + "_emb"])
+    # gradient reaches the bucket table (and only it): d/dW of (bits @ W)/popcount
+    ids = T(z["item_ids"], dev)
+    out = emb.embed_item_ids(ids.clone(), model)
+    good = ~torch.isnan(out).any(1)
+    out[good].sum().backward()
+    bits = T(z["item_bits"], dev).float()[good]
+    want = (bits / bits.sum(1, keepdim=True)).sum(0)[:, None].expand(-1, 64)
+    assert torch.allclose(model.item_oov_buckets.weight.grad, want, rtol=1e-5, atol=1e-6)
+    assert emb.item_lsh.uniform_planes[0].grad is None
+
+
+def test_slsh_embedder_class(mi, golden, dev):
+    z = golden("slsh_b1000.npz")
+    emb = mi.SingleLSHInductiveEmbedder(mi.FeatureTable({"user_id": torch.arange(800), "v": torch.zeros(800, 20)}),
+                                        mi.FeatureTable({"item_id": torch.arange(811), "w": torch.zeros(811, 33)}),
+                                        400, 400, 1000, 777, 24, dev, PRIME_PAD, "none")
+    emb.user_feature_mat, emb.item_feature_mat = T(z["user_feat"], dev), T(z["item_feat"], dev)
+    emb.load_state_dict({"user_lsh.uniform_planes.0": T(z["user_planes"], dev),
+                         "item_lsh.uniform_planes.0": T(z["item_planes"], dev)})
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.user_oov_buckets = torch.nn.Embedding.from_pretrained(T(z["user_buckets"], dev), freeze=False)
+            self.item_oov_buckets = torch.nn.Embedding.from_pretrained(T(z["item_buckets"], dev), freeze=False)
+
+    model = M()
+    assert np.array_equal(emb._hash_items(T(z["item_ids"], dev)).cpu().numpy(), z["item_idx"])
+    out = emb.embed_user_ids(T(z["user_ids"], dev), model)
+    assert bits_equal(out.detach().cpu().numpy(), z["user_emb"])
+    out.sum().backward()  # nn.Embedding-style dense gradient: row counts
+    want = np.bincount(z["user_idx"], minlength=1000).astype(np.float32)
+    assert np.array_equal(model.user_oov_buckets.weight.grad[:, 0].cpu().numpy(), want)
+
+
+def test_dhe_embedder_class(mi, golden, dev, tmp_path, monkeypatch):
+    z, s = golden("dhe.npz"), golden("siphash.json")
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("hash_keys")
+    json.dump(s["dhe_keys"], open("hash_keys/16.hashes", "w"))  # the reference's key file protocol
+    ft = mi.FeatureTable({"id": torch.arange(64), "f": torch.zeros(64)})
+    emb = mi.DeepHashEmbedder(ft, ft, 32, 32, 8, 8, 8, dev, PRIME_PAD, 16)
+    sd = emb.state_dict()
+    for k in z.files:
+        if k.startswith("item_hash_net"):
+            sd[k.replace("__", ".")] = T(z[k], dev)
+    emb.load_state_dict(sd)
+    ids = T(z["ids"], dev)
+    with torch.no_grad():
+        hashes = emb._hash_ids(ids)
+        pre = emb.item_hash_net[:-1](hashes)
+        out = emb.embed_item_ids(ids, None)
+    assert np.array_equal(hashes.cpu().numpy(), z["hashes"])  # bit-exact integer work
+    # raw hashes (~1e7) feed the first Linear un-normalised: compare pre-sigmoid with a GEMM-order tolerance
+    ref = z["item_pre_sigmoid"]
+    assert np.abs(pre.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    assert np.abs(out.cpu().numpy() - z["item_out"]).max() <= 1e-5
+
+
+def test_knn_mean_classes(mi, golden, dev):
+    z = golden("knn.npz")
+    n_users, n_items = int(z["n_users"]), int(z["n_items"])
+    ft_u = mi.FeatureTable({"id": torch.arange(z["user_feat"].shape[0]), "f": torch.from_numpy(z["user_feat"])})
+    ft_i = mi.FeatureTable({"id": torch.arange(z["item_feat"].shape[0]), "f": torch.from_numpy(z["item_feat"])})
+    knn = mi.KNNInductiveEmbedder(ft_u, ft_i, n_users, n_items, 8, 8, 16, dev, PRIME_PAD, n_neighbors=2)
+    knn.user_feature_mat, knn.item_feature_mat = T(z["user_feat"], dev), T(z["item_feat"], dev)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.user_embedding = torch.nn.Embedding.from_pretrained(T(z["user_table"], dev), freeze=False)
+            self.item_embedding = torch.nn.Embedding.from_pretrained(T(z["item_table"], dev), freeze=False)
+
+    model = M()
+    for side, hashfn, fn in (("user", knn._hash_users, knn.embed_user_ids), ("item", knn._hash_items, knn.embed_item_ids)):
+        ids = T(z[side + "_ids"], dev)
+        idx = hashfn(ids).cpu().numpy()
+        # exact search == the exact stand-in used when the fixture was generated (ScaNN itself: unpinned)
+        assert (idx == z[side + "_idx"]).mean() > 0.99
+        same = (idx == z[side + "_idx"]).all(1)
+        out = fn(ids.clone(), model)
+        assert close(out.detach().cpu().numpy()[same], z[side + "_emb"][same])
+    out.sum().backward()
+    assert model.item_embedding.weight.grad.abs().sum() > 0
+    z = golden("mean.npz")
+    mean = mi.MeanEmbedder(ft_u, ft_i, n_users, n_items, 8, 8, 16, dev)
+    model.user_embedding = torch.nn.Embedding.from_pretrained(T(z["user_table"], dev))
+    model.item_embedding = torch.nn.Embedding.from_pretrained(T(z["item_table"], dev))
+    assert close(mean.embed_user_ids(T(z["user_ids"], dev), model).cpu().numpy(), z["user_emb"])
+    assert close(mean.embed_item_ids(T(z["item_ids"], dev), model).cpu().numpy(), z["item_emb"])
+    model.item_embedding.weight.data.zero_()  # cache is never invalidated (mean_embedder.py:54-56)
+    assert close(mean.embed_item_ids(T(z["item_ids"], dev), model).cpu().numpy(), z["item_emb"])
+    zero = mi.ZeroEmbedder(ft_u, ft_i, n_users, n_items, 16, dev)
+    assert not zero.embed_user_ids(T(z["user_ids"], dev), model).any()
+
+
+@pytest.mark.parametrize("with_grad", [False, True])
+def test_bpr_model(mi, golden, dev, with_grad):
+    z = golden("bpr_lsh.npz")
+    n_users, n_items = int(z["n_users"]), int(z["n_items"])
+    cfg = Cfg(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device=dev, embedding_size=64,
+              add_oov_buckets=True, user_oov_buckets=8, item_oov_buckets=8, oov_freeze_embedding=False)
+    ft_u = mi.FeatureTable({"id": torch.arange(z["user_feat"].shape[0]), "f": torch.from_numpy(z["user_feat"])})
+    ft_i = mi.FeatureTable({"id": torch.arange(z["item_feat"].shape[0]), "f": torch.from_numpy(z["item_feat"])})
+    lsh = mi.LSHInductiveEmbedder(ft_u, ft_i, n_users, n_items, 8, 8, 64, dev, PRIME_PAD, "none",
+                                  mi.InductiveFeatureCache())
+    bpr = mi.BPR(cfg, DS(n_users, n_items), None, lsh).to(dev)
+    bpr.load_state_dict({"inductive_embedder.user_lsh.uniform_planes.0": T(z["user_planes"], dev),
+                         "inductive_embedder.item_lsh.uniform_planes.0": T(z["item_planes"], dev),
+                         "user_oov_buckets.weight": T(z["user_buckets"], dev),
+                         "item_oov_buckets.weight": T(z["item_buckets"], dev),
+                         "user_embedding.weight": T(z["user_table"], dev),
+                         "item_embedding.weight": T(z["item_table"], dev)})
+    users, items = T(z["users"], dev), T(z["items"], dev)
+    inter = {"user_id": users, "item_id": items}
+    ctx = torch.enable_grad() if with_grad else torch.no_grad()
+    with ctx:  # with_grad exercises the gather/splice/autograd path, without it the one-launch lsh_lookup
+        ue, ie = bpr.get_user_embedding(users.clone()), bpr.get_item_embedding(items.clone())
+        pred = bpr.predict(inter)
+        fs = bpr.full_sort_predict({"user_id": users[:40]})
+        ifs = bpr.ind_full_sort_predict({"user_id": users[:40]}, torch.arange(z["item_feat"].shape[0], device=dev))
+    assert close(ue.detach().cpu().numpy(), z["user_e"]) and close(ie.detach().cpu().numpy(), z["item_e"])
+    m = ~np.isnan(z["predict"])
+    assert np.allclose(pred.detach().cpu().numpy()[m], z["predict"][m], rtol=RTOL, atol=1e-6)
+    for got, ref in ((fs, z["full_sort"]), (ifs, z["ind_full_sort"])):
+        got = got.detach().cpu().numpy()
+        assert got.shape == ref.shape
+        mm = ~np.isnan(ref)
+        assert np.array_equal(np.isnan(got), ~mm) and np.allclose(got[mm], ref[mm], rtol=RTOL, atol=1e-6)
+    if with_grad:
+        neg = torch.randint(1, n_items, items.shape, device=dev)
+        keep = ~torch.isnan(pred)
+        loss = bpr.calculate_loss({"user_id": users[keep], "item_id": items[keep], "neg_item_id": neg[keep]})
+        loss.backward()
+        assert torch.isfinite(loss)
+        for p in (bpr.user_embedding.weight, bpr.item_embedding.weight):
+            assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().sum() > 0
+    # mapper-only model (no embedder): OOV ids hash to bucket rows (bpr.py:75,122)
+    mp = mi.RandomOOVInductiveMapper(ft_u, ft_i, n_users, n_items, 8, 8, 64, dev, PRIME_PAD, "3round")
+    bm = mi.BPR(cfg, DS(n_users, n_items), mp, None).to(dev)
+    bm.load_state_dict({"user_oov_buckets.weight": T(z["m_user_buckets"], dev),
+                        "item_oov_buckets.weight": T(z["m_item_buckets"], dev),
+                        "user_embedding.weight": T(z["m_user_table"], dev),
+                        "item_embedding.weight": T(z["m_item_table"], dev)})
+    with torch.no_grad():
+        assert bits_equal(bm.get_user_embedding(users.clone()).cpu().numpy(), z["m_user_e"])
+        assert bits_equal(bm.get_item_embedding(items.clone()).cpu().numpy(), z["m_item_e"])
+        assert np.allclose(bm.predict(inter).cpu().numpy(), z["m_predict"], rtol=RTOL, atol=1e-6)
+        vals, idx = bm.full_sort_topk({"user_id": users[:16]}, 10)
+        scores = bm.full_sort_predict({"user_id": users[:16]}).view(16, -1)
+        scores[:, 0] = -float("inf")
+        tv, _ = torch.topk(scores, 10)
+        assert torch.equal(vals, tv) and (idx > 0).all()
+
+
+def test_full_size_properties(mi, dev):
+    """BASELINE-size run (10 M x 64 table, batch 65536): size-independent properties instead of an
+    oracle pass -- determinism, code consistency between the hash-only and the embedding kernels,
+    linearity in the bucket table, permutation equivariance, and the fused score identity."""
+    from mi_oov import ops
+    g = torch.Generator(device=dev).manual_seed(0)
+    N, B, F, H, D = 10_000_000, 65536, 64, 8, 64
+    feat = torch.nn.functional.normalize(torch.randn((N, F), generator=g, device=dev), dim=-1)
+    planes = torch.randn((H, F), generator=g, device=dev)
+    W = torch.randn((H, D), generator=g, device=dev)
+    ids = torch.randint(0, N, (B,), generator=g, device=dev)
+    users = torch.randn((B, D), generator=g, device=dev)
+    e1 = ops.lsh_embed(ids, feat, planes, W)
+    assert torch.equal(torch.nan_to_num(e1), torch.nan_to_num(ops.lsh_embed(ids, feat, planes, W)))
+    bits = ops.lsh_bits(ids, feat, planes).float()
+    cnt = bits.sum(1, keepdim=True)
+    nan_rows = torch.isnan(e1).any(1)
+    assert torch.equal(nan_rows, cnt[:, 0] == 0) and 100 < int(nan_rows.sum()) < 500  # ~2^-8 of the rows
+    ok = ~nan_rows
+    ref = (bits @ W) / cnt  # same definition, BLAS order
+    assert torch.allclose(e1[ok], ref[ok], rtol=1e-5, atol=1e-6)
+    # one-hot bucket table: the embedding IS the normalised code
+    onehot = torch.eye(H, D, device=dev)
+    code = ops.lsh_embed(ids, feat, planes, onehot)[:, :H]
+    assert torch.equal(code[ok] * cnt[ok], bits[ok])
+    # linearity in the bucket table (exact for a power-of-two scale)
+    assert torch.equal(torch.nan_to_num(ops.lsh_embed(ids, feat, planes, 4.0 * W)), torch.nan_to_num(4.0 * e1))
+    perm = torch.randperm(B, generator=g, device=dev)
+    assert torch.equal(torch.nan_to_num(ops.lsh_embed(ids[perm], feat, planes, W)), torch.nan_to_num(e1[perm]))
+    s = ops.lsh_embed_score(ids, feat, planes, W, users)
+    assert torch.equal(torch.nan_to_num(s), torch.nan_to_num(ops.rowdot(users, e1)))  # fused == unfused, bitwise
+    # slsh at full size: idx in range and consistent with the code popcount
+    idx = ops.slsh_index(ids, feat, planes[:3], 8)
+    pop = ops.lsh_bits(ids, feat, planes[:3]).sum(1)
+    assert torch.equal(idx, (3 + pop.long()) % 8)
+    # ids that hash to the mapper: idempotent on in-vocabulary ids, in range otherwise
+    mapped = ops.mapper_map(ids, "3round", N // 2, 1000)
+    assert torch.equal(mapped[ids < N // 2], ids[ids < N // 2])
+    oov = mapped[ids >= N // 2]
+    assert int(oov.min()) >= N // 2 and int(oov.max()) < N // 2 + 1000
+    assert torch.equal(ops.mapper_map(mapped, "3round", N // 2 + 1000, 7), mapped)
