@@ -94,7 +94,7 @@ def cpu_baseline(args, feat, planes, buckets, seconds):
     g = torch.Generator().manual_seed(7)
     users = torch.randn((args.batch, args.dim), generator=g)
     n_done, t_total = 0, 0.0
-    for it in range(1000):
+    for it in range(100000):
         ids = torch.randint(0, f.shape[0], (args.batch,), generator=g)
         t0 = time.perf_counter()
         e = ref_torch.lsh_embed(ids, f, p, w)
@@ -109,6 +109,25 @@ def cpu_baseline(args, feat, planes, buckets, seconds):
     return {"value": n_done * args.batch / t_total, "unit": "lookups/s", "cores": cores, "kind": "port",
             "sample": f"{n_done} batches of {args.batch} lookups+scores through the reference's torch-CPU op "
                       f"sequence (oracle/ref_torch.py), {t_total:.1f} s, torch.set_num_threads({cores})"}
+
+
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/*_bench_summary.json, written by tools/summarize_profile.py from separate --pmc
+    FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  FETCH_SIZE/WRITE_SIZE are in KiB; on
+    gfx950 FETCH_SIZE reports half of the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM
+    section), hence the factor 2.  None when no profile is committed for this kernel."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_summary.json"))):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        for k, v in d.get("pmc_per_launch", {}).items():
+            if k.startswith(kernel_prefix) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                best = (2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0
+    return best
 
 
 def main():
@@ -220,11 +239,12 @@ def main():
                        "items": N, "feat": F, "dim": D, "hashes": H, "batch_per_gpu": B,
                        "table": "row-sharded + all-to-all" if (args.sharded and world > 1) else "replicated per GPU",
                        "launches_per_step": "lsh_embed_score" if fused else "lsh_embed + rowdot"},
-            "roofline": {"bound": "hbm", "kernel": "lsh_table_kernel<8,SCORE>" if fused else "lsh_table_kernel<8,STORE>",
+            "roofline": {"bound": "hbm", "kernel": "lsh_table_kernel<8, true, false" if fused else "lsh_table_kernel<8, false, true",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_lookup": per_lookup, "lookups_per_launch": B, "avg_launch_us": kern_ms * 1e3,
                          "traffic": None},
         }
+        out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, feat, planes, buckets, args.cpu_seconds)
         print(json.dumps(out), flush=True)
