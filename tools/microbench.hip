@@ -8,6 +8,9 @@
 #include <vector>
 
 #include "mi_oov.h"
+#include "../improving-inductive-oov-recsys_amd/csrc/common.hpp"
+using namespace mi_oov;
+namespace mi_oov { thread_local int g_last_hip_error = 0; }
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
@@ -81,6 +84,64 @@ __global__ __launch_bounds__(256) void work_kernel(const int64_t* __restrict__ i
   }
 }
 
+// Staged replica of the hot lsh kernel (score variant): which stage costs what?
+//  STAGE 0 loads (x,u) + one DPP reduce   1 + 8 projections   2 + aggregate   3 + division   4 + score
+template <int STAGE, int R>
+__global__ __launch_bounds__(256) void staged_kernel(const int64_t* __restrict__ ids, int64_t B,
+                                                     const float* __restrict__ feat, const float* __restrict__ planes,
+                                                     const float* __restrict__ buckets, const float* __restrict__ other,
+                                                     float* __restrict__ score) {
+  constexpr int H = 8;
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
+  float4 pw[H], bw[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    pw[h] = *reinterpret_cast<const float4*>(planes + h * 64 + l16 * 4);
+    bw[h] = *reinterpret_cast<const float4*>(buckets + h * 64 + l16 * 4);
+  }
+  for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
+    int64_t row[R], id[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      if (row[r] >= B) row[r] = B - 1;
+      id[r] = ids[row[r]];
+    }
+    float4 u[R], x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
+#pragma unroll
+    for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const float4*>(feat + id[r] * 64 + l16 * 4);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float cnt = 0.f;
+      if (STAGE == 0) {
+        acc = make_float4(x[r].x + u[r].x, x[r].y + u[r].y, x[r].z + u[r].z, x[r].w + u[r].w);
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float s = row16_sum(dot4_fma(x[r], pw[h], 0.f));
+          const float bit = (s < 0.f) ? 0.f : 1.f;
+          cnt = cnt + bit;
+          if (STAGE >= 2) {
+            acc.x = __builtin_fmaf(bit, bw[h].x, acc.x); acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
+            acc.z = __builtin_fmaf(bit, bw[h].z, acc.z); acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+          }
+        }
+        if (STAGE == 1) acc = make_float4(cnt + u[r].x, u[r].y, u[r].z, u[r].w);
+      }
+      if (STAGE >= 3) { acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt; }
+      float sp;
+      if (STAGE >= 4) sp = dot4_muladd(u[r], acc, 0.f);
+      else sp = (acc.x + acc.y) + (acc.z + acc.w) + ((STAGE == 2 || STAGE == 3) ? u[r].x + u[r].y + u[r].z + u[r].w : 0.f);
+      const float s = row16_sum(sp);
+      if (l16 == 0) score[row[r]] = s;
+    }
+  }
+}
+
 template <typename F>
 static float time_it(F launch, int iters) {
   hipEvent_t a, b;
@@ -133,6 +194,23 @@ int main(int argc, char** argv) {
   RUNW(4, 32, false, "copy+work R=4 W=32") RUNW(4, 64, false, "copy+work R=4 W=64")
   RUNW(4, 16, true, "copy+work(dpp) R=4 W=16") RUNW(4, 32, true, "copy+work(dpp) R=4 W=32")
   RUNW(8, 32, false, "copy+work R=8 W=32") RUNW(2, 32, false, "copy+work R=2 W=32")
+  {
+    float *planes2, *buckets2, *users2, *score2;
+    CK(hipMalloc(&planes2, 8 * 64 * 4)); CK(hipMalloc(&buckets2, 8 * 64 * 4));
+    CK(hipMalloc(&users2, 8 * B * 64 * 4)); CK(hipMalloc(&score2, B * 4));
+    CK(hipMemset(planes2, 0, 2048)); CK(hipMemset(buckets2, 0, 2048)); CK(hipMemset(users2, 0, 8 * B * 64 * 4));
+#define RUNS(STAGE, R, NAME)                                                                              \
+    {                                                                                                     \
+      int64_t tiles = (B + 4 * R - 1) / (4 * R);                                                          \
+      int grid = (int)((tiles + 3) / 4);                                                                  \
+      float us = time_it([&](int i) { hipLaunchKernelGGL((staged_kernel<STAGE, R>), dim3(grid), dim3(256), 0, 0, ids + (int64_t)i * B, B, feat, planes2, buckets2, users2 + (int64_t)(i % 8) * B * 64, score2); }, iters); \
+      printf("%-44s %8.2f us  %7.1f GB/s\n", NAME, us, B * 532.0 / us / 1e3);                              \
+    }
+    RUNS(0, 4, "staged 0: loads x,u + reduce   R=4") RUNS(1, 4, "staged 1: + 8 projections       R=4")
+    RUNS(2, 4, "staged 2: + aggregate           R=4") RUNS(3, 4, "staged 3: + division            R=4")
+    RUNS(4, 4, "staged 4: + score (full)        R=4")
+    RUNS(0, 2, "staged 0 R=2") RUNS(4, 2, "staged 4 (full) R=2") RUNS(4, 1, "staged 4 (full) R=1") RUNS(4, 8, "staged 4 (full) R=8")
+  }
   lib_cases:
   {
     // the product kernels through the C ABI (variant chosen by MI_OOV_LSH64_VARIANT)
