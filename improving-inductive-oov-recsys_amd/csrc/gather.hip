@@ -88,10 +88,16 @@ __global__ __launch_bounds__(kBlock) void gather_mean_kernel(const int64_t* __re
 }
 
 // ---- column mean -------------------------------------------------------------------------------
-// Partition p owns rows [p*kPartRows, (p+1)*kPartRows); inside it row-group gr (0..15) sums rows
-// gr, gr+16, ... sequentially; the 16 group sums are added in order gr = 0..15; the partition
-// partials are added in order p = 0..P-1 and divided by N.  oracle/oov_oracle.c mirrors this.
-constexpr int kPartRows = 4096;
+// Deterministic two-pass order, mirrored by oracle/oov_oracle.c::oov_col_mean:
+//   rows are cut in P <= 1024 partitions of RP = col_part_rows(N) rows; inside a partition row-group
+//   gr (0..15) sums rows gr, gr+16, ... sequentially and the 16 group sums are added in order;
+//   the P partials of a column are then dealt to 64 lanes (p mod 64), each lane adds its partials in
+//   increasing p, and the 64 lane sums are combined by a stride-halving tree (32,16,...,1); / N.
+__host__ __device__ inline int64_t col_part_rows(int64_t N) {
+  int64_t rp = (N + 1023) / 1024;
+  rp = (rp + 15) / 16 * 16;
+  return rp < 16 ? 16 : rp;
+}
 
 template <bool VEC>
 __global__ __launch_bounds__(kBlock) void col_partial_kernel(const float* __restrict__ W, int64_t N, int64_t D,
@@ -100,10 +106,11 @@ __global__ __launch_bounds__(kBlock) void col_partial_kernel(const float* __rest
   const int gr = threadIdx.x >> 4, l16 = threadIdx.x & 15;
   const int dchunks = static_cast<int>((D + 63) / 64);
   const int DP = dchunks * 64;
-  const int64_t P = (N + kPartRows - 1) / kPartRows;
+  const int64_t RP = col_part_rows(N);
+  const int64_t P = (N + RP - 1) / RP;
   for (int64_t part = blockIdx.x; part < P; part += gridDim.x) {
-    const int64_t r0 = part * kPartRows;
-    const int64_t r1 = (r0 + kPartRows < N) ? r0 + kPartRows : N;
+    const int64_t r0 = part * RP;
+    const int64_t r1 = (r0 + RP < N) ? r0 + RP : N;
     for (int c = 0; c < dchunks; ++c) {
       const int e = (c * 16 + l16) * 4;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -124,13 +131,17 @@ __global__ __launch_bounds__(kBlock) void col_partial_kernel(const float* __rest
   }
 }
 
+// one wave per column
 __global__ __launch_bounds__(kBlock) void col_final_kernel(const float* __restrict__ partial, int64_t P, int64_t N,
                                                            int64_t D, float* __restrict__ mean) {
-  const int64_t d = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int64_t d = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
   if (d >= D) return;
   float s = 0.f;
-  for (int64_t p = 0; p < P; ++p) s += partial[p * D + d];
-  mean[d] = s / static_cast<float>(N);
+  for (int64_t p = lane; p < P; p += 64) s += partial[p * D + d];
+#pragma unroll
+  for (int stride = 32; stride >= 1; stride >>= 1) s = s + __shfl_xor(s, stride, 64);
+  if (lane == 0) mean[d] = s / static_cast<float>(N);
 }
 
 template <bool VEC>
@@ -238,14 +249,16 @@ extern "C" int mi_oov_gather_mean(const int64_t* idx, int64_t M, int64_t g, cons
 
 extern "C" int64_t mi_oov_col_mean_workspace(int64_t N, int64_t D) {
   if (N <= 0 || D <= 0) return 0;
-  return ((N + kPartRows - 1) / kPartRows) * D;
+  const int64_t RP = col_part_rows(N);
+  return ((N + RP - 1) / RP) * D;
 }
 
 extern "C" int mi_oov_col_mean(const float* W, int64_t N, int64_t D, float* mean, float* workspace, void* stream) {
   if (N <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
   if (!W || !mean || !workspace) return MI_OOV_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int64_t P = (N + kPartRows - 1) / kPartRows;
+  const int64_t RP = col_part_rows(N);
+  const int64_t P = (N + RP - 1) / RP;
   const int dchunks = static_cast<int>((D + 63) / 64);
   const size_t lds = static_cast<size_t>(16) * dchunks * 64 * sizeof(float);
   if (lds > 64 * 1024) return MI_OOV_ERR_SHAPE;
@@ -256,7 +269,7 @@ extern "C" int mi_oov_col_mean(const float* W, int64_t N, int64_t D, float* mean
   else
     hipLaunchKernelGGL(col_partial_kernel<false>, dim3(grid), dim3(kBlock), lds, st, W, N, D, workspace);
   if (int rc = check_launch()) return rc;
-  const int g2 = static_cast<int>((D + kBlock - 1) / kBlock);
+  const int g2 = static_cast<int>((D + kBlock / 64 - 1) / (kBlock / 64));
   hipLaunchKernelGGL(col_final_kernel, dim3(g2), dim3(kBlock), 0, st, workspace, P, N, D, mean);
   return check_launch();
 }

@@ -160,6 +160,136 @@ __global__ __launch_bounds__(kBlock) void topk_rows_kernel(const float* __restri
   }
 }
 
+// ---- radix-select top-k (k <= 256): 3 histogram passes + 1 collection pass instead of k passes --
+// Exact: finds the 32-bit order key T of the k-th best score of the row (11 + 11 + 10 bit digits, most
+// significant first), then collects every column with key > T plus, in increasing column order, as
+// many key == T columns as are still needed (ties -> lower index), and finally rank-sorts the <= k
+// winners by (key desc, column asc).  One workgroup per row.
+constexpr int kSelBins = 2048;
+
+__device__ __forceinline__ int block_excl_scan(int v, int* wave_tot, int& total) {
+  // exclusive prefix of v over the 256 threads of the block (wave ballot-free: shuffles + LDS)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  if (lane == 63) wave_tot[wv] = inc;
+  __syncthreads();
+  int base = 0;
+  total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlock / 64; ++w) {
+    if (w < wv) base += wave_tot[w];
+    total += wave_tot[w];
+  }
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kBlock) void topk_select_kernel(const float* __restrict__ S, int64_t rows, int64_t N,
+                                                             int64_t ldS, int k, int64_t n_skip_low,
+                                                             float* __restrict__ vals, int64_t* __restrict__ idx) {
+  __shared__ int hist[kSelBins];
+  __shared__ int part[kBlock];
+  __shared__ int wave_tot[kBlock / 64];
+  __shared__ uint32_t s_prefix, s_pmask;
+  __shared__ int s_krem;
+  __shared__ uint32_t cand_key[256];
+  __shared__ uint32_t cand_idx[256];
+  const int64_t row = blockIdx.x;
+  if (row >= rows) return;
+  const float* srow = S + row * ldS;
+  const int tid = threadIdx.x;
+  const int64_t nvalid = N > n_skip_low ? N - n_skip_low : 0;
+  const int kk = static_cast<int>(nvalid < k ? nvalid : k);  // winners that exist
+  if (tid == 0) { s_prefix = 0; s_pmask = 0; s_krem = kk; }
+  __syncthreads();
+
+  if (kk > 0) {
+    const int shifts[3] = {21, 10, 0};
+    const int nbits[3] = {11, 11, 10};
+    for (int pass = 0; pass < 3; ++pass) {
+      const int shift = shifts[pass], nb = 1 << nbits[pass];
+      for (int i = tid; i < kSelBins; i += kBlock) hist[i] = 0;
+      __syncthreads();
+      const uint32_t prefix = s_prefix, pmask = s_pmask;
+      for (int64_t c = n_skip_low + tid; c < N; c += kBlock) {
+        const uint32_t key = order_key(srow[c]);
+        if ((key & pmask) == prefix) atomicAdd(&hist[(key >> shift) & (nb - 1)], 1);
+      }
+      __syncthreads();
+      // suffix counts: thread t owns bins [t*per, (t+1)*per), scanned from the top bin downwards
+      const int per = nb / kBlock;  // 8 or 4
+      int mine = 0;
+      for (int j = 0; j < per; ++j) mine += hist[tid * per + j];
+      part[tid] = mine;
+      __syncthreads();
+      if (tid == 0) {
+        int krem = s_krem, above = 0, t = kBlock - 1;
+        for (; t > 0; --t) {  // find the owner of the krem-th element counted from the top
+          if (above + part[t] >= krem) break;
+          above += part[t];
+        }
+        int b = t * per + per - 1;
+        for (; b > t * per; --b) {
+          if (above + hist[b] >= krem) break;
+          above += hist[b];
+        }
+        s_krem = krem - above;
+        s_prefix = prefix | (static_cast<uint32_t>(b) << shift);
+        s_pmask = pmask | (static_cast<uint32_t>(nb - 1) << shift);
+      }
+      __syncthreads();
+    }
+    // collection in increasing column order
+    const uint32_t T = s_prefix;
+    const int need_eq = s_krem;       // how many key == T columns are winners
+    const int n_gt = kk - need_eq;    // all key > T columns are winners
+    int base_gt = 0, base_eq = 0;
+    for (int64_t c0 = n_skip_low; c0 < N; c0 += kBlock) {
+      const int64_t c = c0 + tid;
+      uint32_t key = 0;
+      bool gt = false, eq = false;
+      if (c < N) {
+        key = order_key(srow[c]);
+        gt = key > T;
+        eq = key == T;
+      }
+      int tot_gt, tot_eq;
+      const int p_gt = block_excl_scan(gt ? 1 : 0, wave_tot, tot_gt);
+      const int p_eq = block_excl_scan(eq ? 1 : 0, wave_tot, tot_eq);
+      if (gt) {
+        cand_key[base_gt + p_gt] = key;
+        cand_idx[base_gt + p_gt] = static_cast<uint32_t>(c);
+      } else if (eq && base_eq + p_eq < need_eq) {
+        cand_key[n_gt + base_eq + p_eq] = key;
+        cand_idx[n_gt + base_eq + p_eq] = static_cast<uint32_t>(c);
+      }
+      base_gt += tot_gt;
+      base_eq += tot_eq;
+      if (base_gt >= n_gt && base_eq >= need_eq) break;  // uniform: all winners found
+    }
+    __syncthreads();
+    if (tid < kk) {
+      const uint64_t me = (static_cast<uint64_t>(cand_key[tid]) << 32) | (0xFFFFFFFFu - cand_idx[tid]);
+      int rank = 0;
+      for (int j = 0; j < kk; ++j) {
+        const uint64_t o = (static_cast<uint64_t>(cand_key[j]) << 32) | (0xFFFFFFFFu - cand_idx[j]);
+        rank += (o > me) ? 1 : 0;
+      }
+      vals[row * k + rank] = srow[cand_idx[tid]];
+      idx[row * k + rank] = static_cast<int64_t>(cand_idx[tid]);
+    }
+  }
+  for (int t = kk + tid; t < k; t += kBlock) {  // fewer than k candidate columns
+    vals[row * k + t] = -__builtin_inff();
+    idx[row * k + t] = -1;
+  }
+}
+
 static size_t full_sort_lds() { return static_cast<size_t>(BM + BN) * LDK * sizeof(float); }
 
 static int launch_full_sort(const float* U, int64_t B, const float* E, int64_t N, int64_t D, float* S, int64_t ldS,
@@ -217,8 +347,12 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
   for (int64_t b0 = 0; b0 < B; b0 += chunk) {
     const int64_t rows = (b0 + chunk <= B) ? chunk : (B - b0);
     if (int rc = launch_full_sort(U + b0 * D, rows, E, N, D, S, N, st)) return rc;
-    hipLaunchKernelGGL(topk_rows_kernel, dim3(static_cast<unsigned>(rows)), dim3(kBlock), 0, st, S, rows, N, N, k,
-                       n_skip_low, vals + b0 * k, idx + b0 * k);
+    if (k <= 256)
+      hipLaunchKernelGGL(topk_select_kernel, dim3(static_cast<unsigned>(rows)), dim3(kBlock), 0, st, S, rows, N, N,
+                         static_cast<int>(k), n_skip_low, vals + b0 * k, idx + b0 * k);
+    else
+      hipLaunchKernelGGL(topk_rows_kernel, dim3(static_cast<unsigned>(rows)), dim3(kBlock), 0, st, S, rows, N, N, k,
+                         n_skip_low, vals + b0 * k, idx + b0 * k);
     if (int rc = check_launch()) return rc;
   }
   return MI_OOV_OK;

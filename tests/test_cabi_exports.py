@@ -40,4 +40,4 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mi_oov_lsh_embed(None, -1, None, 10, 4, None, 2, None, 4, None, None, None) == -2  # shape
     assert lib.mi_oov_mapper_map(None, 5, 9, 1, 1, None, None) == -3  # unknown hash kind
     assert lib.mi_oov_siphash24_mod(None, 5, None, 4, 1000, None, None) == -2  # mod not a power of two
-    assert lib.mi_oov_col_mean_workspace(10_000_000, 64) == 2442 * 64
+    assert lib.mi_oov_col_mean_workspace(10_000_000, 64) == 1023 * 64  # <= 1024 row partitions of 9776 rows

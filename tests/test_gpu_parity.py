@@ -190,6 +190,26 @@ def test_scores_topk_vs_oracle(B, N, D, k, oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
+def test_topk_edge_cases(oracle, ops, dev):
+    rng = np.random.default_rng(3)
+    U = rng.standard_normal((17, 8), dtype=np.float32)
+    E = rng.standard_normal((300, 8), dtype=np.float32)
+    E[7] = np.nan           # NaN scores sort first (torch.topk)
+    E[40:60] = E[40]        # a run of exact ties straddling the k-th place
+    E[100] = np.inf
+    for k, skip in ((1, 0), (5, 1), (50, 1), (256, 0), (300, 0), (256, 290)):  # k > 256 -> multi-pass kernel; k > columns
+        vals, idx = ops.score_topk(T(U, dev), T(E, dev), k, skip)
+        o_vals, o_idx = oracle.score_topk(U, E, k, skip)
+        assert np.array_equal(idx.cpu().numpy(), o_idx), (k, skip)
+        assert bits_equal(vals.cpu().numpy(), o_vals), (k, skip)
+    # many columns, heavy duplication of values (stress the radix passes)
+    E2 = np.round(rng.standard_normal((20000, 8)), 1).astype(np.float32)
+    U2 = np.round(rng.standard_normal((9, 8)), 1).astype(np.float32)
+    vals, idx = ops.score_topk(T(U2, dev), T(E2, dev), 100, 1)
+    o_vals, o_idx = oracle.score_topk(U2, E2, 100, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx) and bits_equal(vals.cpu().numpy(), o_vals)
+
+
 def test_gather_splice_vs_oracle(oracle, ops, dev):
     rng = np.random.default_rng(11)
     for D in (64, 1, 50, 200):
