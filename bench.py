@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--sharded", action="store_true", help="row-shard the table + RCCL all-to-all exchange")
     ap.add_argument("--unfused", action="store_true", help="two launches (lsh_embed + rowdot) instead of the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
+    ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
@@ -141,12 +143,17 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = 0 if args.single_device else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=args.dist_backend)
+    ctl_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where control tensors live
 
     import mi_oov  # noqa: F401
     from mi_oov import ops, sharded
@@ -207,12 +214,12 @@ def main():
         fence()
         t1 = time.perf_counter()
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=dev)
+    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=ctl_dev)
     if fused:
         kern_ms = region[0].elapsed_time(region[1]) / max(1, args.steps)
     else:
         kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
-    kern = torch.tensor([kern_ms], dtype=torch.float64, device=dev)
+    kern = torch.tensor([kern_ms], dtype=torch.float64, device=ctl_dev)
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         dist.all_reduce(kern, op=dist.ReduceOp.MAX)
