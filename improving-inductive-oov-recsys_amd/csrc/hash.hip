@@ -7,70 +7,92 @@
 
 namespace mi_oov {
 
-__device__ __forceinline__ uint64_t rotl64(uint64_t x, int b) { return (x << b) | (x >> (64 - b)); }
+// 64-bit lanes are kept as (lo, hi) dword pairs: on gfx950 a 64-bit rotate by r < 32 is two
+// v_alignbit_b32, a rotate by 32 is a register rename, add is v_add_co/v_addc, xor is two v_xor.
+struct u64p {
+  uint32_t lo, hi;
+};
+__device__ __forceinline__ u64p mk(uint64_t v) { return {static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32)}; }
+__device__ __forceinline__ u64p add64(u64p a, u64p b) {
+  const uint64_t r = ((static_cast<uint64_t>(a.hi) << 32) | a.lo) + ((static_cast<uint64_t>(b.hi) << 32) | b.lo);
+  return mk(r);
+}
+__device__ __forceinline__ u64p xor64(u64p a, u64p b) { return {a.lo ^ b.lo, a.hi ^ b.hi}; }
+template <int R>  // 0 < R < 32
+__device__ __forceinline__ u64p rotl(u64p x) {
+  // alignbit(a, b, s) = low 32 bits of ((a:b) >> s)
+  return {__builtin_amdgcn_alignbit(x.lo, x.hi, 32 - R), __builtin_amdgcn_alignbit(x.hi, x.lo, 32 - R)};
+}
+__device__ __forceinline__ u64p rotl32(u64p x) { return {x.hi, x.lo}; }
 
-#define MI_SIPROUND        \
-  do {                     \
-    v0 += v1;              \
-    v1 = rotl64(v1, 13);   \
-    v1 ^= v0;              \
-    v0 = rotl64(v0, 32);   \
-    v2 += v3;              \
-    v3 = rotl64(v3, 16);   \
-    v3 ^= v2;              \
-    v0 += v3;              \
-    v3 = rotl64(v3, 21);   \
-    v3 ^= v0;              \
-    v2 += v1;              \
-    v1 = rotl64(v1, 17);   \
-    v1 ^= v2;              \
-    v2 = rotl64(v2, 32);   \
+#define MI_SIPROUND                \
+  do {                             \
+    v0 = add64(v0, v1);            \
+    v1 = rotl<13>(v1);             \
+    v1 = xor64(v1, v0);            \
+    v0 = rotl32(v0);               \
+    v2 = add64(v2, v3);            \
+    v3 = rotl<16>(v3);             \
+    v3 = xor64(v3, v2);            \
+    v0 = add64(v0, v3);            \
+    v3 = rotl<21>(v3);             \
+    v3 = xor64(v3, v0);            \
+    v2 = add64(v2, v1);            \
+    v1 = rotl<17>(v1);             \
+    v1 = xor64(v1, v2);            \
+    v2 = rotl32(v2);               \
   } while (0)
 
-// SipHash-2-4 of the 8-byte little-endian encoding of m under key (k0,k1).
-__device__ __forceinline__ uint64_t siphash24_u64(uint64_t k0, uint64_t k1, uint64_t m) {
-  uint64_t v0 = k0 ^ 0x736f6d6570736575ULL;
-  uint64_t v1 = k1 ^ 0x646f72616e646f6dULL;
-  uint64_t v2 = k0 ^ 0x6c7967656e657261ULL;
-  uint64_t v3 = k1 ^ 0x7465646279746573ULL;
-  v3 ^= m;
+// SipHash-2-4 of the 8-byte little-endian encoding of m under key (k0,k1); returns the low dword
+// of the 64-bit hash (all the path needs: `% 16777216`).
+__device__ __forceinline__ uint32_t siphash24_lo(u64p k0, u64p k1, u64p m) {
+  u64p v0 = xor64(k0, mk(0x736f6d6570736575ULL));
+  u64p v1 = xor64(k1, mk(0x646f72616e646f6dULL));
+  u64p v2 = xor64(k0, mk(0x6c7967656e657261ULL));
+  u64p v3 = xor64(k1, mk(0x7465646279746573ULL));
+  v3 = xor64(v3, m);
   MI_SIPROUND;
   MI_SIPROUND;
-  v0 ^= m;
-  const uint64_t last = 8ULL << 56;  // message length 8, no tail bytes
-  v3 ^= last;
+  v0 = xor64(v0, m);
+  const u64p last = mk(8ULL << 56);  // message length 8, no tail bytes
+  v3 = xor64(v3, last);
   MI_SIPROUND;
   MI_SIPROUND;
-  v0 ^= last;
-  v2 ^= 0xff;
+  v0 = xor64(v0, last);
+  v2.lo ^= 0xff;
   MI_SIPROUND;
   MI_SIPROUND;
   MI_SIPROUND;
   MI_SIPROUND;
-  return v0 ^ v1 ^ v2 ^ v3;
+  return v0.lo ^ v1.lo ^ v2.lo ^ v3.lo;
 }
 
-// out[b, j] for j fastest: a wave writes 256 contiguous bytes; the id is wave-uniform for
-// K >= 64 and the key pair comes from LDS (K*16 B, staged once per workgroup).
+// Thread -> (id slot, key): KP = min(256, next pow2 >= K) keys per id slot, 256/KP id slots per
+// workgroup, so no 64-bit division is needed; j fastest -> a wave writes contiguous floats.  The id
+// is wave-uniform for K >= 64; key pairs come from LDS (K*16 B, staged once per workgroup).
 template <bool KEYS_IN_LDS>
 __global__ __launch_bounds__(kBlock) void siphash_kernel(const int64_t* __restrict__ ids, int64_t B,
-                                                         const uint8_t* __restrict__ keys, int64_t K,
+                                                         const uint8_t* __restrict__ keys, int K, int log2kp,
                                                          uint32_t mask, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) uint64_t skeys[];
-  const uint64_t* kp = reinterpret_cast<const uint64_t*>(keys);  // little-endian host & device
+  extern __shared__ __attribute__((aligned(16))) uint32_t skeys[];
+  const uint32_t* kp = reinterpret_cast<const uint32_t*>(keys);  // little-endian host & device
   if (KEYS_IN_LDS) {
-    for (int64_t i = threadIdx.x; i < 2 * K; i += kBlock) skeys[i] = kp[i];
+    for (int i = threadIdx.x; i < 4 * K; i += kBlock) skeys[i] = kp[i];
     __syncthreads();
   }
-  const int64_t total = B * K;
-  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
-       i += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int64_t b = i / K;
-    const int64_t j = i - b * K;
-    const uint64_t k0 = KEYS_IN_LDS ? skeys[2 * j] : kp[2 * j];
-    const uint64_t k1 = KEYS_IN_LDS ? skeys[2 * j + 1] : kp[2 * j + 1];
-    const uint64_t h = siphash24_u64(k0, k1, static_cast<uint64_t>(ids[b]));
-    out[i] = static_cast<float>(static_cast<uint32_t>(h) & mask);  // < 2^24: exact in f32
+  const int KP = 1 << log2kp;
+  const int jl = threadIdx.x & (KP - 1);
+  const int slot = threadIdx.x >> log2kp;
+  const int slots = kBlock >> log2kp;
+  for (int64_t b = static_cast<int64_t>(blockIdx.x) * slots + slot; b < B;
+       b += static_cast<int64_t>(gridDim.x) * slots) {
+    const u64p m = mk(static_cast<uint64_t>(ids[b]));
+    for (int j = jl; j < K; j += KP) {
+      const uint32_t* kj = KEYS_IN_LDS ? skeys + 4 * j : kp + 4 * j;
+      const u64p k0 = {kj[0], kj[1]}, k1 = {kj[2], kj[3]};
+      const uint32_t h = siphash24_lo(k0, k1, m);
+      out[b * K + j] = static_cast<float>(h & mask);  // < 2^24: exact in f32
+    }
   }
 }
 
@@ -155,14 +177,21 @@ extern "C" int mi_oov_siphash24_mod(const int64_t* ids, int64_t B, const uint8_t
   if (mod == 0 || (mod & (mod - 1)) != 0 || mod > (1u << 24)) return MI_OOV_ERR_SHAPE;
   if (B == 0) return MI_OOV_OK;
   if (!ids || !keys || !out) return MI_OOV_ERR_NULL;
-  if ((reinterpret_cast<uintptr_t>(keys) & 7u) != 0) return MI_OOV_ERR_ALIGN;
+  if ((reinterpret_cast<uintptr_t>(keys) & 3u) != 0) return MI_OOV_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int grid = grid_for(B * K, kBlock * 4);
+  if (K > (1 << 20)) return MI_OOV_ERR_SHAPE;
+  int log2kp = 0;
+  while ((1 << log2kp) < K && log2kp < 8) ++log2kp;  // KP = min(256, next pow2 >= K)
+  const int slots = kBlock >> log2kp;
+  const int64_t per_block = static_cast<int64_t>(slots) * (K > 256 ? 1 : 4);
+  const int grid = grid_for(B, per_block);
   const size_t lds = static_cast<size_t>(K) * 16;
   if (lds <= 48 * 1024) {
-    hipLaunchKernelGGL(siphash_kernel<true>, dim3(grid), dim3(kBlock), lds, st, ids, B, keys, K, mod - 1, out);
+    hipLaunchKernelGGL(siphash_kernel<true>, dim3(grid), dim3(kBlock), lds, st, ids, B, keys, static_cast<int>(K),
+                       log2kp, mod - 1, out);
   } else {
-    hipLaunchKernelGGL(siphash_kernel<false>, dim3(grid), dim3(kBlock), 0, st, ids, B, keys, K, mod - 1, out);
+    hipLaunchKernelGGL(siphash_kernel<false>, dim3(grid), dim3(kBlock), 0, st, ids, B, keys, static_cast<int>(K),
+                       log2kp, mod - 1, out);
   }
   return check_launch();
 }

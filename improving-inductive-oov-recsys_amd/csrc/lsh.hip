@@ -327,8 +327,9 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
     for (int r = 0; r < R; ++r) {
       row[r] = tile * (4 * R) + r * 4 + grp;
       live[r] = row[r] < p.B;
-      id[r] = live[r] ? p.ids[row[r]] : -1;
+      id[r] = p.ids[live[r] ? row[r] : p.B - 1];  // clamped, never branched on
       valid[r] = live[r] && (static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(p.N));
+      if (!valid[r]) id[r] = 0;
       pop[r] = 0;
     }
     for (int h0 = 0; h0 < H; h0 += HB) {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
         float4 xv[R];
 #pragma unroll
         for (int r = 0; r < R; ++r)
-          xv[r] = valid[r] ? load4<VEC>(p.feat + id[r] * p.F, e, p.F) : make_float4(0.f, 0.f, 0.f, 0.f);
+          xv[r] = load4<VEC>(p.feat + id[r] * p.F, e, p.F);
 #pragma unroll
         for (int j = 0; j < HB; ++j) {
           if (h0 + j < H) {
@@ -361,17 +362,25 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
         }
       }
     }
+    // (2 ** bits).sum(1) = sum of 1 or 2 per plane = H + popcount  (single_lsh_embedder.py:86).
+    // All R bucket ids first, then all R bucket-row gathers back-to-back, then the stores: the
+    // second dependent HBM round trip is paid once per tile, not once per lookup.
+    int64_t bkt[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      // (2 ** bits).sum(1) = sum of 1 or 2 per plane = H + popcount  (single_lsh_embedder.py:86)
-      const int64_t b = valid[r] ? (static_cast<int64_t>(H) + pop[r]) % p.n_buckets : -1;
-      if (p.idx && l16 == 0 && live[r]) p.idx[row[r]] = b;
-      if (p.out && live[r]) {
-        for (int c = 0; c < dchunks; ++c) {
-          const int e = (c * 16 + l16) * 4;
-          float4 v = valid[r] ? load4<VEC>(p.buckets + b * p.D, e, p.D)
-                              : make_float4(qnan(), qnan(), qnan(), qnan());
-          store4<VEC>(p.out + row[r] * p.D, e, p.D, v);
+      bkt[r] = valid[r] ? (static_cast<int64_t>(H) + pop[r]) % p.n_buckets : -1;
+      if (p.idx && l16 == 0 && live[r]) p.idx[row[r]] = bkt[r];
+    }
+    if (p.out) {
+      for (int c = 0; c < dchunks; ++c) {
+        const int e = (c * 16 + l16) * 4;
+        float4 v[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) v[r] = load4<VEC>(p.buckets + (valid[r] ? bkt[r] : 0) * p.D, e, p.D);
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (!valid[r]) v[r] = make_float4(qnan(), qnan(), qnan(), qnan());
+          if (live[r]) store4<VEC>(p.out + row[r] * p.D, e, p.D, v[r]);
         }
       }
     }
