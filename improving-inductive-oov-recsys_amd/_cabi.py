@@ -29,6 +29,8 @@ _SIGNATURES = {
     "mi_oov_lsh_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "mi_oov_lsh_embed_score": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_lookup": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    "mi_oov_lsh_lookup_score": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
+                                               _vp, _vp]),
     "mi_oov_slsh_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_siphash24_mod": (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_uint32, _vp, _vp]),
     "mi_oov_mapper_hash": (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp]),

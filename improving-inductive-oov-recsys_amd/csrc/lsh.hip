@@ -429,8 +429,9 @@ static int dispatch_lsh(const LshParams& p, hipStream_t st) {
 }
 
 // lsh64.hip: lane-owns-lookup kernel for the hot shape F = D = 64
-int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes, int H,
-                 const float* buckets, const float* other, float* score, float* out, hipStream_t st);
+int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
+                 const float* planes, int H, const float* buckets, const float* other, float* score, float* out,
+                 hipStream_t st);
 
 static bool lsh64_enabled() {
   static const bool on = [] {
@@ -454,10 +455,10 @@ static int run_lsh(LshParams p, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = (p.F % 4 == 0) && (p.D % 4 == 0) && aligned16(p.feat) && (!p.out || aligned16(p.out)) &&
                    (!p.other || aligned16(p.other)) && (!p.table || aligned16(p.table));
-  if (vec && p.F == 64 && p.D == 64 && p.H <= 8 && want_emb && !p.table && !p.bits && aligned16(p.planes) &&
+  if (vec && p.F == 64 && p.D == 64 && p.H <= 8 && want_emb && !p.bits && aligned16(p.planes) &&
       aligned16(p.buckets) && lsh64_enabled())
-    return launch_lsh64(p.ids, p.B, p.feat, p.N, p.planes, static_cast<int>(p.H), p.buckets, p.other, p.score, p.out,
-                        st);
+    return launch_lsh64(p.ids, p.B, p.feat, p.N, p.table, p.n_vocab, p.planes, static_cast<int>(p.H), p.buckets,
+                        p.other, p.score, p.out, st);
   return vec ? dispatch_lsh<true>(p, st) : dispatch_lsh<false>(p, st);
 }
 
@@ -491,6 +492,18 @@ extern "C" int mi_oov_lsh_lookup(const int64_t* ids, int64_t B, const float* tab
   LshParams p{};
   p.ids = ids; p.B = B; p.feat = feat; p.N = N; p.F = F; p.planes = planes; p.H = H;
   p.buckets = buckets; p.n_buckets = H; p.D = D; p.table = table; p.n_vocab = n_vocab; p.out = out;
+  return mi_oov::run_lsh(p, stream);
+}
+
+extern "C" int mi_oov_lsh_lookup_score(const int64_t* ids, int64_t B, const float* table, int64_t n_vocab,
+                                       const float* feat, int64_t N, int64_t F, const float* planes, int64_t H,
+                                       const float* buckets, int64_t D, const float* other, float* score, float* out,
+                                       void* stream) {
+  if (!table || !score) return MI_OOV_ERR_NULL;
+  LshParams p{};
+  p.ids = ids; p.B = B; p.feat = feat; p.N = N; p.F = F; p.planes = planes; p.H = H;
+  p.buckets = buckets; p.n_buckets = H; p.D = D; p.table = table; p.n_vocab = n_vocab;
+  p.other = other; p.score = score; p.out = out;
   return mi_oov::run_lsh(p, stream);
 }
 

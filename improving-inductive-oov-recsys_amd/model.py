@@ -107,8 +107,7 @@ class BPR(InductiveGeneralRecommender):
         if self.inductive_mapper is not None:
             ids = self.inductive_mapper.map_user_ids(ids) if user else self.inductive_mapper.map_item_ids(ids)
         emb = self.inductive_embedder
-        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        if isinstance(emb, LSHInductiveEmbedder) and not needs_grad and not emb.training:
+        if self._fused_lsh_inference():
             # one launch: in-vocabulary rows and lsh rows spliced inside the kernel
             feat = emb.user_feature_mat if user else emb.item_feature_mat
             planes = (emb.user_lsh if user else emb.item_lsh).uniform_planes[0].data
@@ -157,8 +156,22 @@ class BPR(InductiveGeneralRecommender):
         neg_e = self.get_item_embedding(neg_item)
         return self.loss(ops.rowdot(user_e, pos_e), ops.rowdot(user_e, neg_e))
 
+    def _fused_lsh_inference(self):
+        emb = self.inductive_embedder
+        needs_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        return isinstance(emb, LSHInductiveEmbedder) and not needs_grad and not emb.training
+
     def predict(self, interaction):
-        user_e, item_e = self.forward(interaction[self.USER_ID], interaction[self.ITEM_ID])
+        user, item = interaction[self.USER_ID], interaction[self.ITEM_ID]
+        if self._fused_lsh_inference():
+            # two launches: user lookup, then item lookup fused with the row dot (item rows never stored)
+            user_e = self.get_user_embedding(user)
+            emb = self.inductive_embedder
+            if self.inductive_mapper is not None:
+                item = self.inductive_mapper.map_item_ids(item)
+            return ops.lsh_lookup_score(item, self.item_embedding.weight, emb.item_feature_mat,
+                                        emb.item_lsh.uniform_planes[0].data, self.item_oov_buckets.weight, user_e)
+        user_e, item_e = self.forward(user, item)
         return ops.rowdot(user_e, item_e)
 
     def ind_full_sort_predict(self, interaction, item_ids):

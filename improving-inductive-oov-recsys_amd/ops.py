@@ -105,6 +105,25 @@ def lsh_lookup(ids, table, feat, planes, buckets):
     return out
 
 
+def lsh_lookup_score(ids, table, feat, planes, buckets, other, want_emb=False):
+    """BPR.predict for one side with an lsh plugin: lookup (in-vocab row or lsh row) fused with the
+    row dot against `other` (bpr.py:94-125,145-149).  Inference only."""
+    ids, table, feat, planes, buckets, other = (_ids(ids), _f32(table, "table"), _f32(feat, "feat"),
+                                                _f32(planes, "planes"), _f32(buckets, "buckets"),
+                                                _f32(other, "other"))
+    B, (N, F), H, D = ids.numel(), feat.shape, planes.shape[0], buckets.shape[1]
+    if other.shape != (B, D):
+        raise ValueError(f"other must be [{B},{D}], got {tuple(other.shape)}")
+    score = torch.empty((B,), dtype=torch.float32, device=ids.device)
+    out = torch.empty((B, D), dtype=torch.float32, device=ids.device) if want_emb else None
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_lsh_lookup_score(C.ptr(ids), B, C.ptr(table), table.shape[0], C.ptr(feat), N, F,
+                                             C.ptr(planes), H, C.ptr(buckets), D, C.ptr(other), C.ptr(score),
+                                             C.ptr(out), C.stream_of(ids))
+    C.check(rc, "mi_oov_lsh_lookup_score")
+    return (score, out) if want_emb else score
+
+
 def _slsh_forward(ids, feat, planes, buckets, n_buckets, want_out=True):
     ids, feat, planes = _ids(ids), _f32(feat, "feat"), _f32(planes, "planes")
     B, (N, F), H = ids.numel(), feat.shape, planes.shape[0]

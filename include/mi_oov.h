@@ -91,6 +91,16 @@ int mi_oov_lsh_lookup(const int64_t* ids, int64_t B,
                       const float* buckets, int64_t D,
                       float* out, void* stream);
 
+/* BPR.predict with an lsh plugin on this side (bpr.py:145-149 over :94-125): the lookup above fused
+ * with the row dot against the already-embedded other side; `out` may be NULL.            */
+int mi_oov_lsh_lookup_score(const int64_t* ids, int64_t B,
+                            const float* table, int64_t n_vocab,
+                            const float* feat, int64_t N, int64_t F,
+                            const float* planes, int64_t H,
+                            const float* buckets, int64_t D,
+                            const float* other, float* score,
+                            float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * slsh: SingleLSHInductiveEmbedder._hash_node + embed_* (R/inductive/single_lsh_embedder.py:82-109)
  *     bits as above with H = bits_req planes;  idx = (sum_h 2**bits[h]) % n_buckets

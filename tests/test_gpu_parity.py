@@ -165,6 +165,33 @@ def test_lsh_shapes_vs_oracle(B, N, F, H, D, oracle, ops, dev):
     assert np.array_equal(ops.slsh_index(T(ids, dev), T(feat, dev), T(planes, dev), nb).cpu().numpy(), o_idx)
 
 
+@pytest.mark.parametrize("F,H,D", [(64, 8, 64), (64, 3, 64), (64, 12, 64), (22, 8, 64), (64, 8, 32)])
+def test_lookup_and_lookup_score_vs_oracle(F, H, D, oracle, ops, dev):
+    """BPR lookups (in-vocab rows spliced with lsh rows) and the lookup fused with BPR.predict;
+    (64, <=8, 64) takes the register-resident kernel, the others the generic LDS kernel."""
+    rng = np.random.default_rng(F * 100 + H)
+    n_vocab, N, B = 500, 900, 3001
+    table = rng.standard_normal((n_vocab, D), dtype=np.float32)
+    feat = rng.standard_normal((N, F), dtype=np.float32)
+    planes = rng.standard_normal((H, F), dtype=np.float32)
+    buckets = rng.standard_normal((H, D), dtype=np.float32)
+    other = rng.standard_normal((B, D), dtype=np.float32)
+    ids = rng.integers(0, N, size=B, dtype=np.int64)
+    ids[5], ids[6] = -3, N + 10  # invalid on either side of the vocabulary boundary
+    want = oracle.lsh_lookup(ids, table, feat, planes, buckets)
+    got = ops.lsh_lookup(T(ids, dev), T(table, dev), T(feat, dev), T(planes, dev), T(buckets, dev)).cpu().numpy()
+    assert bits_equal(got, want)
+    iv = (ids >= 0) & (ids < n_vocab)
+    assert bits_equal(got[iv], table[ids[iv]])  # in-vocabulary rows are verbatim copies
+    assert np.isnan(got[5]).all() and np.isnan(got[6]).all()
+    score, emb = ops.lsh_lookup_score(T(ids, dev), T(table, dev), T(feat, dev), T(planes, dev), T(buckets, dev),
+                                      T(other, dev), want_emb=True)
+    assert bits_equal(emb.cpu().numpy(), want)
+    assert bits_equal(score.cpu().numpy(), oracle.rowdot(other, want))
+    s2 = ops.lsh_lookup_score(T(ids, dev), T(table, dev), T(feat, dev), T(planes, dev), T(buckets, dev), T(other, dev))
+    assert bits_equal(s2.cpu().numpy(), oracle.rowdot(other, want))
+
+
 def test_empty_batches(ops, dev):
     ids = torch.empty((0,), dtype=torch.int64, device=dev)
     feat = torch.randn(10, 8, device=dev)
