@@ -13,7 +13,8 @@ namespace mi_oov {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BM = 128, BN = 128, KC = 64, LDK = KC + 4;  // LDS row stride 68 floats: b128 reads conflict-free
+constexpr int BM = 128, BN = 128, KC = 32, LDK = KC + 4;  // K chunk 32: 36 KB LDS -> 4 workgroups per CU;
+                                                          // row stride 36 floats keeps the b128 reads conflict-free
 
 // Loads 8 consecutive k of one row (guarded), returns them split into even/odd k so that the MFMA
 // lane halves (h = lane>>5 supplies k = 2s+h) read their 4 values with ONE ds_read_b128 and the
@@ -64,11 +65,12 @@ __global__ __launch_bounds__(kBlock) void full_sort_kernel(const float* __restri
 
   for (int kc = 0; kc < D; kc += KC) {
     if (kc) __syncthreads();
-    // stage: 128 rows x 8 units of 8 floats per operand = 1024 units, 4 per thread per operand
+    // stage: 128 rows x KC/8 units of 8 floats per operand
+    constexpr int UPR = KC / 8;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < (BM * UPR) / kBlock; ++j) {
       const int u = tid + kBlock * j;
-      const int r = u >> 3, t8 = u & 7;
+      const int r = u / UPR, t8 = u % UPR;
       float4 ev, od;
       load8_split<VEC>(U, b0 + r, B, D, kc + t8 * 8, ev, od);
       *reinterpret_cast<float4*>(sA + r * LDK + t8 * 8) = ev;
