@@ -41,8 +41,11 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--ramp-seconds", type=float, default=1.0,
+                    help="untimed pre-warm-up that lets the GPU leave its idle clock (sclk idles at ~500 MHz and "
+                         "needs tens of ms of load to ramp; 200 x 11 us steps alone are over before it does)")
     ap.add_argument("--items", type=int, default=10_000_000)
     ap.add_argument("--feat", type=int, default=64)
     ap.add_argument("--dim", type=int, default=64)
@@ -196,6 +199,13 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        t_ramp = time.perf_counter()
+        i = 0
+        while time.perf_counter() - t_ramp < args.ramp_seconds:  # clock ramp, before the W warm-up steps
+            step(i % total)
+            i += 1
+            if i % 256 == 0:
+                torch.cuda.synchronize()
         for i in range(args.warmup):
             step(i)
         # HIP events on the launch stream (torch's current stream is the one handed to the C ABI).
@@ -246,7 +256,7 @@ def main():
                        "items": N, "feat": F, "dim": D, "hashes": H, "batch_per_gpu": B,
                        "table": "row-sharded + all-to-all" if (args.sharded and world > 1) else "replicated per GPU",
                        "launches_per_step": "lsh_embed_score" if fused else "lsh_embed + rowdot"},
-            "roofline": {"bound": "hbm", "kernel": "lsh_table_kernel<8, true, false" if fused else "lsh_table_kernel<8, false, true",
+            "roofline": {"bound": "hbm", "kernel": "lsh64_kernel<8, true, false, false>" if fused else "lsh64_kernel<8, false, true, false>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_lookup": per_lookup, "lookups_per_launch": B, "avg_launch_us": kern_ms * 1e3,
                          "traffic": None},
