@@ -24,6 +24,12 @@
 // Floor for this access pattern (tools/microbench.hip, back-to-back launches): empty launch 2.3 us,
 // gather only 5.7 us, gather x and u rows 7.5 us, gather + 256-B row store 7.8 us.  Stage costs on top
 // of the 7.5 us floor: 8 projections +1.1 us, aggregate +1.0, division +0.7, score +0.3.
+// Per-wave s_memrealtime stamps (MB_STAMPS=1 tools/microbench): all 4096 waves start within 0.4 us,
+// the kernel spans 8.4 us in-kernel (the other ~2.3 us of a launch are dispatch + boundary); ids
+// land at p50 2.6 / max 5.2 us and a wave's four rows land over a further ~2.4 us: the 34.9 MB of a
+// launch need >= 5.8 us at the ~6 TB/s the memory system sustains, i.e. the middle of the kernel is
+// bandwidth-bound and only its head (launch, first dependent hop) and tail (last rounds' VALU)
+// are not.  Re-ordering the issue (ids before weights, user rows after the gathers) changed nothing.
 #include "common.hpp"
 
 namespace mi_oov {
@@ -41,13 +47,22 @@ __global__ __launch_bounds__(kBlock) void lsh64_kernel(const int64_t* __restrict
   const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
   const int64_t tstep = static_cast<int64_t>(gridDim.x) * 4;
 
-  // Small, L2-resident operands FIRST: vmcnt retires in order, so anything issued after the gathers
-  // could not be consumed before the gathers have landed.
+  // Plane / bucket slices -> VGPRs through LDS: the workgroup fetches the 2 x H x 256 B once (one 16-B
+  // load per thread) and every lane reads its 2 x H float4 back with ds_read_b128, instead of 2 x H
+  // global loads per lane (16 KiB of L1 traffic per wave) queued in front of the ids -> rows gathers.
+  // Measured neutral at B = 65536 (10.7 vs 10.9 us): kept because it removes 4096 x 16 KiB of
+  // redundant vector-memory requests per launch.
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [2][H][64]
+  for (int i = threadIdx.x; i < 2 * H * 16; i += kBlock) {
+    const float* src = (i < H * 16) ? planes + i * 4 : buckets + (i - H * 16) * 4;
+    *reinterpret_cast<float4*>(sw + i * 4) = *reinterpret_cast<const float4*>(src);
+  }
+  __syncthreads();
   float4 pw[H], bw[H];
 #pragma unroll
   for (int h = 0; h < H; ++h) {
-    pw[h] = *reinterpret_cast<const float4*>(planes + h * 64 + l16 * 4);
-    bw[h] = *reinterpret_cast<const float4*>(buckets + h * 64 + l16 * 4);
+    pw[h] = *reinterpret_cast<const float4*>(sw + (h * 16 + l16) * 4);
+    bw[h] = *reinterpret_cast<const float4*>(sw + (H * 16 + h * 16 + l16) * 4);
   }
 
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles; tile += tstep) {
@@ -109,7 +124,7 @@ static int launch64(const int64_t* ids, int64_t B, const float* feat, int64_t N,
                     const float* planes, const float* buckets, const float* other, float* score, float* out,
                     hipStream_t st) {
   const int grid = grid_for(B, 64);  // 4 waves x 16 lookups per workgroup pass
-  hipLaunchKernelGGL((lsh64_kernel<H, SCORE, STORE, LOOKUP>), dim3(grid), dim3(kBlock), 0, st, ids, B, feat, N, vtable,
+  hipLaunchKernelGGL((lsh64_kernel<H, SCORE, STORE, LOOKUP>), dim3(grid), dim3(kBlock), 2 * H * 64 * sizeof(float), st, ids, B, feat, N, vtable,
                      n_vocab, planes, buckets, other, score, out);
   return check_launch();
 }

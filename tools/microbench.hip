@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
 #include <vector>
 
 #include "mi_oov.h"
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void work_kernel(const int64_t* __restrict__ i
 
 // Staged replica of the hot lsh kernel (score variant): which stage costs what?
 //  STAGE 0 loads (x,u) + one DPP reduce   1 + 8 projections   2 + aggregate   3 + division   4 + score
-template <int STAGE, int R>
+template <int STAGE, int R, int ORDER = 0>
 __global__ __launch_bounds__(256) void staged_kernel(const int64_t* __restrict__ ids, int64_t B,
                                                      const float* __restrict__ feat, const float* __restrict__ planes,
                                                      const float* __restrict__ buckets, const float* __restrict__ other,
@@ -95,10 +96,33 @@ __global__ __launch_bounds__(256) void staged_kernel(const int64_t* __restrict__
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
   const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
   float4 pw[H], bw[H];
+  int64_t id0[R];
+  if (ORDER == 1) {  // the tile's ids go out before anything else
+    const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    pw[h] = *reinterpret_cast<const float4*>(planes + h * 64 + l16 * 4);
-    bw[h] = *reinterpret_cast<const float4*>(buckets + h * 64 + l16 * 4);
+    for (int r = 0; r < R; ++r) {
+      int64_t rw = tile * (4 * R) + r * 4 + grp;
+      if (rw >= B) rw = B - 1;
+      id0[r] = ids[rw];
+    }
+  }
+  __shared__ __attribute__((aligned(16))) float sw_raw[ORDER == 2 ? 2 * H * 64 : 4];
+  if (ORDER == 2) {  // weights: 4 KB per workgroup through LDS instead of 16 KB per wave through L1
+    const float* src = (threadIdx.x < H * 16) ? planes + threadIdx.x * 4 : buckets + (threadIdx.x - H * 16) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(src);
+    *reinterpret_cast<float4*>(sw_raw + threadIdx.x * 4) = v;
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      pw[h] = *reinterpret_cast<const float4*>(sw_raw + (h * 16 + l16) * 4);
+      bw[h] = *reinterpret_cast<const float4*>(sw_raw + (H * 16 + h * 16 + l16) * 4);
+    }
+  } else {
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      pw[h] = *reinterpret_cast<const float4*>(planes + h * 64 + l16 * 4);
+      bw[h] = *reinterpret_cast<const float4*>(buckets + h * 64 + l16 * 4);
+    }
   }
   for (int64_t tile = (int64_t)blockIdx.x * 4 + wv; tile < ntiles; tile += (int64_t)gridDim.x * 4) {
     int64_t row[R], id[R];
@@ -106,13 +130,24 @@ __global__ __launch_bounds__(256) void staged_kernel(const int64_t* __restrict__
     for (int r = 0; r < R; ++r) {
       row[r] = tile * (4 * R) + r * 4 + grp;
       if (row[r] >= B) row[r] = B - 1;
-      id[r] = ids[row[r]];
+      id[r] = (ORDER == 1 && tile == (int64_t)blockIdx.x * 4 + wv) ? id0[r] : ids[row[r]];
     }
     float4 u[R], x[R];
+    if (ORDER == 0) {
 #pragma unroll
-    for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
+      for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const float4*>(feat + id[r] * 64 + l16 * 4);
+    if (ORDER == 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        int64_t ro = row[r];
+        int lo = (int)id[r];
+        asm volatile("" : "+v"(ro) : "v"(lo));  // u's address "depends" on the id: cannot be hoisted above the id wait
+        u[r] = *reinterpret_cast<const float4*>(other + ro * 64 + l16 * 4);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -142,6 +177,70 @@ __global__ __launch_bounds__(256) void staged_kernel(const int64_t* __restrict__
   }
 }
 
+// Full kernel (stage 4) with per-wave wall-clock stamps (100 MHz s_memrealtime): where does a wave
+// spend its life?  stamps: 0 start, 1 ids landed, 2 x[0] landed, 3 x[R-1] landed, 4 done.
+template <int R>
+__global__ __launch_bounds__(256) void stamped_kernel(const int64_t* __restrict__ ids, int64_t B,
+                                                      const float* __restrict__ feat, const float* __restrict__ planes,
+                                                      const float* __restrict__ buckets, const float* __restrict__ other,
+                                                      float* __restrict__ score, unsigned long long* __restrict__ stamps) {
+  constexpr int H = 8;
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  unsigned long long t0 = wall_clock64(), t1 = 0, t2 = 0, t3 = 0;
+  float4 pw[H], bw[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    pw[h] = *reinterpret_cast<const float4*>(planes + h * 64 + l16 * 4);
+    bw[h] = *reinterpret_cast<const float4*>(buckets + h * 64 + l16 * 4);
+  }
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+  int64_t row[R], id[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    row[r] = tile * (4 * R) + r * 4 + grp;
+    if (row[r] >= B) row[r] = B - 1;
+    id[r] = ids[row[r]];
+  }
+  float4 u[R], x[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
+  // force the ids to have landed, then stamp
+  long long idsum = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) idsum += id[r];
+  asm volatile("" ::"v"(idsum));
+  t1 = wall_clock64();
+#pragma unroll
+  for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const float4*>(feat + id[r] * 64 + l16 * 4);
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    asm volatile("" ::"v"(x[r].x));
+    if (r == 0) t2 = wall_clock64();
+    if (r == R - 1) t3 = wall_clock64();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cnt = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float s = row16_sum(dot4_fma(x[r], pw[h], 0.f));
+      const float bit = (s < 0.f) ? 0.f : 1.f;
+      cnt = cnt + bit;
+      acc.x = __builtin_fmaf(bit, bw[h].x, acc.x); acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
+      acc.z = __builtin_fmaf(bit, bw[h].z, acc.z); acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+    }
+    acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt;
+    const float s = row16_sum(dot4_muladd(u[r], acc, 0.f));
+    if (l16 == 0) score[row[r]] = s;
+    tot += s;
+  }
+  asm volatile("" ::"v"(tot));
+  unsigned long long t4 = wall_clock64();
+  if (lane == 0) {
+    unsigned long long* o = stamps + 5 * ((size_t)blockIdx.x * 4 + wv);
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
+  }
+}
+
 template <typename F>
 static float time_it(F launch, int iters) {
   hipEvent_t a, b;
@@ -152,6 +251,8 @@ static float time_it(F launch, int iters) {
   for (int i = 0; i < iters; ++i) launch(10 + i);
   CK(hipEventRecord(b, 0));
   CK(hipEventSynchronize(b));
+  CK(hipGetLastError());
+  CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, a, b));
   return ms * 1e3f / iters;
 }
@@ -199,17 +300,51 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&planes2, 8 * 64 * 4)); CK(hipMalloc(&buckets2, 8 * 64 * 4));
     CK(hipMalloc(&users2, 8 * B * 64 * 4)); CK(hipMalloc(&score2, B * 4));
     CK(hipMemset(planes2, 0, 2048)); CK(hipMemset(buckets2, 0, 2048)); CK(hipMemset(users2, 0, 8 * B * 64 * 4));
-#define RUNS(STAGE, R, NAME)                                                                              \
+#define RUNS(STAGE, R, NAME) RUNSO(STAGE, R, 0, NAME)
+#define RUNSO(STAGE, R, ORDER, NAME)                                                                      \
     {                                                                                                     \
       int64_t tiles = (B + 4 * R - 1) / (4 * R);                                                          \
       int grid = (int)((tiles + 3) / 4);                                                                  \
-      float us = time_it([&](int i) { hipLaunchKernelGGL((staged_kernel<STAGE, R>), dim3(grid), dim3(256), 0, 0, ids + (int64_t)i * B, B, feat, planes2, buckets2, users2 + (int64_t)(i % 8) * B * 64, score2); }, iters); \
+      float us = time_it([&](int i) { hipLaunchKernelGGL((staged_kernel<STAGE, R, ORDER>), dim3(grid), dim3(256), 0, 0, ids + (int64_t)i * B, B, feat, planes2, buckets2, users2 + (int64_t)(i % 8) * B * 64, score2); }, iters); \
       printf("%-44s %8.2f us  %7.1f GB/s\n", NAME, us, B * 532.0 / us / 1e3);                              \
     }
     RUNS(0, 4, "staged 0: loads x,u + reduce   R=4") RUNS(1, 4, "staged 1: + 8 projections       R=4")
     RUNS(2, 4, "staged 2: + aggregate           R=4") RUNS(3, 4, "staged 3: + division            R=4")
     RUNS(4, 4, "staged 4: + score (full)        R=4")
+    RUNSO(0, 4, 1, "staged 0 ORDER=1 (ids, w, x, u) R=4") RUNSO(4, 4, 1, "staged 4 (full) ORDER=1 R=4")
+    RUNSO(4, 2, 1, "staged 4 (full) ORDER=1 R=2") RUNSO(4, 8, 1, "staged 4 (full) ORDER=1 R=8")
+    RUNSO(4, 4, 2, "staged 4 (full) weights via LDS R=4") RUNSO(4, 2, 2, "staged 4 (full) weights via LDS R=2")
+    RUNSO(4, 8, 2, "staged 4 (full) weights via LDS R=8") RUNSO(1, 4, 2, "staged 1 weights via LDS R=4")
     RUNS(0, 2, "staged 0 R=2") RUNS(4, 2, "staged 4 (full) R=2") RUNS(4, 1, "staged 4 (full) R=1") RUNS(4, 8, "staged 4 (full) R=8")
+  }
+  if (getenv("MB_STAMPS")) {
+    float *planes2, *buckets2, *users2, *score2; unsigned long long* st;
+    const int grid = (int)(B / 64), nw = grid * 4;
+    CK(hipMalloc(&planes2, 2048)); CK(hipMalloc(&buckets2, 2048)); CK(hipMalloc(&users2, B * 64 * 4)); CK(hipMalloc(&score2, B * 4));
+    CK(hipMalloc(&st, (size_t)nw * 5 * 8));
+    CK(hipMemset(planes2, 0, 2048)); CK(hipMemset(buckets2, 0, 2048)); CK(hipMemset(users2, 0, B * 64 * 4));
+    for (int i = 0; i < 50; ++i) hipLaunchKernelGGL((stamped_kernel<4>), dim3(grid), dim3(256), 0, 0, ids + (int64_t)i * B, B, feat, planes2, buckets2, users2, score2, st);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> hs((size_t)nw * 5);
+    CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+    unsigned long long base = ~0ull, end = 0;
+    for (int w = 0; w < nw; ++w) { if (hs[5 * w] < base) base = hs[5 * w]; if (hs[5 * w + 4] > end) end = hs[5 * w + 4]; }
+    printf("stamped kernel: first start -> last end = %.2f us (100 MHz ticks)\n", (end - base) / 100.0);
+    const char* names[5] = {"start", "ids landed", "x[0] landed", "x[3] landed", "done"};
+    for (int k = 0; k < 5; ++k) {
+      std::vector<double> v(nw);
+      for (int w = 0; w < nw; ++w) v[w] = (hs[5 * w + k] - base) / 100.0;
+      std::sort(v.begin(), v.end());
+      printf("  %-12s  min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us\n", names[k], v[0], v[nw / 10], v[nw / 2], v[nw * 9 / 10], v[nw - 1]);
+    }
+    std::vector<double> d(nw);
+    for (int w = 0; w < nw; ++w) d[w] = (hs[5 * w + 4] - hs[5 * w + 3]) / 100.0;
+    std::sort(d.begin(), d.end());
+    printf("  x[3] landed -> done (compute tail): p10 %.2f p50 %.2f p90 %.2f us\n", d[nw / 10], d[nw / 2], d[nw * 9 / 10]);
+    for (int w = 0; w < nw; ++w) d[w] = (hs[5 * w + 3] - hs[5 * w + 2]) / 100.0;
+    std::sort(d.begin(), d.end());
+    printf("  x[0] landed -> x[3] landed (incl. 3 rounds of compute): p10 %.2f p50 %.2f p90 %.2f us\n", d[nw / 10], d[nw / 2], d[nw * 9 / 10]);
+    return 0;
   }
   lib_cases:
   {
