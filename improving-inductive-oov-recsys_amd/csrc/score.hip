@@ -41,9 +41,24 @@ __device__ __forceinline__ void load8_split(const float* M, int64_t row, int64_t
   od = make_float4(v[1], v[3], v[5], v[7]);
 }
 
-template <bool VEC>
-__global__ __launch_bounds__(kBlock) void full_sort_kernel(const float* __restrict__ U, int64_t B,
+// Epilogues: the same tiled product serves full-sort scoring (EPI_NONE) and the Linear layers of the
+// dhe/fdhe/dnn hash nets (y = act(x W^T + b), dh_embedder.py:70-89): W is [N_out, K] row-major, exactly
+// the E operand's layout.
+enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SIGMOID = 3 };
+
+template <int EPI>
+__device__ __forceinline__ float epilogue(float v, float b) {
+  if (EPI == EPI_NONE) return v;
+  v = v + b;
+  if (EPI == EPI_BIAS_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // nn.GELU(): erf form
+  if (EPI == EPI_BIAS_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+template <bool VEC, int EPI>
+__global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __restrict__ U, int64_t B,
                                                            const float* __restrict__ E, int64_t N, int64_t D,
+                                                           const float* __restrict__ bias,
                                                            float* __restrict__ S, int64_t ldS) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* sA = smem;             // [BM][LDK]
@@ -63,6 +78,9 @@ __global__ __launch_bounds__(kBlock) void full_sort_kernel(const float* __restri
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
+  // K loop.  A register-prefetched (software-pipelined) variant measured SLOWER on MI355X (full sort
+  // 442 vs 362 us, dhe MLP 1.53 vs 1.49 ms): with 36 KB of LDS four workgroups share a CU and already
+  // overlap one another's staging with MFMA work, while the extra 32 VGPRs of prefetch cost occupancy.
   for (int kc = 0; kc < D; kc += KC) {
     if (kc) __syncthreads();
     // stage: 128 rows x KC/8 units of 8 floats per operand
@@ -107,10 +125,11 @@ __global__ __launch_bounds__(kBlock) void full_sort_kernel(const float* __restri
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
       const int64_t col = n0 + wn * 64 + n * 32 + i32;
+      const float bcol = (EPI != EPI_NONE && col < N) ? bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < B && col < N) S[row * ldS + col] = acc[m][n][r];
+        if (row < B && col < N) S[row * ldS + col] = epilogue<EPI>(acc[m][n][r], bcol);
       }
     }
 }
@@ -294,21 +313,22 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const float* __rest
 
 static size_t full_sort_lds() { return static_cast<size_t>(BM + BN) * LDK * sizeof(float); }
 
+template <bool VEC, int EPI>
+static int launch_tiled(const float* U, int64_t B, const float* E, int64_t N, int64_t D, const float* bias, float* S,
+                        int64_t ldS, hipStream_t st) {
+  const dim3 grid(static_cast<unsigned>((N + BN - 1) / BN), static_cast<unsigned>((B + BM - 1) / BM));
+  const size_t lds = full_sort_lds();
+  auto k = full_sort_kernel<VEC, EPI>;
+  if (int rc = set_lds(k, lds)) return rc;
+  hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, U, B, E, N, D, bias, S, ldS);
+  return check_launch();
+}
+
 static int launch_full_sort(const float* U, int64_t B, const float* E, int64_t N, int64_t D, float* S, int64_t ldS,
                             hipStream_t st) {
   const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
-  const dim3 grid(static_cast<unsigned>((N + BN - 1) / BN), static_cast<unsigned>((B + BM - 1) / BM));
-  const size_t lds = full_sort_lds();
-  if (vec) {
-    auto k = full_sort_kernel<true>;
-    if (int rc = set_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, U, B, E, N, D, S, ldS);
-  } else {
-    auto k = full_sort_kernel<false>;
-    if (int rc = set_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, grid, dim3(kBlock), lds, st, U, B, E, N, D, S, ldS);
-  }
-  return check_launch();
+  return vec ? launch_tiled<true, EPI_NONE>(U, B, E, N, D, nullptr, S, ldS, st)
+             : launch_tiled<false, EPI_NONE>(U, B, E, N, D, nullptr, S, ldS, st);
 }
 
 constexpr int64_t kTopkChunkBytes = 1LL << 30;  // scores workspace per user chunk
@@ -331,6 +351,26 @@ extern "C" int mi_oov_full_sort_scores(const float* U, int64_t B, const float* E
   if (!U || !E || !scores) return MI_OOV_ERR_NULL;
   if ((B + BM - 1) / BM > 65535) return MI_OOV_ERR_SHAPE;
   return launch_full_sort(U, B, E, N, D, scores, N, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, const float* bias,
+                                 int64_t N_out, int act, float* Y, void* stream) {
+  if (B < 0 || K <= 0 || N_out <= 0) return MI_OOV_ERR_SHAPE;
+  if (act < 0 || act > 2) return MI_OOV_ERR_KIND;
+  if (B == 0) return MI_OOV_OK;
+  if (!X || !W || !bias || !Y) return MI_OOV_ERR_NULL;
+  if ((B + BM - 1) / BM > 65535) return MI_OOV_ERR_SHAPE;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (K % 4 == 0) && aligned16(X) && aligned16(W);
+#define MI_LIN(V)                                                                                   \
+  switch (act) {                                                                                    \
+    case 0: return launch_tiled<V, EPI_BIAS>(X, B, W, N_out, K, bias, Y, N_out, st);                \
+    case 1: return launch_tiled<V, EPI_BIAS_GELU>(X, B, W, N_out, K, bias, Y, N_out, st);           \
+    default: return launch_tiled<V, EPI_BIAS_SIGMOID>(X, B, W, N_out, K, bias, Y, N_out, st);       \
+  }
+  if (vec) { MI_LIN(true) }
+  MI_LIN(false)
+#undef MI_LIN
 }
 
 extern "C" int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k) {

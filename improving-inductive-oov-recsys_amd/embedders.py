@@ -297,6 +297,15 @@ def _hash_mlp(in_features, hidden, out_features, device):
                          nn.Sigmoid()).to(device)
 
 
+def _run_hash_net(net, x):
+    """The reference's `*_hash_net(x)`.  Without autograd the Linear+GELU / Linear+Sigmoid pairs run
+    on mi_oov_linear_act (f32 MFMA, activation fused in the epilogue); when a gradient is required
+    the nn.Sequential itself runs so that torch autograd sees it."""
+    if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
+        return net(x)
+    return ops.hash_net_forward(net, x)
+
+
 class _HashKeyMixin:
     HASH_KEY_PATH = "./hash_keys"
     MAX_HASH = 16777216
@@ -358,10 +367,10 @@ class DeepHashEmbedder(_HashKeyMixin, _FeatureEmbedder):
         self.hash_keys = self.get_hash_keys()
 
     def _hash_users(self, users):
-        return self.user_hash_net(self._hash_ids(users))
+        return _run_hash_net(self.user_hash_net, self._hash_ids(users))
 
     def _hash_items(self, items):
-        return self.item_hash_net(self._hash_ids(items))
+        return _run_hash_net(self.item_hash_net, self._hash_ids(items))
 
     def embed_user_ids(self, user_ids, model):
         return self._hash_users(user_ids)
@@ -395,11 +404,11 @@ class FeatDeepHashEmbedder(_HashKeyMixin, _FeatureEmbedder):
 
     def _hash_users(self, users, feat_lookup_users):
         nn_input = torch.hstack((self._hash_ids(users), ops.gather_rows(feat_lookup_users, self.user_feature_mat)))
-        return self.user_hash_net(nn_input)
+        return _run_hash_net(self.user_hash_net, nn_input)
 
     def _hash_items(self, items, feat_lookup_items):
         nn_input = torch.hstack((self._hash_ids(items), ops.gather_rows(feat_lookup_items, self.item_feature_mat)))
-        return self.item_hash_net(nn_input)
+        return _run_hash_net(self.item_hash_net, nn_input)
 
     def embed_user_ids(self, old_user_ids, model):
         return self._hash_users(old_user_ids, self._lookup(old_user_ids))
@@ -427,10 +436,10 @@ class DNNEmbedder(_FeatureEmbedder):
         return old_ids
 
     def _hash_users(self, users, feat_lookup_users):
-        return self.user_hash_net(ops.gather_rows(feat_lookup_users, self.user_feature_mat))
+        return _run_hash_net(self.user_hash_net, ops.gather_rows(feat_lookup_users, self.user_feature_mat))
 
     def _hash_items(self, items, feat_lookup_items):
-        return self.item_hash_net(ops.gather_rows(feat_lookup_items, self.item_feature_mat))
+        return _run_hash_net(self.item_hash_net, ops.gather_rows(feat_lookup_items, self.item_feature_mat))
 
     def embed_user_ids(self, old_user_ids, model):
         return self._hash_users(old_user_ids, self._lookup(old_user_ids))

@@ -400,6 +400,43 @@ def full_sort_scores(U, E):
     return _full_sort_forward(U, E)
 
 
+ACTS = {None: 0, "none": 0, "gelu": 1, "sigmoid": 2}
+
+
+def linear_act(X, W, bias, act=None):
+    """act(X @ W.T + bias) on the f32 matrix cores (nn.Linear + nn.GELU()/nn.Sigmoid() of the hash nets,
+    dh_embedder.py:70-89).  Forward only: training goes through torch autograd."""
+    X, W, bias = _f32(X, "X"), _f32(W, "W"), _f32(bias, "bias")
+    if X.shape[1] != W.shape[1] or bias.numel() != W.shape[0]:
+        raise ValueError(f"shape mismatch: X {tuple(X.shape)}, W {tuple(W.shape)}, bias {tuple(bias.shape)}")
+    Y = torch.empty((X.shape[0], W.shape[0]), dtype=torch.float32, device=X.device)
+    with C.on_device(X):
+        rc = C.lib().mi_oov_linear_act(C.ptr(X), X.shape[0], X.shape[1], C.ptr(W), C.ptr(bias), W.shape[0], ACTS[act],
+                                       C.ptr(Y), C.stream_of(X))
+    C.check(rc, "mi_oov_linear_act")
+    return Y
+
+
+def hash_net_forward(net, x):
+    """Run an nn.Sequential of Linear / GELU / Sigmoid (the reference's *_hash_net) through
+    mi_oov_linear_act, fusing each activation into the producing layer's epilogue.  Used when no
+    gradient is needed; otherwise the caller falls back to the module itself (torch autograd)."""
+    mods = list(net)
+    i = 0
+    while i < len(mods):
+        lin = mods[i]
+        if not isinstance(lin, torch.nn.Linear) or lin.bias is None:
+            raise TypeError("hash_net_forward expects Linear(+bias) layers followed by GELU / Sigmoid")
+        act = None
+        if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.GELU) and mods[i + 1].approximate == "none":
+            act, i = "gelu", i + 1
+        elif i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.Sigmoid):
+            act, i = "sigmoid", i + 1
+        x = linear_act(x, lin.weight, lin.bias, act)
+        i += 1
+    return x
+
+
 def score_topk(U, E, k, n_skip_low=0):
     """Per-row top-k of U @ E.T without returning the [B,N] matrix.  Returns (vals, idx)."""
     U, E = _f32(U, "U"), _f32(E, "E")

@@ -182,11 +182,22 @@ int mi_oov_broadcast_rows(const float* vec, int64_t B, int64_t D, float* out, vo
  *          BPR.full_sort_predict / ind_full_sort_predict (bpr.py:151-163)
  *              scores[b,n] = sum_d U[b,d]*E[n,d]    -> f32[B,N] (caller views it [B*N])
  *          computed on the f32 MFMA (v_mfma_f32_32x32x2_f32): per element an fmaf chain in
- *          increasing d starting from +0 (exact f32, no reduced precision).
+ *          increasing d starting from +0, d zero-padded to a multiple of 32 (exact f32, no
+ *          reduced precision).
  * ------------------------------------------------------------------------------------------ */
 int mi_oov_rowdot(const float* U, const float* E, int64_t B, int64_t D, float* score, void* stream);
 int mi_oov_full_sort_scores(const float* U, int64_t B, const float* E, int64_t N, int64_t D,
                             float* scores, void* stream);
+
+/* Linear layer of the dhe / fdhe / dnn hash nets (R/inductive/dh_embedder.py:70-89,
+ * feat_dh_embedder.py:108-127, dnn_embedder.py:65-90):  Y = act(X W^T + bias)
+ *   X f32[B,K]   W f32[N_out,K] (nn.Linear.weight)   bias f32[N_out]   Y f32[B,N_out]
+ *   act: 0 identity, 1 nn.GELU() (erf form), 2 nn.Sigmoid()
+ * Same f32-MFMA tiling as the scoring kernel: per element an fmaf chain over increasing k from +0
+ * (k zero-padded to a multiple of 32), then + bias, then the activation.                      */
+enum { MI_OOV_ACT_NONE = 0, MI_OOV_ACT_GELU = 1, MI_OOV_ACT_SIGMOID = 2 };
+int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, const float* bias,
+                      int64_t N_out, int act, float* Y, void* stream);
 
 /* Fused full-sort score + per-row top-k (the [B,N] matrix is never written).  Serves
  *   - the evaluator's torch.topk(scores, k) (R/evaluator/collector.py:158-167), and

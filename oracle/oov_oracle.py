@@ -192,6 +192,13 @@ def full_sort_scores(U, E):
     return out
 
 
+def linear_act(X, W, bias, act=0):
+    X, W, bias = _f32(X), _f32(W), _f32(bias)
+    Y = np.empty((X.shape[0], W.shape[0]), np.float32)
+    lib().oov_linear_act(_p(X), _c(X.shape[0]), _c(X.shape[1]), _p(W), _p(bias), _c(W.shape[0]), ctypes.c_int(act), _p(Y))
+    return Y
+
+
 def score_topk(U, E, k, n_skip_low=0):
     U, E = _f32(U), _f32(E)
     vals = np.empty((U.shape[0], k), np.float32)

@@ -217,6 +217,25 @@ def test_scores_topk_vs_oracle(B, N, D, k, oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
+@pytest.mark.parametrize("B,K,N_out", [(7, 16, 512), (300, 1024, 512), (513, 512, 64), (130, 22, 8), (64, 100, 130)])
+def test_linear_act_vs_oracle(B, K, N_out, oracle, ops, dev):
+    """Linear layers of the dhe/fdhe/dnn hash nets: pre-activation bit-exact (same fmaf chain),
+    GELU / sigmoid within a few ulp (device erff/expf vs libm)."""
+    rng = np.random.default_rng(K + N_out)
+    X = (rng.standard_normal((B, K)) * (1000.0 if K == 16 else 1.0)).astype(np.float32)
+    W = (rng.standard_normal((N_out, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N_out).astype(np.float32)
+    got = ops.linear_act(T(X, dev), T(W, dev), T(b, dev), None).cpu().numpy()
+    assert bits_equal(got, oracle.linear_act(X, W, b, 0))
+    for name, act in (("gelu", 1), ("sigmoid", 2)):
+        got = ops.linear_act(T(X, dev), T(W, dev), T(b, dev), name).cpu().numpy()
+        want = oracle.linear_act(X, W, b, act)
+        assert np.allclose(got, want, rtol=2e-6, atol=1e-7), name
+    ref = torch.nn.functional.gelu(torch.nn.functional.linear(torch.from_numpy(X), torch.from_numpy(W), torch.from_numpy(b)))
+    got = ops.linear_act(T(X, dev), T(W, dev), T(b, dev), "gelu").cpu()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+
+
 def test_topk_edge_cases(oracle, ops, dev):
     rng = np.random.default_rng(3)
     U = rng.standard_normal((17, 8), dtype=np.float32)
