@@ -256,6 +256,24 @@ def test_topk_edge_cases(oracle, ops, dev):
     assert np.array_equal(idx.cpu().numpy(), o_idx) and bits_equal(vals.cpu().numpy(), o_vals)
 
 
+@pytest.mark.parametrize("B,N,D,k,skip", [(70, 3000, 64, 10, 1), (9, 1300, 22, 5, 0), (130, 4159, 64, 20, 1),
+                                          (33, 20000, 32, 100, 1), (5, 40000, 64, 256, 7)])
+def test_fused_topk_vs_oracle(B, N, D, k, skip, oracle, ops, dev):
+    """N >= 128 k takes the fused two-pass path (tile maxima -> tau -> filter -> rank): exact top-k with
+    the [B,N] matrix never written, including ties across tiles, NaN rows and duplicated scores."""
+    rng = np.random.default_rng(N + k)
+    U = rng.standard_normal((B, D), dtype=np.float32)
+    E = rng.standard_normal((N, D), dtype=np.float32)
+    E[100:160] = E[100]            # 60 exact ties inside one tile and across its neighbour
+    E[N - 1] = E[3]                # tie between the first and the last tile
+    E[700] = np.nan                # NaN sorts first
+    U[1] = 0.0                     # a whole row of equal scores (+0): candidate list overflows -> fallback
+    vals, idx = ops.score_topk(T(U, dev), T(E, dev), k, skip)
+    o_vals, o_idx = oracle.score_topk(U, E, k, skip)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    assert bits_equal(vals.cpu().numpy(), o_vals)
+
+
 def test_gather_splice_vs_oracle(oracle, ops, dev):
     rng = np.random.default_rng(11)
     for D in (64, 1, 50, 200):
