@@ -199,13 +199,23 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
+        # Clock ramp, before the W warm-up steps: keep launching until the time of a 256-step burst has
+        # settled (two consecutive bursts within 2 %) and at least --ramp-seconds have passed; give up
+        # after 5 x that.  Untimed; uses the same id batches as the run.
         t_ramp = time.perf_counter()
-        i = 0
-        while time.perf_counter() - t_ramp < args.ramp_seconds:  # clock ramp, before the W warm-up steps
-            step(i % total)
-            i += 1
-            if i % 256 == 0:
-                torch.cuda.synchronize()
+        i, prev = 0, None
+        while True:
+            t_b = time.perf_counter()
+            for _ in range(256):
+                step(i % total)
+                i += 1
+            torch.cuda.synchronize()
+            now = time.perf_counter()
+            burst = now - t_b
+            settled = prev is not None and abs(burst - prev) <= 0.02 * burst
+            prev = burst
+            if (settled and now - t_ramp >= args.ramp_seconds) or now - t_ramp >= 5 * args.ramp_seconds:
+                break
         for i in range(args.warmup):
             step(i)
         # HIP events on the launch stream (torch's current stream is the one handed to the C ABI).

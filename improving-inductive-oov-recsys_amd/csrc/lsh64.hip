@@ -102,11 +102,30 @@ __global__ __launch_bounds__(kBlock) void lsh64_kernel(const int64_t* __restrict
         acc.z = __builtin_fmaf(bit, bw[h].z, acc.z);
         acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
       }
+      // emb = acc / cnt, correctly rounded (0/0 -> NaN row, lsh_embedder.py:178).  cnt is an integer in
+      // [0, 8], so instead of four IEEE division sequences (~9 VALU each) one reciprocal r = RN(1/cnt)
+      // is shared and each quotient is refined once:  q = a r;  e = fma(-q, cnt, a);  q' = fma(e, r, q).
+      // Verified EXHAUSTIVELY on the CPU (same IEEE fma) for cnt = 1..8 and all 2^32 values of a: q'
+      // equals RN(a / cnt) except for a = -0 (acc is never -0: it starts at +0 and every step is
+      // RN(bit*w + acc)) and for |a| < 2^-124 with cnt = 6 (result subnormal).  Lanes whose |acc| is
+      // below 2^-100 (including exact zeros, i.e. the cnt = 0 rows) or infinite take the IEEE division.
+      const float rc = 1.0f / cnt;
       float4 emb;
-      emb.x = acc.x / cnt;  // 0/0 -> NaN row (lsh_embedder.py:178)
-      emb.y = acc.y / cnt;
-      emb.z = acc.z / cnt;
-      emb.w = acc.w / cnt;
+      {
+        float q;
+        q = acc.x * rc; emb.x = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.x), rc, q);
+        q = acc.y * rc; emb.y = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.y), rc, q);
+        q = acc.z * rc; emb.z = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.z), rc, q);
+        q = acc.w * rc; emb.w = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.w), rc, q);
+      }
+      const float amin = fminf(fminf(fabsf(acc.x), fabsf(acc.y)), fminf(fabsf(acc.z), fabsf(acc.w)));
+      const float amax = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+      if (!(amin >= 0x1p-100f) || !(amax < __builtin_inff())) {
+        emb.x = acc.x / cnt;
+        emb.y = acc.y / cnt;
+        emb.z = acc.z / cnt;
+        emb.w = acc.w / cnt;
+      }
       if (LOOKUP && !oov[r]) emb = x[r];
       if (!valid[r]) emb = make_float4(qnan(), qnan(), qnan(), qnan());
       const bool live = row[r] < B;

@@ -192,6 +192,32 @@ def test_lookup_and_lookup_score_vs_oracle(F, H, D, oracle, ops, dev):
     assert bits_equal(s2.cpu().numpy(), oracle.rowdot(other, want))
 
 
+@pytest.mark.parametrize("H", [3, 6, 7, 8])
+def test_lsh_division_extremes(H, oracle, ops, dev):
+    """The hot kernel divides by the code's popcount with a shared reciprocal + one fma refinement and
+    falls back to IEEE division for tiny / zero / infinite sums: sweep bucket tables whose entries are
+    subnormal, near the normal/subnormal border, huge, zero and mixed-sign so that every branch and
+    every popcount 0..H is hit, bit for bit against the oracle's plain division."""
+    rng = np.random.default_rng(H)
+    N, B = 20000, 20000
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    planes = rng.standard_normal((H, 64), dtype=np.float32)
+    ids = np.arange(B, dtype=np.int64)
+    scales = [1.0, 1e-45, 3e-39, 1.2e-38, 2.4e-38, 1e-36, 1e-30, 1e30, 3.0e38, 0.0]
+    for s in scales:
+        W = rng.standard_normal((H, 64)).astype(np.float32)
+        with np.errstate(over="ignore", under="ignore"):
+            W = (W.astype(np.float64) * s).astype(np.float32)
+        W[0, :8] = 0.0
+        W[1, 8:16] = -W[2, 8:16]  # exact cancellations -> +0 sums
+        if s == 3.0e38:
+            W[H - 1, 16:24] = np.inf
+        emb = ops.lsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(W, dev)).cpu().numpy()
+        want, bits = oracle.lsh_embed(ids, feat, planes, W, want_bits=True)
+        assert bits_equal(emb, want), f"scale {s}"
+        assert len(set(bits.sum(1).tolist())) >= H  # (almost) every popcount occurs
+
+
 def test_empty_batches(ops, dev):
     ids = torch.empty((0,), dtype=torch.int64, device=dev)
     feat = torch.randn(10, 8, device=dev)

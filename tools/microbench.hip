@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void staged_kernel(const int64_t* __restrict__
       id[r] = (ORDER == 1 && tile == (int64_t)blockIdx.x * 4 + wv) ? id0[r] : ids[row[r]];
     }
     float4 u[R], x[R];
-    if (ORDER == 0) {
+    if (ORDER != 1) {
 #pragma unroll
       for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
     }
@@ -167,7 +167,15 @@ __global__ __launch_bounds__(256) void staged_kernel(const int64_t* __restrict__
         }
         if (STAGE == 1) acc = make_float4(cnt + u[r].x, u[r].y, u[r].z, u[r].w);
       }
-      if (STAGE >= 3) { acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt; }
+      if (STAGE >= 3 && ORDER != 3) { acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt; }
+      if (STAGE >= 3 && ORDER == 3) {  // Markstein: r = RN(1/c); q = a r; e = fma(-q, c, a); q' = fma(e, r, q)
+        const float rc = 1.0f / cnt;
+        float q;
+        q = acc.x * rc; acc.x = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.x), rc, q);
+        q = acc.y * rc; acc.y = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.y), rc, q);
+        q = acc.z * rc; acc.z = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.z), rc, q);
+        q = acc.w * rc; acc.w = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.w), rc, q);
+      }
       float sp;
       if (STAGE >= 4) sp = dot4_muladd(u[r], acc, 0.f);
       else sp = (acc.x + acc.y) + (acc.z + acc.w) + ((STAGE == 2 || STAGE == 3) ? u[r].x + u[r].y + u[r].z + u[r].w : 0.f);
@@ -315,6 +323,8 @@ int main(int argc, char** argv) {
     RUNSO(4, 2, 1, "staged 4 (full) ORDER=1 R=2") RUNSO(4, 8, 1, "staged 4 (full) ORDER=1 R=8")
     RUNSO(4, 4, 2, "staged 4 (full) weights via LDS R=4") RUNSO(4, 2, 2, "staged 4 (full) weights via LDS R=2")
     RUNSO(4, 8, 2, "staged 4 (full) weights via LDS R=8") RUNSO(1, 4, 2, "staged 1 weights via LDS R=4")
+    RUNSO(4, 4, 3, "staged 4 (full) Markstein division R=4") RUNSO(4, 4, 0, "staged 4 (full) IEEE division R=4 (again)")
+    RUNSO(4, 4, 3, "staged 4 (full) Markstein division R=4 (again)")
     RUNS(0, 2, "staged 0 R=2") RUNS(4, 2, "staged 4 (full) R=2") RUNS(4, 1, "staged 4 (full) R=1") RUNS(4, 8, "staged 4 (full) R=8")
   }
   if (getenv("MB_STAMPS")) {
