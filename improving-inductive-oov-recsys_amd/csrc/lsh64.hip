@@ -34,6 +34,87 @@
 
 namespace mi_oov {
 
+// One tile = 16 lookups of one wave (4 rounds x 4 groups).  FULL tiles (all 16 rows < B) skip every
+// tail clamp and liveness test; only the last tile of a launch can be partial.
+template <int H, bool SCORE, bool STORE, bool LOOKUP, bool FULL>
+__device__ __forceinline__ void lsh64_tile(int64_t tile, int l16, int grp, const float4 (&pw)[H], const float4 (&bw)[H],
+                                           const int64_t* __restrict__ ids, int64_t B,
+                                           const float* __restrict__ feat, int64_t N,
+                                           const float* __restrict__ vtable, int64_t n_vocab,
+                                           const float* __restrict__ other, float* __restrict__ score,
+                                           float* __restrict__ out) {
+  constexpr int R = 4;
+  int64_t row[R], idc[R];
+  bool valid[R], oov[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    row[r] = tile * (4 * R) + r * 4 + grp;
+    idc[r] = ids[(FULL || row[r] < B) ? row[r] : B - 1];  // clamped: tail groups recompute the last row
+  }
+  float4 u[SCORE ? R : 1];
+  if (SCORE) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      u[r] = *reinterpret_cast<const float4*>(other + ((FULL || row[r] < B) ? row[r] : B - 1) * 64 + l16 * 4);
+  }
+  float4 x[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    oov[r] = !LOOKUP || idc[r] >= n_vocab;
+    valid[r] = oov[r] ? static_cast<uint64_t>(idc[r]) < static_cast<uint64_t>(N) : idc[r] >= 0;
+    const float* base = oov[r] ? feat : vtable;
+    x[r] = *reinterpret_cast<const float4*>(base + (valid[r] ? idc[r] : 0) * 64 + l16 * 4);
+  }
+
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cnt = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float s = row16_sum(dot4_fma(x[r], pw[h], 0.f));
+      const float bit = (s < 0.f) ? 0.f : 1.f;  // >= 0, +-0 and NaN -> 1 (torch_hash.py:57-59)
+      cnt = cnt + bit;
+      acc.x = __builtin_fmaf(bit, bw[h].x, acc.x);
+      acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
+      acc.z = __builtin_fmaf(bit, bw[h].z, acc.z);
+      acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+    }
+    // emb = acc / cnt, correctly rounded (0/0 -> NaN row, lsh_embedder.py:178).  cnt is an integer in
+    // [0, 8], so instead of four IEEE division sequences (~9 VALU each) one reciprocal r = RN(1/cnt)
+    // is shared and each quotient is refined once:  q = a r;  e = fma(-q, cnt, a);  q' = fma(e, r, q).
+    // Verified EXHAUSTIVELY on the CPU (same IEEE fma) for cnt = 1..8 and all 2^32 values of a: q'
+    // equals RN(a / cnt) except for a = -0 (acc is never -0: it starts at +0 and every step is
+    // RN(bit*w + acc)) and for |a| < 2^-124 with cnt = 6 (result subnormal).  Lanes whose |acc| is
+    // below 2^-100 (including exact zeros, i.e. the cnt = 0 rows) or infinite take the IEEE division.
+    const float rc = 1.0f / cnt;
+    float4 emb;
+    {
+      float q;
+      q = acc.x * rc; emb.x = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.x), rc, q);
+      q = acc.y * rc; emb.y = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.y), rc, q);
+      q = acc.z * rc; emb.z = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.z), rc, q);
+      q = acc.w * rc; emb.w = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.w), rc, q);
+    }
+    const float amin = fminf(fminf(fabsf(acc.x), fabsf(acc.y)), fminf(fabsf(acc.z), fabsf(acc.w)));
+    const float amax = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+    if (!(amin >= 0x1p-100f) || !(amax < __builtin_inff())) {
+      emb.x = acc.x / cnt;
+      emb.y = acc.y / cnt;
+      emb.z = acc.z / cnt;
+      emb.w = acc.w / cnt;
+    }
+    if (LOOKUP && !oov[r]) emb = x[r];
+    if (!valid[r]) emb = make_float4(qnan(), qnan(), qnan(), qnan());
+    const bool live = FULL || row[r] < B;
+    if (STORE && live) *reinterpret_cast<float4*>(out + row[r] * 64 + l16 * 4) = emb;
+    if (SCORE) {
+      const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
+      if (l16 == 0 && live) score[row[r]] = s;
+    }
+  }
+}
+
 template <int H, bool SCORE, bool STORE, bool LOOKUP>
 __global__ __launch_bounds__(kBlock) void lsh64_kernel(const int64_t* __restrict__ ids, int64_t B,
                                                        const float* __restrict__ feat, int64_t N,
@@ -42,16 +123,15 @@ __global__ __launch_bounds__(kBlock) void lsh64_kernel(const int64_t* __restrict
                                                        const float* __restrict__ buckets,
                                                        const float* __restrict__ other,
                                                        float* __restrict__ score, float* __restrict__ out) {
-  constexpr int R = 4;
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
-  const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
+  const int64_t ntiles = (B + 15) / 16;
+  const int64_t nfull = B / 16;
   const int64_t tstep = static_cast<int64_t>(gridDim.x) * 4;
 
   // Plane / bucket slices -> VGPRs through LDS: the workgroup fetches the 2 x H x 256 B once (one 16-B
   // load per thread) and every lane reads its 2 x H float4 back with ds_read_b128, instead of 2 x H
-  // global loads per lane (16 KiB of L1 traffic per wave) queued in front of the ids -> rows gathers.
-  // Measured neutral at B = 65536 (10.7 vs 10.9 us): kept because it removes 4096 x 16 KiB of
-  // redundant vector-memory requests per launch.
+  // global loads per lane (16 KiB of L1 traffic per wave) queued in front of the ids -> rows gathers
+  // (-0.4 us in tools/microbench.hip).
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [2][H][64]
   for (int i = threadIdx.x; i < 2 * H * 16; i += kBlock) {
     const float* src = (i < H * 16) ? planes + i * 4 : buckets + (i - H * 16) * 4;
@@ -66,75 +146,10 @@ __global__ __launch_bounds__(kBlock) void lsh64_kernel(const int64_t* __restrict
   }
 
   for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles; tile += tstep) {
-    int64_t row[R], idc[R];
-    bool valid[R], oov[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      row[r] = tile * (4 * R) + r * 4 + grp;
-      idc[r] = ids[row[r] < B ? row[r] : B - 1];  // clamped: tail groups recompute the last row
-    }
-    float4 u[SCORE ? R : 1];
-    if (SCORE) {
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        u[r] = *reinterpret_cast<const float4*>(other + (row[r] < B ? row[r] : B - 1) * 64 + l16 * 4);
-    }
-    float4 x[R];
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      oov[r] = !LOOKUP || idc[r] >= n_vocab;
-      valid[r] = oov[r] ? static_cast<uint64_t>(idc[r]) < static_cast<uint64_t>(N) : idc[r] >= 0;
-      const float* base = oov[r] ? feat : vtable;
-      x[r] = *reinterpret_cast<const float4*>(base + (valid[r] ? idc[r] : 0) * 64 + l16 * 4);
-    }
-
-#pragma unroll
-    for (int r = 0; r < R; ++r) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      float cnt = 0.f;
-#pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const float s = row16_sum(dot4_fma(x[r], pw[h], 0.f));
-        const float bit = (s < 0.f) ? 0.f : 1.f;  // >= 0, +-0 and NaN -> 1 (torch_hash.py:57-59)
-        cnt = cnt + bit;
-        acc.x = __builtin_fmaf(bit, bw[h].x, acc.x);
-        acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
-        acc.z = __builtin_fmaf(bit, bw[h].z, acc.z);
-        acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
-      }
-      // emb = acc / cnt, correctly rounded (0/0 -> NaN row, lsh_embedder.py:178).  cnt is an integer in
-      // [0, 8], so instead of four IEEE division sequences (~9 VALU each) one reciprocal r = RN(1/cnt)
-      // is shared and each quotient is refined once:  q = a r;  e = fma(-q, cnt, a);  q' = fma(e, r, q).
-      // Verified EXHAUSTIVELY on the CPU (same IEEE fma) for cnt = 1..8 and all 2^32 values of a: q'
-      // equals RN(a / cnt) except for a = -0 (acc is never -0: it starts at +0 and every step is
-      // RN(bit*w + acc)) and for |a| < 2^-124 with cnt = 6 (result subnormal).  Lanes whose |acc| is
-      // below 2^-100 (including exact zeros, i.e. the cnt = 0 rows) or infinite take the IEEE division.
-      const float rc = 1.0f / cnt;
-      float4 emb;
-      {
-        float q;
-        q = acc.x * rc; emb.x = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.x), rc, q);
-        q = acc.y * rc; emb.y = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.y), rc, q);
-        q = acc.z * rc; emb.z = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.z), rc, q);
-        q = acc.w * rc; emb.w = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.w), rc, q);
-      }
-      const float amin = fminf(fminf(fabsf(acc.x), fabsf(acc.y)), fminf(fabsf(acc.z), fabsf(acc.w)));
-      const float amax = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
-      if (!(amin >= 0x1p-100f) || !(amax < __builtin_inff())) {
-        emb.x = acc.x / cnt;
-        emb.y = acc.y / cnt;
-        emb.z = acc.z / cnt;
-        emb.w = acc.w / cnt;
-      }
-      if (LOOKUP && !oov[r]) emb = x[r];
-      if (!valid[r]) emb = make_float4(qnan(), qnan(), qnan(), qnan());
-      const bool live = row[r] < B;
-      if (STORE && live) *reinterpret_cast<float4*>(out + row[r] * 64 + l16 * 4) = emb;
-      if (SCORE) {
-        const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
-        if (l16 == 0 && live) score[row[r]] = s;
-      }
-    }
+    if (tile < nfull)
+      lsh64_tile<H, SCORE, STORE, LOOKUP, true>(tile, l16, grp, pw, bw, ids, B, feat, N, vtable, n_vocab, other, score, out);
+    else
+      lsh64_tile<H, SCORE, STORE, LOOKUP, false>(tile, l16, grp, pw, bw, ids, B, feat, N, vtable, n_vocab, other, score, out);
   }
 }
 
