@@ -38,6 +38,8 @@ _SIGNATURES = {
     "mi_oov_gather_mean": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),
     "mi_oov_gather_rows": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "mi_oov_splice_rows": (ctypes.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_token_fields_embed": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp,
+                                                 _vp, _i64, ctypes.c_int, _vp, _vp]),
     "mi_oov_col_mean_workspace": (_i64, [_i64, _i64]),
     "mi_oov_col_mean": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_broadcast_rows": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),

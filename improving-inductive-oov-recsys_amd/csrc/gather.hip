@@ -197,9 +197,119 @@ __global__ __launch_bounds__(kBlock) void rowdot_kernel(const float* __restrict_
   }
 }
 
+// ---- context models: fused-table token gather with the user/item OOV splice ---------------------
+// InductiveContextRecommender.embed_token_fields (abstract_recommender.py:794-842) and
+// InductiveFMFirstOrderLinear.embed_token_fields (layers.py:1634-1693): row (b, f) is
+// table[tokens[b,f] + offsets[f]] except that field 0 / 1 take the plugin (or OOV bucket) row of an
+// out-of-vocabulary user / item.  The reference zeroes those ids, gathers, and overwrites.
+struct TokenArgs {
+  const int64_t* tokens;  // [B, nf]
+  int64_t B, nf;
+  const int64_t* offsets;  // [nf]
+  const float* table;      // [T, D]
+  int64_t T, D;
+  int64_t n_users, n_items;
+  const float* oov_u;  // [n_oov_u, D] rows of the OOV users in order of appearance
+  const int64_t* rank_u;  // [B] rank of row b among the OOV users
+  int64_t n_oov_u;
+  const float* oov_i;
+  const int64_t* rank_i;
+  int64_t n_oov_i;
+  float* out;  // [B, nf, D], or [B, D] when summing over the fields
+};
+
+__device__ __forceinline__ const float* token_row(const TokenArgs& a, int64_t b, int64_t f) {
+  const int64_t tok = a.tokens[b * a.nf + f];
+  if (f == 0 && tok >= a.n_users) {
+    const int64_t k = a.rank_u[b];
+    return (static_cast<uint64_t>(k) < static_cast<uint64_t>(a.n_oov_u)) ? a.oov_u + k * a.D : nullptr;
+  }
+  if (f == 1 && tok >= a.n_items) {
+    const int64_t k = a.rank_i[b];
+    return (static_cast<uint64_t>(k) < static_cast<uint64_t>(a.n_oov_i)) ? a.oov_i + k * a.D : nullptr;
+  }
+  const int64_t r = tok + a.offsets[f];
+  return (tok >= 0 && static_cast<uint64_t>(r) < static_cast<uint64_t>(a.T)) ? a.table + r * a.D : nullptr;
+}
+
+// second order: one 16-lane group per (b, f) row, float4 per lane, R rows in flight
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void token_fields_kernel(TokenArgs a) {
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t rows = a.B * a.nf;
+  const int64_t ntiles = (rows + 4 * R - 1) / (4 * R);
+  const int dchunks = static_cast<int>((a.D + 63) / 64);
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+       tile += static_cast<int64_t>(gridDim.x) * 4) {
+    const float* src[R];
+    int64_t row[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      src[r] = (row[r] < rows) ? token_row(a, row[r] / a.nf, row[r] % a.nf) : nullptr;
+    }
+    for (int c = 0; c < dchunks; ++c) {
+      const int e = (c * 16 + l16) * 4;
+      float4 v[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        v[r] = src[r] ? load4<VEC>(src[r], e, a.D) : make_float4(qnan(), qnan(), qnan(), qnan());
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (row[r] < rows) store4<VEC>(a.out + row[r] * a.D, e, a.D, v[r]);
+    }
+  }
+}
+
+// first order: out[b, d] = sum over the fields, in field order (torch.sum(dim=1) of [B, nf, D]); D is
+// the model's output_dim (1), so one thread per (b, d)
+__global__ __launch_bounds__(kBlock) void token_fields_sum_kernel(TokenArgs a) {
+  const int64_t total = a.B * a.D;
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t b = i / a.D, d = i - b * a.D;
+    float acc = 0.f;
+    bool ok = true;
+    for (int64_t f = 0; f < a.nf; ++f) {
+      const float* src = token_row(a, b, f);
+      ok = ok && (src != nullptr);
+      acc = acc + (src ? src[d] : 0.f);
+    }
+    a.out[i] = ok ? acc : qnan();
+  }
+}
+
 }  // namespace mi_oov
 
 using namespace mi_oov;
+
+extern "C" int mi_oov_token_fields_embed(const int64_t* tokens, int64_t B, int64_t nf, const int64_t* offsets,
+                                         const float* table, int64_t T, int64_t D, int64_t n_users, int64_t n_items,
+                                         const float* oov_user_rows, const int64_t* user_rank, int64_t n_oov_users,
+                                         const float* oov_item_rows, const int64_t* item_rank, int64_t n_oov_items,
+                                         int sum_fields, float* out, void* stream) {
+  if (B < 0 || nf <= 0 || T <= 0 || D <= 0 || n_oov_users < 0 || n_oov_items < 0) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!tokens || !offsets || !table || !out) return MI_OOV_ERR_NULL;
+  if ((n_oov_users > 0 && (!oov_user_rows || !user_rank)) || (n_oov_items > 0 && (!oov_item_rows || !item_rank)))
+    return MI_OOV_ERR_NULL;
+  TokenArgs a{tokens, B, nf, offsets, table, T, D, n_users, n_items, oov_user_rows, user_rank, n_oov_users,
+              oov_item_rows, item_rank, n_oov_items, out};
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (sum_fields) {
+    hipLaunchKernelGGL(token_fields_sum_kernel, dim3(grid_for(B * D, kBlock)), dim3(kBlock), 0, st, a);
+    return check_launch();
+  }
+  const bool vec = (D % 4 == 0) && aligned16(table) && aligned16(out) && (!oov_user_rows || aligned16(oov_user_rows)) &&
+                   (!oov_item_rows || aligned16(oov_item_rows));
+  const int grid = grid_for(B * nf, 64);
+  if (vec)
+    hipLaunchKernelGGL(token_fields_kernel<true>, dim3(grid), dim3(kBlock), 0, st, a);
+  else
+    hipLaunchKernelGGL(token_fields_kernel<false>, dim3(grid), dim3(kBlock), 0, st, a);
+  return check_launch();
+}
 
 extern "C" int mi_oov_gather_rows(const int64_t* ids, int64_t B, const float* W, int64_t N, int64_t D, float* out,
                                   void* stream) {

@@ -165,6 +165,22 @@ int mi_oov_splice_rows(const int64_t* ids, const int64_t* oov_rank, int64_t B,
                        const float* oov_rows, int64_t n_oov, int64_t D,
                        float* out, void* stream);
 
+/* Context models (DCNV2 / WideDeep / xDeepFM): the fused-table token gather with the OOV splice.
+ *   InductiveContextRecommender.embed_token_fields   (R/model/abstract_recommender.py:794-842)
+ *   InductiveFMFirstOrderLinear.embed_token_fields   (R/model/layers.py:1634-1693)
+ *   out[b,f,:] = table[tokens[b,f] + offsets[f], :], except
+ *       f == 0 and tokens[b,0] >= n_users  ->  oov_user_rows[user_rank[b], :]
+ *       f == 1 and tokens[b,1] >= n_items  ->  oov_item_rows[item_rank[b], :]
+ *   (rank = number of OOV users / items before row b; the rows come from the plugin's
+ *   embed_*_ids or from the OOV bucket tables via the mapper, as in the reference).
+ *   sum_fields != 0: the first-order form, out[b,:] = sum_f of those rows in field order ([B,D]).
+ *   tokens i64[B,nf]  offsets i64[nf]  table f32[T,D]  out f32[B,nf,D] or f32[B,D]              */
+int mi_oov_token_fields_embed(const int64_t* tokens, int64_t B, int64_t nf, const int64_t* offsets,
+                              const float* table, int64_t T, int64_t D, int64_t n_users, int64_t n_items,
+                              const float* oov_user_rows, const int64_t* user_rank, int64_t n_oov_users,
+                              const float* oov_item_rows, const int64_t* item_rank, int64_t n_oov_items,
+                              int sum_fields, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * mean / zero: MeanEmbedder (R/inductive/mean_embedder.py:41-87), ZeroEmbedder (zero_embedder.py:36-60)
  *   mi_oov_col_mean      : mean[d] = (1/N) sum_n W[n,d]   (two-pass, deterministic:

@@ -164,6 +164,22 @@ def splice_rows(ids, table, oov_rows):
     return out
 
 
+def token_fields_embed(tokens, offsets, table, n_users, n_items, oov_user_rows, oov_item_rows, sum_fields=False):
+    tokens, offsets, table = _i64(tokens), _i64(offsets), _f32(table)
+    B, nf = tokens.shape
+    T, D = table.shape
+    ou, oi = tokens[:, 0] >= n_users, tokens[:, 1] >= n_items
+    ru, ri = _i64(np.cumsum(ou) - ou), _i64(np.cumsum(oi) - oi)
+    oov_user_rows = _f32(oov_user_rows).reshape(-1, D)
+    oov_item_rows = _f32(oov_item_rows).reshape(-1, D)
+    out = np.empty((B, D) if sum_fields else (B, nf, D), np.float32)
+    lib().oov_token_fields_embed(_p(tokens), _c(B), _c(nf), _p(offsets), _p(table), _c(T), _c(D), _c(n_users),
+                                 _c(n_items), _p(oov_user_rows), _p(ru), _c(oov_user_rows.shape[0]),
+                                 _p(oov_item_rows), _p(ri), _c(oov_item_rows.shape[0]),
+                                 ctypes.c_int(1 if sum_fields else 0), _p(out))
+    return out
+
+
 def col_mean(W):
     W = _f32(W)
     mean = np.empty((W.shape[1],), np.float32)
