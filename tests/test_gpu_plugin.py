@@ -265,3 +265,28 @@ def test_full_size_properties(mi, dev):
     oov = mapped[ids >= N // 2]
     assert int(oov.min()) >= N // 2 and int(oov.max()) < N // 2 + 1000
     assert torch.equal(ops.mapper_map(mapped, "3round", N // 2 + 1000, 7), mapped)
+
+
+def test_config4_slsh_wide_rows(mi, dev):
+    """BASELINE config 4 shape on ONE GPU (the 77 GB of the 100 M-row case fit 288 GB HBM, so the table
+    is replicated, not sharded; here 20 M rows keep the test short): slsh with 128-d rows gathered from
+    a catalogue-sized bucket table.  Size-independent properties: bucket id == (bits_req + popcount) %
+    n_buckets, output row == bucket row bit for bit, determinism, permutation equivariance."""
+    from mi_oov import ops
+    g = torch.Generator(device=dev).manual_seed(1)
+    N, B, F, D = 20_000_000, 65536, 64, 128
+    feat = torch.randn((N, F), generator=g, device=dev)
+    table = torch.randn((N, D), generator=g, device=dev)
+    H = int(np.ceil(np.log2(N)))  # 25 planes
+    planes = torch.randn((H, F), generator=g, device=dev)
+    ids = torch.randint(0, N, (B,), generator=g, device=dev)
+    idx = ops.slsh_index(ids, feat, planes, N)
+    pop = ops.lsh_bits(ids, feat, planes).sum(1).long()
+    assert torch.equal(idx, (H + pop) % N)
+    out = ops.slsh_embed(ids, feat, planes, table)
+    assert torch.equal(out, table[idx])
+    assert torch.equal(out, ops.slsh_embed(ids, feat, planes, table))
+    perm = torch.randperm(B, generator=g, device=dev)
+    assert torch.equal(ops.slsh_embed(ids[perm], feat, planes, table), out[perm])
+    # the reference's popcount quirk: only bits_req + 1 distinct buckets are reachable
+    assert idx.min() >= H and idx.max() <= 2 * H
