@@ -1,0 +1,283 @@
+"""Minimal end-to-end driver behind the reference's `run_recbole.py` command line (S/run_recbole.py:202-266).
+
+SCOPE.  RecBole's config / data / trainer / evaluator layers are out of scope of this build
+(SURVEY.md section 2.1); what the north star asks to keep is the ENTRY: the same `--key=value` flags
+driving the inductive path end to end.  This module therefore implements only the minimum around the
+kernels, deliberately simplified and documented as such:
+
+  * atomic-file loader (`<name>.inter/.user/.item`, `field:type` headers, token ids remapped with 0 =
+    padding like RecBole) -> feature tables the embedders consume;
+  * an inductive split: the last `--oov_fraction` of the remapped user / item ids are out of
+    vocabulary (no embedding rows), 10 % of the interactions are held out for testing;
+  * BPR training with Adam and uniform negatives; `--train_oov` adds the reference's OOV augmentation
+    (R/trainer/trainer.py:1654-1667,1748-1759: a share of each batch is re-issued with `oov_prime_pad`
+    added to the user and/or item id, and entries are zeroed at `oov_feature_mask_rate`);
+  * evaluation in the reference driver's mode `uni250` (S/run_recbole.py:214-221): every held-out
+    positive is ranked against 250 uniformly drawn items through `model.predict`, i.e. through the fused
+    lookup + score kernels; Recall/MRR/NDCG/Hit@k reported overall and for old/new users and items.
+
+Everything numeric on the path (lookups, plugin, scoring) runs on libmi_oov; torch provides autograd,
+the optimiser and the host-side sampling.
+"""
+import json
+import math
+import os
+import random
+import sys
+import time
+
+import numpy as np
+import torch
+
+from .embedders import FeatureTable
+from .factory import get_inductive_embedder, get_inductive_mapper
+from .model import BPR
+
+
+# ---- command line: `--k=v` typed, bare `--k` -> True (S/utils/parse.py:44-61) --------------------------
+def _convert(s):
+    if s.isnumeric():
+        return int(s)
+    try:
+        return float(s)
+    except ValueError:
+        pass
+    if s.lower() in ("true", "false"):
+        return s.lower() == "true"
+    if s.startswith("[") and s.endswith("]"):
+        inner = s[1:-1]
+        return [_convert(x) for x in inner.split(",")] if inner else []
+    return s
+
+
+def custom_parse_args(argv=None):
+    out = {}
+    for arg in (sys.argv if argv is None else argv):
+        if not arg.startswith("--"):
+            continue
+        pieces = arg[2:].split("=", 1)
+        out[pieces[0]] = True if len(pieces) == 1 else _convert(pieces[1])
+    return out
+
+
+class Config(dict):
+    """dict whose missing keys read as None, like recbole's Config (R/config/configurator.py:583-584)."""
+
+    def __getitem__(self, k):
+        return self.get(k, None)
+
+
+DEFAULTS = dict(  # R/properties/overall.yaml:59-119 and the driver's own settings (S/run_recbole.py:205-229)
+    embedding_size=64, train_batch_size=2048, eval_batch_size=100000, learning_rate=1e-3, epochs=5, seed=2020,
+    oov_train_ratio=0.2, oov_feature_mask_rate=0.2, oov_prime_pad=112062759511, oov_hash_function="3round",
+    oov_only_epoch=True, oov_freeze_embedding=False, dhe_num_hashes=128, dhe_layer_size=512,
+    oov_knn_num_neighbors=2, oov_normalization_type="per-feature", topk=[10, 20], oov_fraction=0.2,
+    data_path="dataset", USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", eval_negatives=250)
+
+
+# ---- atomic files ---------------------------------------------------------------------------------------
+def _read_atomic(path):
+    with open(path) as f:
+        header = f.readline().rstrip("\n").split("\t")
+        names, types = zip(*(h.split(":") for h in header))
+        cols = [[] for _ in names]
+        for line in f:
+            for c, v in zip(cols, line.rstrip("\n").split("\t")):
+                c.append(v)
+    return list(names), list(types), cols
+
+
+def _remap(values):
+    """token -> id with 0 reserved for padding (RecBole's [PAD]); ids follow sorted token order."""
+    vocab = {t: i + 1 for i, t in enumerate(sorted(set(values)))}
+    return vocab
+
+
+class AtomicDataset:
+    def __init__(self, name, data_path, user_field="user_id", item_field="item_id"):
+        root = os.path.join(data_path, name)
+        inames, _, icols = _read_atomic(os.path.join(root, f"{name}.inter"))
+        users_raw, items_raw = icols[inames.index(user_field)], icols[inames.index(item_field)]
+        self.uvocab, self.ivocab = _remap(users_raw), _remap(items_raw)
+        self.user_num, self.item_num = len(self.uvocab) + 1, len(self.ivocab) + 1
+        self.inter_user = np.array([self.uvocab[u] for u in users_raw], dtype=np.int64)
+        self.inter_item = np.array([self.ivocab[i] for i in items_raw], dtype=np.int64)
+        self.user_feat = self._features(os.path.join(root, f"{name}.user"), user_field, self.uvocab, self.user_num)
+        self.item_feat = self._features(os.path.join(root, f"{name}.item"), item_field, self.ivocab, self.item_num)
+
+    @staticmethod
+    def _features(path, id_field, vocab, n):
+        cols = {id_field: torch.arange(n)}
+        if not os.path.exists(path):
+            return FeatureTable(cols)
+        names, types, raw = _read_atomic(path)
+        rows = [vocab.get(t, 0) for t in raw[names.index(id_field)]]
+        for name, typ, vals in zip(names, types, raw):
+            if name == id_field:
+                continue
+            if typ == "float":
+                t = torch.zeros(n)
+                t[rows] = torch.tensor([float(v) if v else 0.0 for v in vals])
+            elif typ == "token":
+                tv = _remap(vals)
+                t = torch.zeros(n, dtype=torch.int64)
+                t[rows] = torch.tensor([tv[v] for v in vals])
+            elif typ in ("token_seq", "float_seq"):
+                seqs = [v.split(" ") if v else [] for v in vals]
+                width = max(1, max(len(s) for s in seqs))
+                if typ == "token_seq":
+                    tv = _remap([x for s in seqs for x in s])
+                    t = torch.zeros((n, width), dtype=torch.int64)
+                    for r, s in zip(rows, seqs):
+                        t[r, :len(s)] = torch.tensor([tv[x] for x in s], dtype=torch.int64)
+                else:
+                    t = torch.zeros((n, width))
+                    for r, s in zip(rows, seqs):
+                        t[r, :len(s)] = torch.tensor([float(x) for x in s])
+            else:
+                continue
+            cols[name] = t
+        return FeatureTable(cols)
+
+    def get_user_feature(self):
+        return self.user_feat
+
+    def get_item_feature(self):
+        return self.item_feat
+
+
+class _VocabView:
+    """What the model sees as `dataset`: the in-vocabulary sizes."""
+
+    def __init__(self, n_users, n_items, user_field, item_field):
+        self._n = {user_field: n_users, item_field: n_items}
+
+    def num(self, field):
+        return self._n[field]
+
+
+# ---- OOV augmentation (R/trainer/trainer.py:1654-1667, 1748-1759) ----------------------------------------
+def transform_interaction_oov(batch, cfg, user_key, item_key):
+    option = random.choice([0, 1, 2])
+    if option in (0, 2):
+        batch[item_key] = batch[item_key] + cfg["oov_prime_pad"]
+    if option in (1, 2):
+        batch[user_key] = batch[user_key] + cfg["oov_prime_pad"]
+    rate = cfg["oov_feature_mask_rate"]
+    if rate and rate > 0:
+        for k in batch:
+            mask = torch.rand(batch[k].shape, device=batch[k].device) < rate
+            batch[k] = batch[k].masked_fill(mask, 0)
+    return batch
+
+
+def augment_with_oov(batch, cfg, user_key, item_key):
+    n = len(batch[user_key])
+    sel = torch.rand(n, device=batch[user_key].device) < cfg["oov_train_ratio"]
+    extra = transform_interaction_oov({k: v[sel] for k, v in batch.items()}, cfg, user_key, item_key)
+    perm = torch.randperm(n + int(sel.sum()), device=sel.device)
+    return {k: torch.cat((batch[k], extra[k]))[perm] for k in batch}
+
+
+# ---- metrics for one positive ranked against sampled negatives ---------------------------------------------
+def rank_metrics(rank, topk):
+    """rank: int64[P], 0 = the positive scored highest.  Single-positive forms of RecBole's metrics."""
+    out = {}
+    for k in topk:
+        hit = (rank < k).float()
+        out[f"recall@{k}"] = hit.mean().item()
+        out[f"hit@{k}"] = hit.mean().item()
+        out[f"mrr@{k}"] = (hit / (rank.float() + 1)).mean().item()
+        out[f"ndcg@{k}"] = (hit / torch.log2(rank.float() + 2)).mean().item()
+    return out
+
+
+def evaluate(model, users, items, tot_items, cfg, n_users, n_items, device, gen):
+    """uni250: each (user, positive) row followed by its negatives, scored through model.predict."""
+    ukey, ikey, nneg = cfg["USER_ID_FIELD"], cfg["ITEM_ID_FIELD"], cfg["eval_negatives"]
+    per = max(1, cfg["eval_batch_size"] // (nneg + 1))
+    ranks = []
+    with torch.no_grad():
+        for lo in range(0, len(users), per):
+            u, pos = users[lo:lo + per], items[lo:lo + per]
+            neg = torch.randint(1, tot_items, (len(u), nneg), generator=gen, device=device)
+            cand = torch.cat((pos[:, None], neg), dim=1)
+            scores = model.predict({ukey: u[:, None].expand_as(cand).reshape(-1), ikey: cand.reshape(-1)})
+            scores = scores.view(len(u), nneg + 1)
+            scores = torch.nan_to_num(scores, nan=-float("inf"))  # all-zero lsh codes embed to NaN
+            ranks.append((scores[:, 1:] > scores[:, :1]).sum(1))
+    rank = torch.cat(ranks)
+    res = {"overall": rank_metrics(rank, cfg["topk"])}
+    for name, mask in (("old_users", users < n_users), ("new_users", users >= n_users),
+                       ("old_items", items < n_items), ("new_items", items >= n_items)):
+        if mask.any():
+            res[name] = rank_metrics(rank[mask], cfg["topk"])
+    return res
+
+
+def run(args):
+    cfg = Config({**DEFAULTS, **args})
+    if cfg["model"] not in (None, "BPR"):
+        raise NotImplementedError(f"model {cfg['model']}: only BPR's lookup/scoring path is built (SURVEY.md section 2.1)")
+    if not torch.cuda.is_available():
+        raise RuntimeError("run_recbole needs an MI355X (ROCm device): the path has no CPU fallback")
+    device = torch.device("cuda", int(cfg["gpu_id"] or 0))
+    cfg["device"] = device
+    seed = int(cfg["seed"])
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    ukey, ikey = cfg["USER_ID_FIELD"], cfg["ITEM_ID_FIELD"]
+    ds = AtomicDataset(cfg["dataset"], cfg["data_path"], ukey, ikey)
+    n_users = max(2, int(ds.user_num * (1 - cfg["oov_fraction"])))
+    n_items = max(2, int(ds.item_num * (1 - cfg["oov_fraction"])))
+    rng = np.random.default_rng(seed)
+    is_test = rng.random(len(ds.inter_user)) < 0.1
+    tu = torch.from_numpy(ds.inter_user[~is_test]).to(device)
+    ti = torch.from_numpy(ds.inter_item[~is_test]).to(device)
+    eu = torch.from_numpy(ds.inter_user[is_test]).to(device)
+    ei = torch.from_numpy(ds.inter_item[is_test]).to(device)
+
+    embedder = get_inductive_embedder(cfg, ds, user_num=n_users, item_num=n_items)
+    mapper = get_inductive_mapper(cfg, ds, user_num=n_users, item_num=n_items)
+    model = BPR(cfg, _VocabView(n_users, n_items, ukey, ikey), mapper, embedder).to(device)
+    opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg["learning_rate"])
+    gen = torch.Generator(device=device).manual_seed(seed)
+    print(f"dataset {cfg['dataset']}: {ds.user_num} users ({n_users} in vocabulary), {ds.item_num} items "
+          f"({n_items} in vocabulary), {len(tu)} train / {len(eu)} test interactions; embedder "
+          f"{type(embedder).__name__ if embedder else None}, mapper {type(mapper).__name__ if mapper else None}")
+
+    bs = int(cfg["train_batch_size"])
+    for epoch in range(int(cfg["epochs"])):
+        t0, total, nb = time.time(), 0.0, 0
+        perm = torch.randperm(len(tu), generator=gen, device=device)
+        oov_pass = bool(cfg["train_oov"]) and bool(cfg["oov_only_epoch"])
+        for phase in (("iv", "oov") if oov_pass else ("iv",)):
+            if phase == "oov":
+                model.set_oov_train()
+            for lo in range(0, len(perm), bs):
+                idx = perm[lo:lo + bs]
+                batch = {ukey: tu[idx], ikey: ti[idx],
+                         cfg["NEG_PREFIX"] + ikey: torch.randint(1, ds.item_num, (len(idx),), generator=gen, device=device)}
+                if phase == "oov":
+                    if random.random() > cfg["oov_train_ratio"]:
+                        continue
+                    batch = transform_interaction_oov(batch, cfg, ukey, ikey)
+                elif cfg["train_oov"] and not cfg["oov_only_epoch"]:
+                    model.set_oov_train(no_freeze=True)
+                    batch = augment_with_oov(batch, cfg, ukey, ikey)
+                loss = model.calculate_loss(batch)
+                if not torch.isfinite(loss):  # NaN rows of all-zero lsh codes (reference: _check_nan aborts)
+                    continue
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                total, nb = total + loss.item(), nb + 1
+            if phase == "oov":
+                model.set_oov_eval()
+        print(f"epoch {epoch}: loss {total / max(1, nb):.4f} over {nb} batches, {time.time() - t0:.2f}s")
+    model.eval()
+    model.set_oov_eval()
+    results = evaluate(model, eu, ei, ds.item_num, cfg, n_users, n_items, device, gen)
+    print(json.dumps(results))
+    return results, model
