@@ -27,6 +27,10 @@ _SIGNATURES = {
     "mi_oov_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "mi_oov_last_hip_error": (ctypes.c_int, []),
     "mi_oov_lsh_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
+    "mi_oov_lsh_backward_workspace": (_i64, [_i64, _i64, _i64]),
+    "mi_oov_lsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "mi_oov_slsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "mi_oov_scatter_add_rows": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "mi_oov_lsh_embed_score": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_lookup": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "mi_oov_lsh_lookup_score": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp,

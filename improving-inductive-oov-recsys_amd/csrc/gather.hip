@@ -197,6 +197,88 @@ __global__ __launch_bounds__(kBlock) void rowdot_kernel(const float* __restrict_
   }
 }
 
+// ---- lsh backward: gradient of (bits @ W) / popcount with respect to the bucket table W ----------
+// grad_W[h, d] = sum_b bits[b,h] * (g[b,d] / cnt[b])  -- what autograd derives for lsh_embedder.py:158,178
+// (a cnt = 0 row contributes 0 * (g/0) = NaN, as in the reference, whose trainer then aborts on the NaN
+// loss).  Deterministic two-pass reduction over the batch with the row partitioning of col_mean:
+// P <= 1024 partitions, 16 row-groups each (rows gr, gr+16, ... in order, then the 16 group sums in
+// order), the P partials dealt to 64 lanes and combined by a stride-halving tree.
+constexpr int kBwdH = 8;  // planes per pass over the batch
+
+// ONEHOT: the weights are (idx[b] == h) instead of bits[b,h]/cnt[b] -- the slsh backward (one bucket row
+// per lookup, single_lsh_embedder.py:87,109) when the bucket table is small.
+template <bool VEC, bool ONEHOT>
+__global__ __launch_bounds__(kBlock) void lsh_bwd_partial_kernel(const uint8_t* __restrict__ bits,
+                                                                 const int64_t* __restrict__ idx,
+                                                                 const float* __restrict__ g, int64_t B, int64_t H,
+                                                                 int64_t D, int64_t h0, float* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [16][kBwdH][DP]
+  const int gr = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  const int DP = dchunks * 64;
+  const int64_t RP = col_part_rows(B);
+  const int64_t P = (B + RP - 1) / RP;
+  const int nh = static_cast<int>((H - h0) < kBwdH ? (H - h0) : kBwdH);
+  for (int64_t part = blockIdx.x; part < P; part += gridDim.x) {
+    const int64_t r0 = part * RP;
+    const int64_t r1 = (r0 + RP < B) ? r0 + RP : B;
+    for (int c = 0; c < dchunks; ++c) {
+      const int e = (c * 16 + l16) * 4;
+      float4 acc[kBwdH];
+#pragma unroll
+      for (int j = 0; j < kBwdH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int64_t r = r0 + gr; r < r1; r += 16) {
+        float4 t = load4<VEC>(g + r * D, e, D);
+        int64_t which = -1;
+        if constexpr (ONEHOT) {
+          which = idx[r] - h0;
+        } else {
+          float cnt = 0.f;
+          for (int64_t h = 0; h < H; ++h) cnt = cnt + static_cast<float>(bits[r * H + h]);
+          t.x = t.x / cnt; t.y = t.y / cnt; t.z = t.z / cnt; t.w = t.w / cnt;
+        }
+#pragma unroll
+        for (int j = 0; j < kBwdH; ++j) {
+          if (j < nh) {
+            float bit;
+            if constexpr (ONEHOT) bit = (which == j) ? 1.f : 0.f;
+            else bit = static_cast<float>(bits[r * H + h0 + j]);
+            acc[j].x = __builtin_fmaf(bit, t.x, acc[j].x);
+            acc[j].y = __builtin_fmaf(bit, t.y, acc[j].y);
+            acc[j].z = __builtin_fmaf(bit, t.z, acc[j].z);
+            acc[j].w = __builtin_fmaf(bit, t.w, acc[j].w);
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < kBwdH; ++j) *reinterpret_cast<float4*>(red + (gr * kBwdH + j) * DP + e) = acc[j];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nh * D; i += kBlock) {
+      const int j = i / static_cast<int>(D), d = i % static_cast<int>(D);
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) s += red[(q * kBwdH + j) * DP + d];
+      partial[(part * kBwdH + j) * D + d] = s;
+    }
+    __syncthreads();
+  }
+}
+
+// one wave per (plane, column)
+__global__ __launch_bounds__(kBlock) void lsh_bwd_final_kernel(const float* __restrict__ partial, int64_t P, int nh,
+                                                               int64_t D, int64_t h0, float* __restrict__ gradW) {
+  const int lane = threadIdx.x & 63;
+  const int64_t col = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (col >= nh * D) return;
+  const int64_t j = col / D, d = col % D;
+  float s = 0.f;
+  for (int64_t p = lane; p < P; p += 64) s += partial[(p * kBwdH + j) * D + d];
+#pragma unroll
+  for (int stride = 32; stride >= 1; stride >>= 1) s = s + __shfl_xor(s, stride, 64);
+  if (lane == 0) gradW[(h0 + j) * D + d] = s;
+}
+
 // ---- context models: fused-table token gather with the user/item OOV splice ---------------------
 // InductiveContextRecommender.embed_token_fields (abstract_recommender.py:794-842) and
 // InductiveFMFirstOrderLinear.embed_token_fields (layers.py:1634-1693): row (b, f) is
@@ -283,6 +365,99 @@ __global__ __launch_bounds__(kBlock) void token_fields_sum_kernel(TokenArgs a) {
 }  // namespace mi_oov
 
 using namespace mi_oov;
+
+extern "C" int64_t mi_oov_lsh_backward_workspace(int64_t B, int64_t H, int64_t D) {
+  if (B <= 0 || H <= 0 || D <= 0) return 0;
+  const int64_t RP = col_part_rows(B);
+  return ((B + RP - 1) / RP) * kBwdH * D;  // floats
+}
+
+// rows of `g` added into out[idx[m]] with hardware float atomics (order not fixed); idx outside [0,N) skipped
+template <bool VEC>
+__global__ __launch_bounds__(kBlock) void scatter_add_kernel(const int64_t* __restrict__ idx, int64_t M,
+                                                             const float* __restrict__ g, int64_t N, int64_t D,
+                                                             float* __restrict__ out) {
+  const int l16 = threadIdx.x & 15;
+  const int64_t per = kBlock / 16;
+  for (int64_t m = static_cast<int64_t>(blockIdx.x) * per + (threadIdx.x >> 4); m < M; m += static_cast<int64_t>(gridDim.x) * per) {
+    const int64_t r = idx[m];
+    if (r < 0 || r >= N) continue;
+    for (int64_t e = l16 * 4; e < D; e += 64) {
+      const float4 v = load4<VEC>(g + m * D, e, D);
+      float* o = out + r * D + e;
+      unsafeAtomicAdd(o, v.x);
+      if (e + 1 < D) unsafeAtomicAdd(o + 1, v.y);
+      if (e + 2 < D) unsafeAtomicAdd(o + 2, v.z);
+      if (e + 3 < D) unsafeAtomicAdd(o + 3, v.w);
+    }
+  }
+}
+
+extern "C" int mi_oov_scatter_add_rows(const int64_t* idx, int64_t M, const float* g, int64_t N, int64_t D, float* out,
+                                       void* stream) {
+  if (M < 0 || N < 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (M == 0) return MI_OOV_OK;
+  if (!idx || !g || !out) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const bool vec = (D % 4 == 0) && aligned16(g);
+  const unsigned grid = grid_for(M, kBlock / 16);
+  if (vec) hipLaunchKernelGGL(scatter_add_kernel<true>, dim3(grid), dim3(kBlock), 0, st, idx, M, g, N, D, out);
+  else hipLaunchKernelGGL(scatter_add_kernel<false>, dim3(grid), dim3(kBlock), 0, st, idx, M, g, N, D, out);
+  return check_launch();
+}
+
+static int run_lsh_bwd(const uint8_t* bits, const int64_t* idx, const float* grad_out, int64_t B, int64_t H, int64_t D,
+                       float* grad_buckets, float* workspace, hipStream_t st);
+
+extern "C" int mi_oov_slsh_embed_backward(const int64_t* idx, const float* grad_out, int64_t B, int64_t n_buckets,
+                                          int64_t D, float* grad_buckets, float* workspace, void* stream) {
+  if (B < 0 || n_buckets <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (!grad_buckets) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (n_buckets <= 64 && D <= 256) return run_lsh_bwd(nullptr, idx, grad_out, B, n_buckets, D, grad_buckets, workspace, st);
+  if (hipMemsetAsync(grad_buckets, 0, static_cast<size_t>(n_buckets * D) * sizeof(float), st) != hipSuccess) {
+    check_launch();
+    return MI_OOV_ERR_LAUNCH;
+  }
+  return mi_oov_scatter_add_rows(idx, B, grad_out, n_buckets, D, grad_buckets, stream);
+}
+
+extern "C" int mi_oov_lsh_embed_backward(const uint8_t* bits, const float* grad_out, int64_t B, int64_t H, int64_t D,
+                                         float* grad_buckets, float* workspace, void* stream) {
+  return run_lsh_bwd(bits, nullptr, grad_out, B, H, D, grad_buckets, workspace, static_cast<hipStream_t>(stream));
+}
+
+static int run_lsh_bwd(const uint8_t* bits, const int64_t* idx, const float* grad_out, int64_t B, int64_t H, int64_t D,
+                       float* grad_buckets, float* workspace, hipStream_t st) {
+  if (B < 0 || H <= 0 || D <= 0 || D > 256) return MI_OOV_ERR_SHAPE;
+  if (!grad_buckets) return MI_OOV_ERR_NULL;
+  if (B == 0) {
+    if (hipMemsetAsync(grad_buckets, 0, static_cast<size_t>(H * D) * sizeof(float), st) != hipSuccess) {
+      check_launch();
+      return MI_OOV_ERR_LAUNCH;
+    }
+    return MI_OOV_OK;
+  }
+  if ((!bits && !idx) || !grad_out || !workspace) return MI_OOV_ERR_NULL;
+  const int64_t RP = col_part_rows(B);
+  const int64_t P = (B + RP - 1) / RP;
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  const size_t lds = static_cast<size_t>(16) * kBwdH * dchunks * 64 * sizeof(float);
+  const bool vec = (D % 4 == 0) && aligned16(grad_out);
+  for (int64_t h0 = 0; h0 < H; h0 += kBwdH) {
+    const int nh = static_cast<int>((H - h0) < kBwdH ? (H - h0) : kBwdH);
+    auto k = idx ? (vec ? lsh_bwd_partial_kernel<true, true> : lsh_bwd_partial_kernel<false, true>)
+                 : (vec ? lsh_bwd_partial_kernel<true, false> : lsh_bwd_partial_kernel<false, false>);
+    if (int rc = set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(P)), dim3(kBlock), lds, st, bits, idx, grad_out, B, H, D, h0, workspace);
+    if (int rc = check_launch()) return rc;
+    const int cols = nh * static_cast<int>(D);
+    hipLaunchKernelGGL(lsh_bwd_final_kernel, dim3((cols + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, st, workspace,
+                       P, nh, D, h0, grad_buckets);
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
+}
 
 extern "C" int mi_oov_token_fields_embed(const int64_t* tokens, int64_t B, int64_t nf, const int64_t* offsets,
                                          const float* table, int64_t T, int64_t D, int64_t n_users, int64_t n_items,

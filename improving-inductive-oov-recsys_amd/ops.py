@@ -64,9 +64,24 @@ class _LshEmbed(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (bits,) = ctx.saved_tensors
-        w = bits.to(torch.float32)
-        w = w / w.sum(dim=1, keepdim=True)  # d/dW of (bits @ W) / bits.sum(1); 0/0 rows stay NaN
-        return None, None, None, w.t() @ g.contiguous()
+        return None, None, None, lsh_embed_backward(bits, g)
+
+
+def lsh_embed_backward(bits, grad_out):
+    """d/dW of (bits @ W) / bits.sum(1): grad_W = bits^T @ (g / popcount); a popcount-0 row gives NaN like the
+    reference's autograd.  Deterministic two-pass kernel (mi_oov_lsh_embed_backward)."""
+    bits = C.dev_tensor(bits, torch.uint8, "bits")
+    g = _f32(grad_out, "grad_out")
+    (B, H), D = bits.shape, g.shape[1]
+    if g.shape[0] != B:
+        raise ValueError(f"grad_out has {g.shape[0]} rows, bits {B}")
+    lib = C.lib()
+    ws = torch.empty((max(int(lib.mi_oov_lsh_backward_workspace(B, H, D)), 1),), dtype=torch.float32, device=g.device)
+    out = torch.empty((H, D), dtype=torch.float32, device=g.device)
+    with C.on_device(g):
+        rc = lib.mi_oov_lsh_embed_backward(C.ptr(bits), C.ptr(g), B, H, D, C.ptr(out), C.ptr(ws), C.stream_of(g))
+    C.check(rc, "mi_oov_lsh_embed_backward")
+    return out
 
 
 def lsh_embed(ids, feat, planes, buckets):
@@ -158,9 +173,36 @@ class _SlshEmbed(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (idx,) = ctx.saved_tensors
-        gw = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
-        gw.index_add_(0, idx, g.contiguous())
-        return None, None, None, gw
+        return None, None, None, slsh_embed_backward(idx, g, ctx.shape[0])
+
+
+def slsh_embed_backward(idx, grad_out, n_buckets):
+    """grad of buckets[idx] w.r.t. buckets (mi_oov_slsh_embed_backward): deterministic for n_buckets <= 64."""
+    idx, g = _ids(idx, "idx"), _f32(grad_out, "grad_out")
+    B, D = g.shape
+    lib = C.lib()
+    ws = torch.empty((max(int(lib.mi_oov_lsh_backward_workspace(B, min(n_buckets, 64), D)), 1),), dtype=torch.float32,
+                     device=g.device)
+    out = torch.empty((n_buckets, D), dtype=torch.float32, device=g.device)
+    with C.on_device(g):
+        rc = lib.mi_oov_slsh_embed_backward(C.ptr(idx), C.ptr(g), B, n_buckets, D, C.ptr(out), C.ptr(ws), C.stream_of(g))
+    C.check(rc, "mi_oov_slsh_embed_backward")
+    return out
+
+
+def scatter_add_rows(idx, g, n_rows, out=None):
+    """out[idx[m]] += g[m] (float atomics; entries of idx outside [0, n_rows) are skipped) -- the backward of the
+    row gathers.  Returns `out` (zeros[n_rows, D] when not given)."""
+    idx, g = _ids(idx, "idx"), _f32(g, "g")
+    M, D = g.shape
+    if idx.numel() != M:
+        raise ValueError(f"idx has {idx.numel()} entries, g {M} rows")
+    if out is None:
+        out = torch.zeros((n_rows, D), dtype=torch.float32, device=g.device)
+    with C.on_device(g):
+        rc = C.lib().mi_oov_scatter_add_rows(C.ptr(idx), M, C.ptr(g), n_rows, D, C.ptr(out), C.stream_of(g))
+    C.check(rc, "mi_oov_scatter_add_rows")
+    return out
 
 
 def slsh_embed(ids, feat, planes, buckets):
@@ -228,9 +270,7 @@ class _GatherMean(torch.autograd.Function):
         M, g = idx.numel(), ctx.g
         grp = torch.arange(M, device=idx.device) // g
         cnt = torch.bincount(grp, minlength=grad.shape[0]).to(grad.dtype)
-        gw = torch.zeros(ctx.shape, dtype=grad.dtype, device=grad.device)
-        gw.index_add_(0, idx, (grad / cnt[:, None])[grp])
-        return None, gw, None
+        return None, scatter_add_rows(idx, (grad / cnt[:, None])[grp], ctx.shape[0]), None
 
 
 def gather_mean(idx, W, g=2):
@@ -260,9 +300,7 @@ class _GatherRows(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (ids,) = ctx.saved_tensors
-        gw = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
-        gw.index_add_(0, ids, g.contiguous())
-        return None, gw
+        return None, scatter_add_rows(ids, g, ctx.shape[0])
 
 
 def gather_rows(ids, W):
@@ -293,12 +331,8 @@ class _Splice(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         ids, rank = ctx.saved_tensors
-        g = g.contiguous()
-        iv = ids < ctx.tshape[0]
-        gt = torch.zeros(ctx.tshape, dtype=g.dtype, device=g.device)
-        gt.index_add_(0, ids[iv], g[iv])
-        go = torch.zeros(ctx.oshape, dtype=g.dtype, device=g.device)
-        go.index_add_(0, rank[~iv], g[~iv])
+        gt = scatter_add_rows(ids, g, ctx.tshape[0])  # ids >= n_vocab are skipped by the kernel
+        go = scatter_add_rows(torch.where(ids < ctx.tshape[0], -1, rank), g, ctx.oshape[0])
         return None, None, gt, go
 
 

@@ -67,6 +67,28 @@ int mi_oov_lsh_embed(const int64_t* ids, int64_t B,
                      const float* buckets, int64_t D,
                      float* out, uint8_t* bits, void* stream);
 
+/* Backward of mi_oov_lsh_embed with respect to the bucket table (the only input of the lsh plugin that
+ * carries a gradient: planes are read through `.data`, lsh_embedder.py:129):
+ *     grad_buckets[h,d] = sum_b bits[b,h] * (grad_out[b,d] / popcount(bits[b,:]))
+ *   bits u8[B,H] as returned by the forward; grad_out f32[B,D]; grad_buckets f32[H,D] (overwritten);
+ *   workspace f32[mi_oov_lsh_backward_workspace(B,H,D)].  Deterministic (fixed two-pass order).      */
+int64_t mi_oov_lsh_backward_workspace(int64_t B, int64_t H, int64_t D); /* number of floats */
+int mi_oov_lsh_embed_backward(const uint8_t* bits, const float* grad_out, int64_t B, int64_t H, int64_t D,
+                              float* grad_buckets, float* workspace, void* stream);
+
+/* Backward of mi_oov_slsh_embed w.r.t. the bucket table: grad_buckets[idx[b],:] += grad_out[b,:]
+ * (autograd of the `.weight[idx]` gather, single_lsh_embedder.py:87,109).  grad_buckets f32[n_buckets,D]
+ * is overwritten.  n_buckets <= 64: the deterministic two-pass reduction of the lsh backward (workspace
+ * f32[mi_oov_lsh_backward_workspace(B,n_buckets,D)]); larger tables: memset + float atomics.            */
+int mi_oov_slsh_embed_backward(const int64_t* idx, const float* grad_out, int64_t B, int64_t n_buckets, int64_t D,
+                               float* grad_buckets, float* workspace, void* stream);
+
+/* out[idx[m],:] += g[m,:] with hardware float atomics (summation order not fixed): the backward of every
+ * row gather on the path (mi_oov_gather_rows, mi_oov_splice_rows, knn's gather_mean after scaling).
+ *   idx i64[M] (entries outside [0,N) are skipped); g f32[M,D]; out f32[N,D] (accumulated into).       */
+int mi_oov_scatter_add_rows(const int64_t* idx, int64_t M, const float* g, int64_t N, int64_t D, float* out,
+                            void* stream);
+
 /* As mi_oov_lsh_embed, fused with the pairwise score of BPR.predict
  * (R/model/general_recommender/bpr.py:145-149): score[b] = sum_d other[b,d] * emb[b,d],
  * computed in canonical order with a separate multiply and add (torch.mul(...).sum(1)).

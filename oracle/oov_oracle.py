@@ -180,6 +180,16 @@ def token_fields_embed(tokens, offsets, table, n_users, n_items, oov_user_rows, 
     return out
 
 
+def lsh_embed_backward(bits, grad_out):
+    bits = np.ascontiguousarray(bits, dtype=np.uint8)
+    g = _f32(grad_out)
+    B, H = bits.shape
+    D = g.shape[1]
+    out = np.empty((H, D), np.float32)
+    lib().oov_lsh_embed_backward(_p(bits), _p(g), _c(B), _c(H), _c(D), _p(out))
+    return out
+
+
 def col_mean(W):
     W = _f32(W)
     mean = np.empty((W.shape[1],), np.float32)

@@ -1,0 +1,99 @@
+#!/usr/bin/env python3
+"""Gradient fixtures: the REAL reference's autograd through the OOV training step.
+
+    python tests/golden/make_golden_grad.py        (build container only; needs /root/reference)
+
+Writes bpr_grad.npz: for each plugin variant (lsh / slsh with 8 buckets / slsh with 200 buckets / knn /
+mapper) a reference BPR in train mode, one `calculate_loss` over a batch that mixes in-vocabulary and
+prime-padded OOV ids (bpr.py:127-143, lsh_embedder.py:153-155), and the gradient of every table.
+Ids whose lsh code is all-zero are excluded from the batch: the reference's loss is NaN for them and
+its trainer aborts (trainer.py `_check_nan`), so no gradient exists to compare.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden as mg  # noqa: E402  (installs the shims, imports the reference)
+
+import torch  # noqa: E402
+from recbole.data.interaction import Interaction  # noqa: E402
+
+PRIME_PAD = mg.PRIME_PAD
+
+
+def one_case(tag, build, n_users, n_items, n_new_u, n_new_i, D, n_ub, n_ib, seed, out):
+    uf = mg.features(n_new_u, [("a", 1, "float"), ("v", 9, "float")], seed, "user_id")
+    itf = mg.features(n_new_i, [("y", 1, "float"), ("w", 20, "float")], seed + 1, "item_id")
+    torch.manual_seed(seed + 2)
+    mapper, emb = build(uf, itf)
+    model = mg.make_bpr(n_users, n_items, D, mapper, emb, n_ub, n_ib, seed + 3)
+    model.train()
+    if emb is not None and hasattr(emb, "set_train"):
+        emb.set_train()
+    g = torch.Generator().manual_seed(seed + 4)
+    B = 300
+    users = torch.randint(1, n_new_u, (B,), generator=g)
+    pos = torch.randint(1, n_new_i, (B,), generator=g)
+    neg = torch.randint(1, n_new_i, (B,), generator=g)
+    if tag == "lsh":  # drop ids with an all-zero code (NaN rows)
+        with torch.no_grad():
+            ok_u = emb._hash_users(torch.arange(n_new_u)).sum(1) > 0
+            ok_i = emb._hash_items(torch.arange(n_new_i)).sum(1) > 0
+        keep = ok_u[users] & ok_i[pos] & ok_i[neg]
+        users, pos, neg = users[keep], pos[keep], neg[keep]
+    # the trainer adds prime_pad to the OOV ids it samples (trainer / dataloader `_transform_interaction_oov`)
+    pad = lambda ids, n: torch.where(ids >= n, ids + PRIME_PAD, ids)  # noqa: E731
+    if emb is not None:
+        u_in, p_in, n_in = pad(users, n_users), pad(pos, n_items), pad(neg, n_items)
+    else:
+        u_in, p_in, n_in = users, pos, neg
+    inter = Interaction({"user_id": u_in.clone(), "item_id": p_in.clone(), "neg_item_id": n_in.clone()})
+    loss = model.calculate_loss(inter)
+    loss.backward()
+    assert torch.isfinite(loss), tag
+    out[f"{tag}__users"], out[f"{tag}__pos"], out[f"{tag}__neg"] = mg.np_(u_in), mg.np_(p_in), mg.np_(n_in)
+    out[f"{tag}__loss"] = mg.np_(loss)
+    for name, p in model.named_parameters():
+        key = name.replace(".", "_")
+        out[f"{tag}__w__{key}"] = mg.np_(p)
+        out[f"{tag}__g__{key}"] = mg.np_(p.grad) if p.grad is not None else np.zeros((0,), np.float32)
+    if emb is not None and hasattr(emb, "user_feature_mat"):
+        out[f"{tag}__user_feat"] = np.asarray(mg.np_(emb.user_feature_mat) if torch.is_tensor(emb.user_feature_mat) else emb.user_feature_mat)
+        out[f"{tag}__item_feat"] = np.asarray(mg.np_(emb.item_feature_mat) if torch.is_tensor(emb.item_feature_mat) else emb.item_feature_mat)
+    if emb is not None and hasattr(emb, "user_lsh"):
+        out[f"{tag}__user_planes"] = mg.np_(emb.user_lsh.uniform_planes[0].data)
+        out[f"{tag}__item_planes"] = mg.np_(emb.item_lsh.uniform_planes[0].data)
+    out[f"{tag}__dims"] = np.array([n_users, n_items, n_new_u, n_new_i, D, n_ub, n_ib])
+    grads = {n: float(p.grad.abs().sum()) for n, p in model.named_parameters() if p.grad is not None}
+    print(f"{tag}: B={len(users)} loss={float(loss):.6f} |grad| = {grads}")
+
+
+def main():
+    torch.set_num_threads(4)
+    out = {}
+    n_users, n_items, n_new_u, n_new_i, D = 200, 260, 280, 360, 64
+    args = (n_users, n_items, n_new_u, n_new_i, D)
+    one_case("lsh", lambda uf, itf: (None, mg.LSHInductiveEmbedder(uf, itf, n_users, n_items, 8, 8, D, "cpu", PRIME_PAD,
+                                                                  "per-feature", mg.InductiveFeatureCache())),
+             *args, 8, 8, 700, out)
+    one_case("slsh8", lambda uf, itf: (None, mg.SingleLSHInductiveEmbedder(uf, itf, n_users, n_items, 8, 8, D, "cpu",
+                                                                         PRIME_PAD, "per-feature")),
+             *args, 8, 8, 710, out)
+    one_case("slsh200", lambda uf, itf: (None, mg.SingleLSHInductiveEmbedder(uf, itf, n_users, n_items, 200, 200, D, "cpu",
+                                                                           PRIME_PAD, "none")),
+             *args, 200, 200, 720, out)
+    one_case("knn", lambda uf, itf: (None, mg.KNNInductiveEmbedder(uf, itf, n_users, n_items, 8, 8, D, "cpu", PRIME_PAD,
+                                                                  n_neighbors=2)),
+             *args, 8, 8, 730, out)
+    one_case("mapper", lambda uf, itf: (mg.RandomOOVInductiveMapper(uf, itf, n_users, n_items, 8, 8, D, "cpu", PRIME_PAD,
+                                                                   "3round"), None),
+             *args, 8, 8, 740, out)
+    np.savez_compressed(os.path.join(HERE, "bpr_grad.npz"), **out)
+    print("bpr_grad.npz", os.path.getsize(os.path.join(HERE, "bpr_grad.npz")), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -315,3 +315,48 @@ def test_gather_splice_vs_oracle(oracle, ops, dev):
         for g in (2, 3, 5):
             got = ops.gather_mean(T(idx, dev), T(table, dev), g).cpu().numpy()
             assert bits_equal(got, oracle.gather_mean(idx, table, g))
+
+
+@pytest.mark.parametrize("B,H,D", [(1, 8, 64), (300, 8, 64), (70000, 8, 64), (5000, 12, 64), (999, 3, 22), (4097, 40, 50)])
+def test_lsh_backward_vs_oracle(B, H, D, oracle, ops, dev):
+    """grad of (bits @ W)/popcount w.r.t. W: bit-exact against the oracle (same two-pass order), within 1e-5
+    of torch autograd on the reference's op sequence (lsh_embedder.py:158,178), NaN rows as in the reference."""
+    rng = np.random.default_rng(B + H)
+    bits = (rng.random((B, H)) < 0.5).astype(np.uint8)
+    bits[bits.sum(1) == 0, 0] = 1
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    got = ops.lsh_embed_backward(T(bits, dev), T(g, dev)).cpu().numpy()
+    assert bits_equal(got, oracle.lsh_embed_backward(bits, g))
+    W = torch.zeros((H, D), requires_grad=True)
+    bt = torch.from_numpy(bits).float()
+    ((bt @ W) / bt.sum(1, keepdim=True) * torch.from_numpy(g)).sum().backward()
+    assert np.abs(got - W.grad.numpy()).max() <= RTOL * np.abs(W.grad.numpy()).max()
+    if B > 1:  # an all-zero code poisons the gradient exactly like the reference's autograd
+        bits[B // 2] = 0
+        got = ops.lsh_embed_backward(T(bits, dev), T(g, dev)).cpu().numpy()
+        assert bits_equal(got, oracle.lsh_embed_backward(bits, g)) and np.isnan(got).all()
+
+
+@pytest.mark.parametrize("B,nb,D", [(1, 8, 64), (3000, 9, 64), (70000, 64, 64), (5000, 777, 24), (4097, 65, 50)])
+def test_slsh_backward_and_scatter(B, nb, D, oracle, ops, dev):
+    rng = np.random.default_rng(B + nb)
+    idx = rng.integers(0, nb, B)
+    g = rng.standard_normal((B, D)).astype(np.float32)
+    got = ops.slsh_embed_backward(T(idx, dev), T(g, dev), nb).cpu().numpy()
+    want = np.zeros((nb, D), np.float64)
+    np.add.at(want, idx, g.astype(np.float64))
+    assert np.abs(got - want).max() <= RTOL * np.abs(want).max()
+    if nb <= 64:  # deterministic path: identical to the lsh backward on one-hot codes
+        onehot = (idx[:, None] == np.arange(nb)[None]).astype(np.uint8)
+        assert bits_equal(got, oracle.lsh_embed_backward(onehot, g))
+        assert bits_equal(got, ops.slsh_embed_backward(T(idx, dev), T(g, dev), nb).cpu().numpy())
+    # generic scatter: out-of-range entries are skipped, accumulation goes into the given tensor
+    idx2 = idx.copy()
+    idx2[::7] = nb + 5
+    idx2[1::11] = -1
+    base = rng.standard_normal((nb, D)).astype(np.float32)
+    out = ops.scatter_add_rows(T(idx2, dev), T(g, dev), nb, out=T(base, dev)).cpu().numpy()
+    keep = (idx2 >= 0) & (idx2 < nb)
+    want = base.astype(np.float64)
+    np.add.at(want, idx2[keep], g[keep].astype(np.float64))
+    assert np.abs(out - want).max() <= RTOL * np.abs(want).max()

@@ -290,3 +290,49 @@ def test_config4_slsh_wide_rows(mi, dev):
     assert torch.equal(ops.slsh_embed(ids[perm], feat, planes, table), out[perm])
     # the reference's popcount quirk: only bits_req + 1 distinct buckets are reachable
     assert idx.min() >= H and idx.max() <= 2 * H
+
+
+@pytest.mark.parametrize("tag", ["lsh", "slsh8", "slsh200", "knn", "mapper"])
+def test_bpr_training_step_grads(mi, golden, dev, tag):
+    """One OOV training step (bpr.py:127-143 with prime-padded OOV ids) against the loss and the table
+    gradients the REAL reference's autograd produced (tests/golden/make_golden_grad.py).  Every backward on
+    the path is a HIP kernel: mi_oov_lsh_embed_backward / mi_oov_slsh_embed_backward / mi_oov_scatter_add_rows."""
+    z = golden("bpr_grad.npz")
+    n_users, n_items, n_new_u, n_new_i, D, n_ub, n_ib = (int(v) for v in z[tag + "__dims"])
+    cfg = Cfg(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device=dev, embedding_size=D,
+              add_oov_buckets=True, user_oov_buckets=n_ub, item_oov_buckets=n_ib, oov_freeze_embedding=False)
+    ft_u = mi.FeatureTable({"id": torch.arange(n_new_u), "f": torch.zeros(n_new_u, 10)})
+    ft_i = mi.FeatureTable({"id": torch.arange(n_new_i), "f": torch.zeros(n_new_i, 21)})
+    mapper = emb = None
+    if tag == "lsh":
+        emb = mi.LSHInductiveEmbedder(ft_u, ft_i, n_users, n_items, n_ub, n_ib, D, dev, PRIME_PAD, "none",
+                                      mi.InductiveFeatureCache())
+    elif tag.startswith("slsh"):
+        emb = mi.SingleLSHInductiveEmbedder(ft_u, ft_i, n_users, n_items, n_ub, n_ib, D, dev, PRIME_PAD, "none")
+    elif tag == "knn":
+        emb = mi.KNNInductiveEmbedder(ft_u, ft_i, n_users, n_items, n_ub, n_ib, D, dev, PRIME_PAD, n_neighbors=2)
+    else:
+        mapper = mi.RandomOOVInductiveMapper(ft_u, ft_i, n_users, n_items, n_ub, n_ib, D, dev, PRIME_PAD, "3round")
+    if emb is not None:
+        emb.user_feature_mat, emb.item_feature_mat = T(z[tag + "__user_feat"], dev), T(z[tag + "__item_feat"], dev)
+        if hasattr(emb, "user_lsh"):
+            emb.load_state_dict({"user_lsh.uniform_planes.0": T(z[tag + "__user_planes"], dev),
+                                 "item_lsh.uniform_planes.0": T(z[tag + "__item_planes"], dev)})
+        emb.set_train()
+    bpr = mi.BPR(cfg, DS(n_users, n_items), mapper, emb).to(dev)
+    names = ["user_embedding_weight", "item_embedding_weight"]
+    names += [] if tag == "knn" else ["user_oov_buckets_weight", "item_oov_buckets_weight"]
+    with torch.no_grad():
+        for n in names:
+            getattr(bpr, n[:-len("_weight")]).weight.copy_(T(z[f"{tag}__w__{n}"], dev))
+    bpr.train()
+    loss = bpr.calculate_loss({"user_id": T(z[tag + "__users"], dev), "item_id": T(z[tag + "__pos"], dev),
+                               "neg_item_id": T(z[tag + "__neg"], dev)})
+    loss.backward()
+    assert abs(loss.item() - float(z[tag + "__loss"])) <= 1e-5 * abs(float(z[tag + "__loss"]))
+    for n in names:
+        ref = z[f"{tag}__g__{n}"]
+        got = getattr(bpr, n[:-len("_weight")]).weight.grad
+        assert got is not None and got.shape == ref.shape, n
+        err = np.abs(got.cpu().numpy() - ref).max()
+        assert err <= 1e-5 * np.abs(ref).max(), (tag, n, err, np.abs(ref).max())

@@ -140,3 +140,24 @@ def test_ref_torch_restatement(case, golden):
     emb = ref_torch.lsh_embed(t("item_ids"), t("item_feat"), t("item_planes"), t("item_buckets")).numpy()
     safe = (z["item_margin"] > 1e-5) | (z["item_margin"] == 0)
     assert rel_err(emb[safe], z["item_emb"][safe]) <= RTOL
+
+
+def test_lsh_backward_oracle_matches_autograd(oracle):
+    """The oracle's bucket-table gradient against torch autograd run on the reference's own op sequence
+    (`(bits @ W) / bits.sum(1)`, lsh_embedder.py:158,178)."""
+    import torch
+    rng = np.random.default_rng(5)
+    for B, H, D in ((1, 8, 64), (777, 8, 64), (20000, 12, 32), (100, 3, 22)):
+        bits = (rng.random((B, H)) < 0.5).astype(np.uint8)
+        bits[bits.sum(1) == 0, 0] = 1
+        g = rng.standard_normal((B, D)).astype(np.float32)
+        W = torch.zeros((H, D), requires_grad=True)
+        bt = torch.from_numpy(bits).float()
+        ((bt @ W) / bt.sum(1, keepdim=True) * torch.from_numpy(g)).sum().backward()
+        got = oracle.lsh_embed_backward(bits, g)
+        assert np.abs(got - W.grad.numpy()).max() <= 1e-5 * np.abs(W.grad.numpy()).max()
+    bits[3] = 0  # all-zero code: the reference's gradient is NaN everywhere (0 * inf)
+    W = torch.zeros((H, D), requires_grad=True)
+    bt = torch.from_numpy(bits).float()
+    ((bt @ W) / bt.sum(1, keepdim=True) * torch.from_numpy(g)).sum().backward()
+    assert torch.isnan(W.grad).all() and np.isnan(oracle.lsh_embed_backward(bits, g)).all()
