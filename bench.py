@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--sharded", action="store_true", help="row-shard the table + RCCL all-to-all exchange")
     ap.add_argument("--unfused", action="store_true", help="two launches (lsh_embed + rowdot) instead of the fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="launch every step from Python instead of replaying one HIP graph of the K launches")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -180,11 +182,17 @@ def main():
     users = torch.randn((n_user_bufs, B, D), generator=g, device=dev)
 
     fused = not args.unfused and not (args.sharded and world > 1)
+    # The K timed launches are captured once into a HIP graph (stream capture sees the C-ABI launches, which
+    # go to torch's current stream) and the timed region is ONE replay: the host contributes nothing per
+    # step.  Launched from Python, a step costs ~8.6 us of host time against ~9.5 us on the GPU, so any
+    # host jitter shows up in the number (tools/stability.py).  Same kernels, same K distinct id batches.
+    use_graph = fused and not args.no_graph
+    scores = torch.empty((n_user_bufs, B), dtype=torch.float32, device=dev)
 
     def step(i, ev=None):
         ids = all_ids[i]
         if fused:
-            return ops.lsh_embed_score(ids, feat, planes, buckets, users[i % n_user_bufs])
+            return ops.lsh_embed_score(ids, feat, planes, buckets, users[i % n_user_bufs], score_out=scores[i % n_user_bufs])
         if ev:
             ev[0].record()
         e = embed(ids)
@@ -199,16 +207,28 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        # Clock ramp, before the W warm-up steps: keep launching until the time of a 256-step burst has
-        # settled (two consecutive bursts within 2 %) and at least --ramp-seconds have passed; give up
-        # after 5 x that.  Untimed; uses the same id batches as the run.
+        graph = None
+        if use_graph:
+            for i in range(3):  # first-use initialisation outside the capture
+                step(i)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for k in range(args.steps):
+                    step(args.warmup + k)
+        # Clock ramp, before the W warm-up steps: keep launching until the time of a burst (256 steps, or one
+        # replay of the graph) has settled (two consecutive bursts within 2 %) and at least --ramp-seconds
+        # have passed; give up after 5 x that.  Untimed; uses the same id batches as the run.
         t_ramp = time.perf_counter()
         i, prev = 0, None
         while True:
             t_b = time.perf_counter()
-            for _ in range(256):
-                step(i % total)
-                i += 1
+            if graph is not None:
+                graph.replay()
+            else:
+                for _ in range(256):
+                    step(i % total)
+                    i += 1
             torch.cuda.synchronize()
             now = time.perf_counter()
             burst = now - t_b
@@ -228,8 +248,11 @@ def main():
         fence()
         t0 = time.perf_counter()
         region[0].record()
-        for k in range(args.steps):
-            step(args.warmup + k, events[k] if events else None)
+        if graph is not None:
+            graph.replay()  # the K captured steps
+        else:
+            for k in range(args.steps):
+                step(args.warmup + k, events[k] if events else None)
         region[1].record()
         fence()
         t1 = time.perf_counter()
@@ -265,7 +288,8 @@ def main():
                                    f"({N}-item x {F}-feature table, {H} hashes/buckets, {D}-d, batch {B} per GPU)",
                        "items": N, "feat": F, "dim": D, "hashes": H, "batch_per_gpu": B,
                        "table": "row-sharded + all-to-all" if (args.sharded and world > 1) else "replicated per GPU",
-                       "launches_per_step": "lsh_embed_score" if fused else "lsh_embed + rowdot"},
+                       "launches_per_step": "lsh_embed_score" if fused else "lsh_embed + rowdot",
+                       "launch_mode": "one HIP graph of the K launches, replayed once" if use_graph else "one launch per step from the host"},
             "roofline": {"bound": "hbm", "kernel": "lsh64_kernel<8, true, false, false>" if fused else "lsh64_kernel<8, false, true, false>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_lookup": per_lookup, "lookups_per_launch": B, "avg_launch_us": kern_ms * 1e3,

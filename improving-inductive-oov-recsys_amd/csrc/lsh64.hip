@@ -34,30 +34,86 @@
 
 namespace mi_oov {
 
+// ---- eight row sums at once ---------------------------------------------------------------------------
+// row16_sum's tree is (l, l+8), (l, l+4), (l, l+2), (l, l+1).  After level 1 a sum needs only 8 lanes, after
+// level 2 only 4: bank_mask (a DPP row = 4 banks of 4 lanes) lets a second plane's level-1 result be written
+// into lanes 8-15 of the same register, and two such registers be folded into one at level 2 (row_shl:4
+// feeds banks 0 and 2, row_shr:4 banks 1 and 3).  16 DPP adds instead of 32, every individual addition the
+// same as in row16_sum (IEEE add is commutative), so the totals are bit-identical.  Result layout:
+//   t0: bank 0 plane 0 | bank 1 plane 2 | bank 2 plane 1 | bank 3 plane 3       (all 4 lanes of a bank equal)
+//   t1: bank 0 plane 4 | bank 1 plane 6 | bank 2 plane 5 | bank 3 plane 7
+// Inline asm because the compiler cannot express a partially masked v_add_f32_dpp; the s_nop's are the
+// "VALU write -> DPP read" wait states (2) the hazard recognizer would otherwise insert.
+__device__ __forceinline__ void rows8_sum(const float (&p)[8], float& t0, float& t1) {
+  float r0, r1, r2, r3;
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_add_f32_dpp %2, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %3, %8, %8 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %4, %10, %10 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %5, %12, %12 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %2, %7, %7 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %3, %9, %9 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %4, %11, %11 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %5, %13, %13 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+      "v_add_f32_dpp %0, %2, %2 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %1, %4, %4 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+      "v_add_f32_dpp %0, %3, %3 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "v_add_f32_dpp %1, %5, %5 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0\n\t"
+      "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 0"
+      : "=&v"(t0), "=&v"(t1), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3)
+      : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]));
+}
+
+// bit of plane h for every lane of the row, from the banked registers of rows8_sum (row_newbcast:lane)
+template <int CTRL>
+__device__ __forceinline__ float dpp_all_f32(float v) {  // every lane is written: no `old` value to preserve
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float bcast8(int h, float b0, float b1) {
+  switch (h) {
+    case 0: return dpp_all_f32<0x150>(b0);   // t0 bank 0
+    case 1: return dpp_all_f32<0x158>(b0);   // t0 bank 2
+    case 2: return dpp_all_f32<0x154>(b0);   // t0 bank 1
+    case 3: return dpp_all_f32<0x15C>(b0);   // t0 bank 3
+    case 4: return dpp_all_f32<0x150>(b1);
+    case 5: return dpp_all_f32<0x158>(b1);
+    case 6: return dpp_all_f32<0x154>(b1);
+    default: return dpp_all_f32<0x15C>(b1);
+  }
+}
+
 // One tile = 16 lookups of one wave (4 rounds x 4 groups).  FULL tiles (all 16 rows < B) skip every
 // tail clamp and liveness test; only the last tile of a launch can be partial.
 template <int H, bool SCORE, bool STORE, bool LOOKUP, bool FULL>
-__device__ __forceinline__ void lsh64_tile(int64_t tile, int l16, int grp, const float4 (&pw)[H], const float4 (&bw)[H],
-                                           const int64_t* __restrict__ ids, int64_t B,
+__device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, const float4 (&pw)[H], const float4 (&bw)[H],
+                                           const int64_t (&idc)[4], unsigned B,
                                            const float* __restrict__ feat, int64_t N,
                                            const float* __restrict__ vtable, int64_t n_vocab,
                                            const float* __restrict__ other, float* __restrict__ score,
                                            float* __restrict__ out) {
   constexpr int R = 4;
-  int64_t row[R], idc[R];
+  // rows of the batch are addressed with 32-bit byte offsets from uniform bases (B <= kMaxRows64, checked by
+  // the host): global_load/store with an SGPR base + VGPR offset instead of 64-bit VGPR pointers.
+  unsigned row[R];
   bool valid[R], oov[R];
 #pragma unroll
-  for (int r = 0; r < R; ++r) {
-    row[r] = tile * (4 * R) + r * 4 + grp;
-    idc[r] = ids[(FULL || row[r] < B) ? row[r] : B - 1];  // clamped: tail groups recompute the last row
-  }
+  for (int r = 0; r < R; ++r) row[r] = tile * (4 * R) + r * 4 + grp;
+  // the gathers first (they wait on nothing but the ids), the sequential rows of the other side behind them
+  float4 x[R];
   float4 u[SCORE ? R : 1];
   if (SCORE) {
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      u[r] = *reinterpret_cast<const float4*>(other + ((FULL || row[r] < B) ? row[r] : B - 1) * 64 + l16 * 4);
+      u[r] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(other) +
+                                              (((FULL || row[r] < B) ? row[r] : B - 1) * 256u + l16 * 16u));
   }
-  float4 x[R];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     oov[r] = !LOOKUP || idc[r] >= n_vocab;
@@ -70,15 +126,39 @@ __device__ __forceinline__ void lsh64_tile(int64_t tile, int l16, int grp, const
   for (int r = 0; r < R; ++r) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     float cnt = 0.f;
+    if constexpr (H == 8) {
+      // Eight 16-lane sums for the price of two: the stride-halving tree of row16_sum, with the live copies of
+      // each level packed into fewer registers by bank-masked DPP writes (see rows8_sum).  Lane l then holds
+      // the sums of the two planes of its bank; the 0/1 bits are handed to the whole row with row_newbcast.
+      float p[8];
 #pragma unroll
-    for (int h = 0; h < H; ++h) {
-      const float s = row16_sum(dot4_fma(x[r], pw[h], 0.f));
-      const float bit = (s < 0.f) ? 0.f : 1.f;  // >= 0, +-0 and NaN -> 1 (torch_hash.py:57-59)
-      cnt = cnt + bit;
-      acc.x = __builtin_fmaf(bit, bw[h].x, acc.x);
-      acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
-      acc.z = __builtin_fmaf(bit, bw[h].z, acc.z);
-      acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+      for (int h = 0; h < 8; ++h) p[h] = dot4_fma(x[r], pw[h], 0.f);
+      float t0, t1;
+      rows8_sum(p, t0, t1);
+      const float b0 = (t0 < 0.f) ? 0.f : 1.f;  // >= 0, +-0 and NaN -> 1 (torch_hash.py:57-59)
+      const float b1 = (t1 < 0.f) ? 0.f : 1.f;
+      cnt = b0 + b1;                      // this bank's two planes ...
+      cnt = cnt + dpp_f32<0x124>(cnt);    // ... + the other banks (small integers: exact in any order)
+      cnt = cnt + dpp_f32<0x128>(cnt);
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        const float bit = bcast8(h, b0, b1);
+        acc.x = __builtin_fmaf(bit, bw[h].x, acc.x);
+        acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
+        acc.z = __builtin_fmaf(bit, bw[h].z, acc.z);
+        acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+      }
+    } else {
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float s = row16_sum(dot4_fma(x[r], pw[h], 0.f));
+        const float bit = (s < 0.f) ? 0.f : 1.f;  // >= 0, +-0 and NaN -> 1 (torch_hash.py:57-59)
+        cnt = cnt + bit;
+        acc.x = __builtin_fmaf(bit, bw[h].x, acc.x);
+        acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
+        acc.z = __builtin_fmaf(bit, bw[h].z, acc.z);
+        acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+      }
     }
     // emb = acc / cnt, correctly rounded (0/0 -> NaN row, lsh_embedder.py:178).  cnt is an integer in
     // [0, 8], so instead of four IEEE division sequences (~9 VALU each) one reciprocal r = RN(1/cnt)
@@ -87,7 +167,11 @@ __device__ __forceinline__ void lsh64_tile(int64_t tile, int l16, int grp, const
     // equals RN(a / cnt) except for a = -0 (acc is never -0: it starts at +0 and every step is
     // RN(bit*w + acc)) and for |a| < 2^-124 with cnt = 6 (result subnormal).  Lanes whose |acc| is
     // below 2^-100 (including exact zeros, i.e. the cnt = 0 rows) or infinite take the IEEE division.
-    const float rc = 1.0f / cnt;
+    // rc itself: v_rcp_f32 is accurate to 1 ulp, and one Newton step y' = fma(fma(-cnt, y, 1), y, y) from a
+    // 1-ulp estimate is the correctly rounded reciprocal unless the significand of cnt is all ones (Markstein);
+    // cnt = 0 gives NaN here, and that row takes the IEEE branch below anyway.
+    const float y0 = __builtin_amdgcn_rcpf(cnt);
+    const float rc = __builtin_fmaf(__builtin_fmaf(-cnt, y0, 1.0f), y0, y0);
     float4 emb;
     {
       float q;
@@ -107,16 +191,16 @@ __device__ __forceinline__ void lsh64_tile(int64_t tile, int l16, int grp, const
     if (LOOKUP && !oov[r]) emb = x[r];
     if (!valid[r]) emb = make_float4(qnan(), qnan(), qnan(), qnan());
     const bool live = FULL || row[r] < B;
-    if (STORE && live) *reinterpret_cast<float4*>(out + row[r] * 64 + l16 * 4) = emb;
+    if (STORE && live) *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (row[r] * 256u + l16 * 16u)) = emb;
     if (SCORE) {
       const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
-      if (l16 == 0 && live) score[row[r]] = s;
+      if (l16 == 0 && live) *reinterpret_cast<float*>(reinterpret_cast<char*>(score) + row[r] * 4u) = s;
     }
   }
 }
 
 template <int H, bool SCORE, bool STORE, bool LOOKUP>
-__global__ __launch_bounds__(kBlock) void lsh64_kernel(const int64_t* __restrict__ ids, int64_t B,
+__global__ __launch_bounds__(kBlock, 4) void lsh64_kernel(const int64_t* __restrict__ ids, unsigned B,
                                                        const float* __restrict__ feat, int64_t N,
                                                        const float* __restrict__ vtable, int64_t n_vocab,
                                                        const float* __restrict__ planes,
@@ -124,9 +208,20 @@ __global__ __launch_bounds__(kBlock) void lsh64_kernel(const int64_t* __restrict
                                                        const float* __restrict__ other,
                                                        float* __restrict__ score, float* __restrict__ out) {
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
-  const int64_t ntiles = (B + 15) / 16;
-  const int64_t nfull = B / 16;
-  const int64_t tstep = static_cast<int64_t>(gridDim.x) * 4;
+  const unsigned ntiles = (B + 15) / 16;
+  const unsigned nfull = B / 16;
+  const unsigned tstep = gridDim.x * 4;
+
+  // The ids of the wave's first tile are requested before anything else: their round trip (the first hop of the
+  // ids -> rows chain) then overlaps the staging of the weights instead of following it.
+  unsigned tile = blockIdx.x * 4 + wv;
+  int64_t idc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned row = tile * 16 + r * 4 + grp;
+    // clamped: tail groups recompute the last row (B >= 1 here)
+    idc[r] = *reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(ids) + (row < B ? row : B - 1) * 8u);
+  }
 
   // Plane / bucket slices -> VGPRs through LDS: the workgroup fetches the 2 x H x 256 B once (one 16-B
   // load per thread) and every lane reads its 2 x H float4 back with ds_read_b128, instead of 2 x H
@@ -145,11 +240,19 @@ __global__ __launch_bounds__(kBlock) void lsh64_kernel(const int64_t* __restrict
     bw[h] = *reinterpret_cast<const float4*>(sw + (H * 16 + h * 16 + l16) * 4);
   }
 
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles; tile += tstep) {
+  while (tile < ntiles) {
     if (tile < nfull)
-      lsh64_tile<H, SCORE, STORE, LOOKUP, true>(tile, l16, grp, pw, bw, ids, B, feat, N, vtable, n_vocab, other, score, out);
+      lsh64_tile<H, SCORE, STORE, LOOKUP, true>(tile, l16, grp, pw, bw, idc, B, feat, N, vtable, n_vocab, other, score, out);
     else
-      lsh64_tile<H, SCORE, STORE, LOOKUP, false>(tile, l16, grp, pw, bw, ids, B, feat, N, vtable, n_vocab, other, score, out);
+      lsh64_tile<H, SCORE, STORE, LOOKUP, false>(tile, l16, grp, pw, bw, idc, B, feat, N, vtable, n_vocab, other, score, out);
+    tile += tstep;
+    if (tile < ntiles) {  // only when the grid was capped (B > 16 * 4 * kMaxGrid)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned row = tile * 16 + r * 4 + grp;
+        idc[r] = *reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(ids) + (row < B ? row : B - 1) * 8u);
+      }
+    }
   }
 }
 
@@ -157,10 +260,17 @@ template <int H, bool SCORE, bool STORE, bool LOOKUP>
 static int launch64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
                     const float* planes, const float* buckets, const float* other, float* score, float* out,
                     hipStream_t st) {
-  const int grid = grid_for(B, 64);  // 4 waves x 16 lookups per workgroup pass
-  hipLaunchKernelGGL((lsh64_kernel<H, SCORE, STORE, LOOKUP>), dim3(grid), dim3(kBlock), 2 * H * 64 * sizeof(float), st, ids, B, feat, N, vtable,
-                     n_vocab, planes, buckets, other, score, out);
-  return check_launch();
+  // the kernel addresses batch rows with 32-bit byte offsets: launches of at most kMaxRows64 lookups
+  constexpr int64_t kMaxRows64 = int64_t(1) << 23;  // x 256 B = 2 GiB
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxRows64) {
+    const int64_t nb = (B - b0 < kMaxRows64) ? B - b0 : kMaxRows64;
+    const int grid = grid_for(nb, 64);  // 4 waves x 16 lookups per workgroup pass
+    hipLaunchKernelGGL((lsh64_kernel<H, SCORE, STORE, LOOKUP>), dim3(grid), dim3(kBlock), 2 * H * 64 * sizeof(float), st,
+                       ids + b0, static_cast<unsigned>(nb), feat, N, vtable, n_vocab, planes, buckets,
+                       other ? other + b0 * 64 : nullptr, score ? score + b0 : nullptr, out ? out + b0 * 64 : nullptr);
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
 }
 
 template <int H>

@@ -91,14 +91,20 @@ def lsh_embed(ids, feat, planes, buckets):
     return _lsh_forward(ids, feat, planes, buckets)[0]
 
 
-def lsh_embed_score(ids, feat, planes, buckets, other, want_emb=False):
-    """Fused lsh embedding + BPR.predict row dot (bpr.py:145-149).  Inference only."""
+def lsh_embed_score(ids, feat, planes, buckets, other, want_emb=False, score_out=None):
+    """Fused lsh embedding + BPR.predict row dot (bpr.py:145-149).  Inference only.
+    `score_out` (f32[B], optional) receives the scores instead of a fresh tensor (serving loops, graph capture)."""
     ids, feat, planes, buckets, other = (_ids(ids), _f32(feat, "feat"), _f32(planes, "planes"),
                                          _f32(buckets, "buckets"), _f32(other, "other"))
     B, (N, F), H, D = ids.numel(), feat.shape, planes.shape[0], buckets.shape[1]
     if other.shape != (B, D):
         raise ValueError(f"other must be [{B},{D}], got {tuple(other.shape)}")
-    score = torch.empty((B,), dtype=torch.float32, device=ids.device)
+    if score_out is None:
+        score = torch.empty((B,), dtype=torch.float32, device=ids.device)
+    else:
+        score = C.dev_tensor(score_out, torch.float32, "score_out")
+        if score.shape != (B,) or score.data_ptr() != score_out.data_ptr():
+            raise ValueError(f"score_out must be a contiguous f32[{B}] tensor on the device")
     out = torch.empty((B, D), dtype=torch.float32, device=ids.device) if want_emb else None
     with C.on_device(ids):
         rc = C.lib().mi_oov_lsh_embed_score(C.ptr(ids), B, C.ptr(feat), N, F, C.ptr(planes), H, C.ptr(buckets), D,

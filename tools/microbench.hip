@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <chrono>
 #include <vector>
 
 #include "mi_oov.h"
@@ -265,6 +266,128 @@ static float time_it(F launch, int iters) {
   return ms * 1e3f / iters;
 }
 
+
+// stamps of the PRODUCT kernel's structure (weights through LDS + barrier).  ORDER 0: weights first (as shipped),
+// ORDER 1: ids + user rows issued before the weights are staged.
+// stamps: 0 start, 1 weights in VGPRs, 2 ids landed, 3 x[0] landed, 4 x[R-1] landed, 5 done.
+template <int R, int ORDER>
+__global__ __launch_bounds__(256) void stamped2_kernel(const int64_t* __restrict__ ids, int64_t B,
+                                                       const float* __restrict__ feat, const float* __restrict__ planes,
+                                                       const float* __restrict__ buckets, const float* __restrict__ other,
+                                                       float* __restrict__ score, unsigned long long* __restrict__ stamps) {
+  constexpr int H = 8;
+  __shared__ __attribute__((aligned(16))) float sw[2 * H * 64];
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+  unsigned long long* o = stamps + 6 * ((size_t)blockIdx.x * 4 + wv);
+#define STAMP(k) do { if (lane == 0) __builtin_nontemporal_store(wall_clock64(), o + (k)); } while (0)
+  STAMP(0);
+  int64_t row[R], id[R];
+  float4 u[R], x[R];
+  if (ORDER >= 1) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      if (row[r] >= B) row[r] = B - 1;
+      id[r] = ids[row[r]];
+    }
+    if (ORDER == 1) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
+    }
+  }
+  for (int i = threadIdx.x; i < 2 * H * 16; i += 256) {
+    const float* src = (i < H * 16) ? planes + i * 4 : buckets + (i - H * 16) * 4;
+    *reinterpret_cast<float4*>(sw + i * 4) = *reinterpret_cast<const float4*>(src);
+  }
+  __syncthreads();
+  float4 pw[H], bw[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    pw[h] = *reinterpret_cast<const float4*>(sw + (h * 16 + l16) * 4);
+    bw[h] = *reinterpret_cast<const float4*>(sw + (H * 16 + h * 16 + l16) * 4);
+  }
+  asm volatile("" ::"v"(pw[0].x), "v"(bw[H - 1].w));
+  STAMP(1);
+  if (ORDER == 0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      if (row[r] >= B) row[r] = B - 1;
+      id[r] = ids[row[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
+  }
+  long long idsum = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) idsum += id[r];
+  asm volatile("" ::"v"(idsum));
+  STAMP(2);
+#pragma unroll
+  for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const float4*>(feat + id[r] * 64 + l16 * 4);
+  if (ORDER == 2) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
+  }
+  float tot = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    asm volatile("" ::"v"(x[r].x));
+    if (r == 0) STAMP(3);
+    if (r == R - 1) STAMP(4);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cnt = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float s = row16_sum(dot4_fma(x[r], pw[h], 0.f));
+      const float bit = (s < 0.f) ? 0.f : 1.f;
+      cnt = cnt + bit;
+      acc.x = __builtin_fmaf(bit, bw[h].x, acc.x); acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
+      acc.z = __builtin_fmaf(bit, bw[h].z, acc.z); acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+    }
+    acc.x /= cnt; acc.y /= cnt; acc.z /= cnt; acc.w /= cnt;
+    const float s = row16_sum(dot4_muladd(u[r], acc, 0.f));
+    if (l16 == 0) score[row[r]] = s;
+    tot += s;
+  }
+  asm volatile("" ::"v"(tot));
+  STAMP(5);
+#undef STAMP
+}
+
+template <int ORDER>
+static void run_stamps2(const int64_t* ids, int64_t B, const float* feat, const float* planes2, const float* buckets2,
+                        const float* users2, float* score2) {
+  const int grid = (int)(B / 64), nw = grid * 4;
+  unsigned long long* st;
+  CK(hipMalloc(&st, (size_t)nw * 6 * 8));
+  for (int i = 0; i < 50; ++i)
+    hipLaunchKernelGGL((stamped2_kernel<4, ORDER>), dim3(grid), dim3(256), 0, 0, ids + (int64_t)i * B, B, feat, planes2, buckets2,
+                       users2 + (int64_t)(i % 8) * B * 64, score2, st);
+  CK(hipDeviceSynchronize());
+  std::vector<unsigned long long> hs((size_t)nw * 6);
+  CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long base = ~0ull, end = 0;
+  for (int w = 0; w < nw; ++w) { if (hs[6 * w] < base) base = hs[6 * w]; if (hs[6 * w + 5] > end) end = hs[6 * w + 5]; }
+  printf("stamped2 ORDER=%d: first start -> last end = %.2f us\n", ORDER, (end - base) / 100.0);
+  const char* names[6] = {"start", "weights ready", "ids landed", "x[0] landed", "x[3] landed", "done"};
+  for (int k = 0; k < 6; ++k) {
+    std::vector<double> v(nw);
+    for (int w = 0; w < nw; ++w) v[w] = (hs[6 * w + k] - base) / 100.0;
+    std::sort(v.begin(), v.end());
+    printf("  %-14s  min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  max %6.2f us\n", names[k], v[0], v[nw / 10], v[nw / 2], v[nw * 9 / 10], v[nw - 1]);
+  }
+  // per-XCD view of the start stamps: blockIdx % 8 is the XCD
+  for (int x = 0; x < 8; x += 7) {
+    std::vector<double> v;
+    for (int w = 0; w < nw; ++w) if ((w / 4) % 8 == x) v.push_back((hs[6 * w + 5] - base) / 100.0);
+    std::sort(v.begin(), v.end());
+    printf("  XCD %d done: p50 %.2f max %.2f\n", x, v[v.size() / 2], v.back());
+  }
+  CK(hipFree(st));
+}
+
 int main(int argc, char** argv) {
   const int64_t N = 10000000, B = argc > 1 ? atoll(argv[1]) : 65536;
   const int iters = 200, nb = iters + 10;
@@ -277,6 +400,7 @@ int main(int argc, char** argv) {
   CK(hipMemcpy(ids, h.data(), h.size() * 8, hipMemcpyHostToDevice));
   printf("B=%lld rows of 256 B, table %.2f GB\n", (long long)B, N * 256 / 1e9);
   if (getenv("MB_LIB_ONLY")) goto lib_cases;
+  if (getenv("MB_STAMPS2")) goto stamps2;
   printf("%-44s %8.2f us\n", "empty kernel, 1024 blocks", time_it([&](int) { hipLaunchKernelGGL(empty_kernel, dim3(1024), dim3(256), 0, 0, nullptr); }, iters));
 #define RUN(R, MODE, NAME, BLOCKS)                                                                        \
   {                                                                                                       \
@@ -327,6 +451,16 @@ int main(int argc, char** argv) {
     RUNSO(4, 4, 3, "staged 4 (full) Markstein division R=4 (again)")
     RUNS(0, 2, "staged 0 R=2") RUNS(4, 2, "staged 4 (full) R=2") RUNS(4, 1, "staged 4 (full) R=1") RUNS(4, 8, "staged 4 (full) R=8")
   }
+  stamps2:
+  if (getenv("MB_STAMPS2")) {
+    float *planes2, *buckets2, *users2, *score2;
+    CK(hipMalloc(&planes2, 2048)); CK(hipMalloc(&buckets2, 2048)); CK(hipMalloc(&users2, 8 * B * 64 * 4)); CK(hipMalloc(&score2, B * 4));
+    CK(hipMemset(planes2, 0, 2048)); CK(hipMemset(buckets2, 0, 2048)); CK(hipMemset(users2, 0, 8 * B * 64 * 4));
+    run_stamps2<0>(ids, B, feat, planes2, buckets2, users2, score2);
+    run_stamps2<1>(ids, B, feat, planes2, buckets2, users2, score2);
+    run_stamps2<2>(ids, B, feat, planes2, buckets2, users2, score2);
+    return 0;
+  }
   if (getenv("MB_STAMPS")) {
     float *planes2, *buckets2, *users2, *score2; unsigned long long* st;
     const int grid = (int)(B / 64), nw = grid * 4;
@@ -376,6 +510,40 @@ int main(int argc, char** argv) {
     printf("variant %s: %-32s %8.2f us  %7.1f GB/s\n", var ? var : "0", "mi_oov_lsh_embed", us, B * 520.0 / us / 1e3);
     us = time_it([&](int i) { mi_oov_lsh_embed_score(ids + (int64_t)i * B, B, feat, N, 64, planes, 8, buckets, 64, users + (int64_t)(i % 8) * B * 64, score, nullptr, nullptr); }, iters);
     printf("variant %s: %-32s %8.2f us  %7.1f GB/s\n", var ? var : "0", "mi_oov_lsh_embed_score", us, B * 532.0 / us / 1e3);
+    {  // cache-resident inputs: 1024-row table, one id batch, one user buffer -> what is left is launch + VALU
+      std::vector<int64_t> hsmall(B);
+      for (auto& v : hsmall) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; v = (int64_t)(s % 1024); }
+      int64_t* ids_small; CK(hipMalloc(&ids_small, B * 8));
+      CK(hipMemcpy(ids_small, hsmall.data(), B * 8, hipMemcpyHostToDevice));
+      for (int Hh : {8, 4, 2}) {
+        us = time_it([&](int) { mi_oov_lsh_embed_score(ids_small, B, feat, 1024, 64, planes, Hh, buckets, 64, users, score, nullptr, nullptr); }, iters);
+        printf("cache-resident inputs, H=%d: mi_oov_lsh_embed_score %8.2f us\n", Hh, us);
+      }
+      for (int Hh : {8, 4, 2}) {
+        us = time_it([&](int i) { mi_oov_lsh_embed_score(ids + (int64_t)i * B, B, feat, N, 64, planes, Hh, buckets, 64, users + (int64_t)(i % 8) * B * 64, score, nullptr, nullptr); }, iters);
+        printf("HBM inputs,            H=%d: mi_oov_lsh_embed_score %8.2f us\n", Hh, us);
+      }
+    }
+    {  // how much does cross-launch overlap buy?  same launches, alternating between NS streams
+      for (int NS : {2, 3, 4}) {
+        hipStream_t st[4];
+        for (int k = 0; k < NS; ++k) CK(hipStreamCreateWithFlags(&st[k], hipStreamNonBlocking));
+        float* sc[4];
+        for (int k = 0; k < NS; ++k) CK(hipMalloc(&sc[k], B * 4));
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+        for (int i = 0; i < 20; ++i)
+          mi_oov_lsh_embed_score(ids + (int64_t)i * B, B, feat, N, 64, planes, 8, buckets, 64, users + (int64_t)(i % 8) * B * 64, sc[i % NS], nullptr, st[i % NS]);
+        CK(hipDeviceSynchronize());
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < iters; ++i)
+          mi_oov_lsh_embed_score(ids + (int64_t)(10 + i) * B, B, feat, N, 64, planes, 8, buckets, 64, users + (int64_t)(i % 8) * B * 64, sc[i % NS], nullptr, st[i % NS]);
+        CK(hipDeviceSynchronize());
+        auto t1 = std::chrono::steady_clock::now();
+        double usl = std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
+        printf("%d streams: mi_oov_lsh_embed_score  %8.2f us per launch (wall)  %7.1f GB/s\n", NS, usl, B * 532.0 / usl / 1e3);
+      }
+    }
     us = time_it([&](int i) { mi_oov_rowdot(users + (int64_t)(i % 8) * B * 64, out, B, 64, score, nullptr); }, iters);
     printf("%-44s %8.2f us  %7.1f GB/s\n", "mi_oov_rowdot", us, B * 516.0 / us / 1e3);
   }
