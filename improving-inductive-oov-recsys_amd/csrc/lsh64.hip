@@ -14,22 +14,31 @@
 // Arithmetic and summation order are those of lsh_fused_kernel, so the two kernels and the oracle
 // agree bit for bit.
 //
-// Measured on MI355X (65536 lookups, N = 10 M, H = 8; rocprofv3 kernel time, all bit-identical):
+// Measured on MI355X (65536 lookups, N = 10 M, H = 8; all versions bit-identical):
 //   generic kernel, branchy gathers 16.8 us -> clamped gathers 14.9 us
 //   this kernel (operands in VGPRs)  12.2 us storing rows / 11.4 us fused score
 //   + SLP packing off (v_add_f32_dpp stays fused; -fno-slp-vectorize)  10.6 us fused score
+//   + Markstein division, full-tile fast path                         10.1 us (graph replay, see below)
+//   + ids requested before the weights are staged, 32-bit batch offsets (119 VGPRs), bank-masked
+//     8-plane DPP reduce, Newton reciprocal                            9.40 us
+//   + gathers issued before the user rows (forced)                     9.09 us
+//   + kernel arguments preloaded into SGPRs (-amdgpu-kernarg-preload-count=16)  8.90 us = 3.9 TB/s
+// How it is measured now: bench.py replays ONE HIP graph holding the K launches, which is reproducible to
+// +-0.01 us; launched from Python a step costs 8.6 us of host time against ~9 us on the GPU and the number
+// wanders between 10.0 and 11.5 us from process to process (tools/stability.py, tools/ab_bench.sh).
+// What bounds it (tools/microbench.hip, tools/valu_rate.hip, tools/pmc_hot.sh):
+//   * NOT the VALU: with cache-resident inputs H = 8 / 4 / 2 planes take 6.47 / 6.07 / 5.64 us, i.e. all of the
+//     arithmetic of 6 planes is worth 0.8 us.  CDNA4 issues a wave64 v_fma_f32 in ~2.6-3 cycles, v_pk_fma_f32
+//     in ~4.7 (no gain from packing: a packed version of this kernel was slower), v_add_f32_dpp in ~4.2.
+//     SQ counters: a wave lives ~4200 quad-cycles, waits on memory for 46 % of them and issues VALU for 15 %.
+//   * the dependent chain launch -> ids -> rows -> score store: empty launch 2.3-2.5 us back to back, ids land
+//     ~1.3 us after the wave starts, the first gathered row ~1.5 us later, and the 33.4 MB of rows then stream
+//     at > 6 TB/s.  Launches that are allowed to overlap (2-4 streams) reach 5.9 us per launch = 5.9 TB/s:
+//     the next batch's head hides under this batch's tail.  A single serialized launch cannot do that.
 // Tried and rejected: "lane owns lookup" through an LDS transpose, one wave per SIMD (23 us, LDS
 // latency exposed); per-workgroup 2^H-row code table in LDS replacing aggregate + division (13.2 us
-// with 1024-thread groups, 17.3 us with 256: build + barrier cost more than they save).
-// Floor for this access pattern (tools/microbench.hip, back-to-back launches): empty launch 2.3 us,
-// gather only 5.7 us, gather x and u rows 7.5 us, gather + 256-B row store 7.8 us.  Stage costs on top
-// of the 7.5 us floor: 8 projections +1.1 us, aggregate +1.0, division +0.7, score +0.3.
-// Per-wave s_memrealtime stamps (MB_STAMPS=1 tools/microbench): all 4096 waves start within 0.4 us,
-// the kernel spans 8.4 us in-kernel (the other ~2.3 us of a launch are dispatch + boundary); ids
-// land at p50 2.6 / max 5.2 us and a wave's four rows land over a further ~2.4 us: the 34.9 MB of a
-// launch need >= 5.8 us at the ~6 TB/s the memory system sustains, i.e. the middle of the kernel is
-// bandwidth-bound and only its head (launch, first dependent hop) and tail (last rounds' VALU)
-// are not.  Re-ordering the issue (ids before weights, user rows after the gathers) changed nothing.
+// with 1024-thread groups, 17.3 us with 256: build + barrier cost more than they save); v_pk_fma_f32
+// math; non-temporal loads; 64 / 128 / 512 / 1024-thread workgroups; user rows requested late.
 #include "common.hpp"
 
 namespace mi_oov {
@@ -106,20 +115,26 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
 #pragma unroll
   for (int r = 0; r < R; ++r) row[r] = tile * (4 * R) + r * 4 + grp;
   // the gathers first (they wait on nothing but the ids), the sequential rows of the other side behind them
+  // Issue order matters (A/B under graph replay, +-0.01 us): the R gathers first -- they are the second hop of the
+  // ids -> rows chain and the first thing the VALU waits for -- and the sequential rows of the other side behind
+  // them (needed only by the score at the end of each round): 9.57 us with the user rows first, 9.10 us this
+  // way.  The compiler is free to reorder independent loads, hence the scheduling barrier between the groups.
+  // Non-temporal loads (streaming rows, no reuse) changed nothing for the gathers and cost 0.3 us on the user rows.
   float4 x[R];
   float4 u[SCORE ? R : 1];
-  if (SCORE) {
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      u[r] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(other) +
-                                              (((FULL || row[r] < B) ? row[r] : B - 1) * 256u + l16 * 16u));
-  }
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     oov[r] = !LOOKUP || idc[r] >= n_vocab;
     valid[r] = oov[r] ? static_cast<uint64_t>(idc[r]) < static_cast<uint64_t>(N) : idc[r] >= 0;
     const float* base = oov[r] ? feat : vtable;
     x[r] = *reinterpret_cast<const float4*>(base + (valid[r] ? idc[r] : 0) * 64 + l16 * 4);
+  }
+  if (SCORE) {
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      u[r] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(other) +
+                                              (((FULL || row[r] < B) ? row[r] : B - 1) * 256u + l16 * 16u));
   }
 
 #pragma unroll
@@ -199,8 +214,10 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
   }
 }
 
+// 4 waves (256 threads) per workgroup: 1, 2, 8 and 16 waves measured 9.96 / 9.50 / 9.14 / 9.20 us against 9.09.
+constexpr int kWpb = 4, kBlk = 64 * kWpb;
 template <int H, bool SCORE, bool STORE, bool LOOKUP>
-__global__ __launch_bounds__(kBlock, 4) void lsh64_kernel(const int64_t* __restrict__ ids, unsigned B,
+__global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restrict__ ids, unsigned B,
                                                        const float* __restrict__ feat, int64_t N,
                                                        const float* __restrict__ vtable, int64_t n_vocab,
                                                        const float* __restrict__ planes,
@@ -210,11 +227,11 @@ __global__ __launch_bounds__(kBlock, 4) void lsh64_kernel(const int64_t* __restr
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
   const unsigned ntiles = (B + 15) / 16;
   const unsigned nfull = B / 16;
-  const unsigned tstep = gridDim.x * 4;
+  const unsigned tstep = gridDim.x * kWpb;
 
   // The ids of the wave's first tile are requested before anything else: their round trip (the first hop of the
   // ids -> rows chain) then overlaps the staging of the weights instead of following it.
-  unsigned tile = blockIdx.x * 4 + wv;
+  unsigned tile = blockIdx.x * kWpb + wv;
   int64_t idc[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -228,7 +245,7 @@ __global__ __launch_bounds__(kBlock, 4) void lsh64_kernel(const int64_t* __restr
   // global loads per lane (16 KiB of L1 traffic per wave) queued in front of the ids -> rows gathers
   // (-0.4 us in tools/microbench.hip).
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [2][H][64]
-  for (int i = threadIdx.x; i < 2 * H * 16; i += kBlock) {
+  for (int i = threadIdx.x; i < 2 * H * 16; i += kBlk) {
     const float* src = (i < H * 16) ? planes + i * 4 : buckets + (i - H * 16) * 4;
     *reinterpret_cast<float4*>(sw + i * 4) = *reinterpret_cast<const float4*>(src);
   }
@@ -264,8 +281,8 @@ static int launch64(const int64_t* ids, int64_t B, const float* feat, int64_t N,
   constexpr int64_t kMaxRows64 = int64_t(1) << 23;  // x 256 B = 2 GiB
   for (int64_t b0 = 0; b0 < B; b0 += kMaxRows64) {
     const int64_t nb = (B - b0 < kMaxRows64) ? B - b0 : kMaxRows64;
-    const int grid = grid_for(nb, 64);  // 4 waves x 16 lookups per workgroup pass
-    hipLaunchKernelGGL((lsh64_kernel<H, SCORE, STORE, LOOKUP>), dim3(grid), dim3(kBlock), 2 * H * 64 * sizeof(float), st,
+    const int grid = grid_for(nb, 16 * kWpb);  // kWpb waves x 16 lookups per workgroup pass  // kWpb waves x 16 lookups per workgroup pass
+    hipLaunchKernelGGL((lsh64_kernel<H, SCORE, STORE, LOOKUP>), dim3(grid), dim3(kBlk), 2 * H * 64 * sizeof(float), st,
                        ids + b0, static_cast<unsigned>(nb), feat, N, vtable, n_vocab, planes, buckets,
                        other ? other + b0 * 64 : nullptr, score ? score + b0 : nullptr, out ? out + b0 * 64 : nullptr);
     if (int rc = check_launch()) return rc;

@@ -1,10 +1,13 @@
 #!/bin/bash
-# A/B two builds of libmi_oov.so with bench.py, alternating, on one box:
-#   gpurun -- 'bash tools/ab_bench.sh improving-inductive-oov-recsys_amd/lib/ab/libmi_oov_old.so improving-inductive-oov-recsys_amd/lib/ab/libmi_oov_new.so 3'
+# A/B builds of libmi_oov.so with bench.py (graph replay: +-0.01 us), alternating, on one box:
+#   gpurun -- 'bash tools/ab_bench.sh 2 improving-inductive-oov-recsys_amd/lib/ab/*.so'
 L=improving-inductive-oov-recsys_amd/lib/libmi_oov.so
-for rep in $(seq 1 ${3:-3}); do
-  for v in "$1" "$2"; do
+cp $L /tmp/libmi_oov_keep.so
+reps=$1; shift
+for rep in $(seq 1 $reps); do
+  for v in "$@"; do
     cp "$v" $L
-    timeout -k 10 200 python bench.py --no-cpu-baseline | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$v'.split('/')[-1], round(d['roofline']['avg_launch_us'],3), round(d['value']/1e9,3))" || exit 1
+    timeout -k 10 200 python bench.py --no-cpu-baseline | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-24s %.3f us  %.3f G/s' % ('$v'.split('/')[-1], d['roofline']['avg_launch_us'], d['value']/1e9))" || exit 1
   done
 done
+cp /tmp/libmi_oov_keep.so $L
