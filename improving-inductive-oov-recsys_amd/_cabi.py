@@ -118,6 +118,17 @@ def stream_of(t) -> int:
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+def current_device() -> int:
+    return _get_device() if _get_device is not None else torch.cuda.current_device()
+
+
+def raw_stream(idx: int) -> int:
+    """hipStream_t (raw handle) of torch's current stream on device `idx`."""
+    if _raw_stream is not None:
+        return _raw_stream(idx)
+    return torch.cuda.current_stream(idx).cuda_stream
+
+
 class on_device:
     """Make the tensor's device current for the duration of a launch (no-op when it already is:
     one process per GPU is the deployment model, so the fast path is a single integer compare)."""

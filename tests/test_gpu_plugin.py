@@ -336,3 +336,35 @@ def test_bpr_training_step_grads(mi, golden, dev, tag):
         assert got is not None and got.shape == ref.shape, n
         err = np.abs(got.cpu().numpy() - ref).max()
         assert err <= 1e-5 * np.abs(ref).max(), (tag, n, err, np.abs(ref).max())
+
+
+def test_lsh_scorer_and_graph_replay(mi, dev):
+    """The serving-loop forms of the fused kernel: LshScorer (operands validated once) and a HIP graph of
+    launches captured from torch's stream return exactly what the checked wrapper returns."""
+    from mi_oov import ops
+    g = torch.Generator(device=dev).manual_seed(5)
+    N, B = 50_000, 4099
+    feat = torch.randn((N, 64), generator=g, device=dev)
+    planes, buckets = torch.randn((8, 64), generator=g, device=dev), torch.randn((8, 64), generator=g, device=dev)
+    ids = torch.randint(0, N, (4, B), generator=g, device=dev)
+    users = torch.randn((4, B, 64), generator=g, device=dev)
+    want = [ops.lsh_embed_score(ids[i], feat, planes, buckets, users[i]) for i in range(4)]
+    scorer = ops.LshScorer(feat, planes, buckets)
+    buf = torch.empty((4, B), device=dev)
+    for i in range(4):
+        assert torch.equal(torch.nan_to_num(scorer(ids[i], users[i])), torch.nan_to_num(want[i]))
+        assert scorer(ids[i], users[i], score_out=buf[i]).data_ptr() == buf[i].data_ptr()
+    assert torch.equal(torch.nan_to_num(buf), torch.nan_to_num(torch.stack(want)))
+    with pytest.raises(ValueError):
+        scorer(ids[0].to(torch.int32), users[0])
+    with pytest.raises(ValueError):
+        scorer(ids[0], users[0][:, :32])
+    buf.zero_()
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        for i in range(4):
+            scorer(ids[i], users[i], score_out=buf[i])
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(buf), torch.nan_to_num(torch.stack(want)))

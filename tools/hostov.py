@@ -16,7 +16,12 @@ def t(fn, n=300):
     for _ in range(n): fn()
     t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     return (t1 - t0) / n * 1e6, (t2 - t0) / n * 1e6
+scorer = ops.LshScorer(feat, planes, buckets)
+sbuf = torch.empty((B,), device=dev)
+assert torch.equal(torch.nan_to_num(scorer(ids, emb)), torch.nan_to_num(ops.lsh_embed_score(ids, feat, planes, buckets, emb)))
 for name, fn in [("lsh_embed_score", lambda: ops.lsh_embed_score(ids, feat, planes, buckets, emb)),
+                 ("LshScorer", lambda: scorer(ids, emb)),
+                 ("LshScorer(out=)", lambda: scorer(ids, emb, sbuf)),
                  ("lsh_lookup", lambda: ops.lsh_lookup(ids, table, feat, planes, buckets)),
                  ("mapper_map", lambda: ops.mapper_map(ids, "3round", N // 2, 1000)),
                  ("broadcast_rows", lambda: ops.broadcast_rows(emb[0], B)),
