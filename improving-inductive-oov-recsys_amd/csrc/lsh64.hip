@@ -22,7 +22,8 @@
 //   + ids requested before the weights are staged, 32-bit batch offsets (119 VGPRs), bank-masked
 //     8-plane DPP reduce, Newton reciprocal                            9.40 us
 //   + gathers issued before the user rows (forced)                     9.09 us
-//   + kernel arguments preloaded into SGPRs (-amdgpu-kernarg-preload-count=16)  8.90 us = 3.9 TB/s
+//   + kernel arguments preloaded into SGPRs (-amdgpu-kernarg-preload-count=16)  8.90 us
+//   + the 16 scores of a tile stored by ONE instruction at the end of the tile     8.50 us = 4.1 TB/s
 // How it is measured now: bench.py replays ONE HIP graph holding the K launches, which is reproducible to
 // +-0.01 us; launched from Python a step costs 8.6 us of host time against ~9 us on the GPU and the number
 // wanders between 10.0 and 11.5 us from process to process (tools/stability.py, tools/ab_bench.sh).
@@ -137,6 +138,7 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
                                               (((FULL || row[r] < B) ? row[r] : B - 1) * 256u + l16 * 16u));
   }
 
+  float sc_all = 0.f;
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -209,8 +211,28 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
     if (STORE && live) *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (row[r] * 256u + l16 * 16u)) = emb;
     if (SCORE) {
       const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
-      if (l16 == 0 && live) *reinterpret_cast<float*>(reinterpret_cast<char*>(score) + row[r] * 4u) = s;
+      if (FULL) {
+        if (l16 == r) sc_all = s;  // lane r of the group keeps round r's score: stored once, below
+      } else if (l16 == 0 && live) {
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(score) + row[r] * 4u) = s;
+      }
     }
+  }
+  // ONE 16-lane store of the tile's 16 contiguous scores instead of four 4-lane stores (-0.4 us per launch:
+  // the memory instructions a wave issues are worth more than its arithmetic here)
+  if (SCORE && FULL && l16 < 4)
+    *reinterpret_cast<float*>(reinterpret_cast<char*>(score) + (tile * 16u + l16 * 4u + grp) * 4u) = sc_all;
+}
+
+// The ids of a tile: one 8-byte load per round (4 distinct addresses per instruction).  Fetching all 16 ids
+// with ONE instruction and handing them round with row_newbcast was measured too: 8.61 us against 8.52.
+__device__ __forceinline__ void load_tile_ids(const int64_t* __restrict__ ids, unsigned tile, unsigned B, int l16, int grp,
+                                              int64_t (&idc)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const unsigned row = tile * 16 + r * 4 + grp;
+    // clamped: tail groups recompute the last row (B >= 1 here)
+    idc[r] = *reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(ids) + (row < B ? row : B - 1) * 8u);
   }
 }
 
@@ -233,12 +255,7 @@ __global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restric
   // ids -> rows chain) then overlaps the staging of the weights instead of following it.
   unsigned tile = blockIdx.x * kWpb + wv;
   int64_t idc[4];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const unsigned row = tile * 16 + r * 4 + grp;
-    // clamped: tail groups recompute the last row (B >= 1 here)
-    idc[r] = *reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(ids) + (row < B ? row : B - 1) * 8u);
-  }
+  load_tile_ids(ids, tile, B, l16, grp, idc);
 
   // Plane / bucket slices -> VGPRs through LDS: the workgroup fetches the 2 x H x 256 B once (one 16-B
   // load per thread) and every lane reads its 2 x H float4 back with ds_read_b128, instead of 2 x H
@@ -264,11 +281,7 @@ __global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restric
       lsh64_tile<H, SCORE, STORE, LOOKUP, false>(tile, l16, grp, pw, bw, idc, B, feat, N, vtable, n_vocab, other, score, out);
     tile += tstep;
     if (tile < ntiles) {  // only when the grid was capped (B > 16 * 4 * kMaxGrid)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const unsigned row = tile * 16 + r * 4 + grp;
-        idc[r] = *reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(ids) + (row < B ? row : B - 1) * 8u);
-      }
+      load_tile_ids(ids, tile, B, l16, grp, idc);
     }
   }
 }
