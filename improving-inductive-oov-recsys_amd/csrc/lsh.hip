@@ -431,7 +431,7 @@ static int dispatch_lsh(const LshParams& p, hipStream_t st) {
 // lsh64.hip: lane-owns-lookup kernel for the hot shape F = D = 64
 int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
                  const float* planes, int H, const float* buckets, const float* other, float* score, float* out,
-                 hipStream_t st);
+                 hipStream_t st, uint8_t* bits);
 
 static bool lsh64_enabled() {
   static const bool on = [] {
@@ -453,12 +453,15 @@ static int run_lsh(LshParams p, void* stream) {
   if (p.D > 256) return MI_OOV_ERR_SHAPE;
   if (p.D <= 0) p.D = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool vec = (p.F % 4 == 0) && (p.D % 4 == 0) && aligned16(p.feat) && (!p.out || aligned16(p.out)) &&
+  const bool vec = (p.F % 4 == 0) && (!want_emb || p.D % 4 == 0) && aligned16(p.feat) && (!p.out || aligned16(p.out)) &&
                    (!p.other || aligned16(p.other)) && (!p.table || aligned16(p.table));
-  if (vec && p.F == 64 && p.D == 64 && p.H <= 8 && want_emb && !p.bits && aligned16(p.planes) &&
-      aligned16(p.buckets) && lsh64_enabled())
+  // hot shape: F = D = 64 (D is irrelevant for a codes-only call), H <= 8; codes from that kernel only for H = 8
+  // without score / in-vocabulary table (the training forward and TorchLSHash.hash_points)
+  const bool d_ok = want_emb ? (p.D == 64 && aligned16(p.buckets)) : true;
+  const bool bits_ok = !p.bits || (p.H == 8 && !p.score && !p.table && (reinterpret_cast<uintptr_t>(p.bits) & 7u) == 0);
+  if (vec && p.F == 64 && d_ok && p.H <= 8 && bits_ok && aligned16(p.planes) && lsh64_enabled())
     return launch_lsh64(p.ids, p.B, p.feat, p.N, p.table, p.n_vocab, p.planes, static_cast<int>(p.H), p.buckets,
-                        p.other, p.score, p.out, st);
+                        p.other, p.score, p.out, st, p.bits);
   return vec ? dispatch_lsh<true>(p, st) : dispatch_lsh<false>(p, st);
 }
 

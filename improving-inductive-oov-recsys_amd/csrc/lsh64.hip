@@ -101,13 +101,14 @@ __device__ __forceinline__ float bcast8(int h, float b0, float b1) {
 
 // One tile = 16 lookups of one wave (4 rounds x 4 groups).  FULL tiles (all 16 rows < B) skip every
 // tail clamp and liveness test; only the last tile of a launch can be partial.
-template <int H, bool SCORE, bool STORE, bool LOOKUP, bool FULL>
+template <int H, bool SCORE, bool STORE, bool LOOKUP, bool FULL, bool BITS = false>
 __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, const float4 (&pw)[H], const float4 (&bw)[H],
                                            const int64_t (&idc)[4], unsigned B,
                                            const float* __restrict__ feat, int64_t N,
                                            const float* __restrict__ vtable, int64_t n_vocab,
                                            const float* __restrict__ other, float* __restrict__ score,
-                                           float* __restrict__ out) {
+                                           float* __restrict__ out, uint8_t* __restrict__ bits = nullptr) {
+  static_assert(!BITS || H == 8, "codes are written as one 8-byte word per lookup");
   constexpr int R = 4;
   // rows of the batch are addressed with 32-bit byte offsets from uniform bases (B <= kMaxRows64, checked by
   // the host): global_load/store with an SGPR base + VGPR offset instead of 64-bit VGPR pointers.
@@ -139,6 +140,15 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
   }
 
   float sc_all = 0.f;
+  uint32_t bits_lo = 0, bits_hi = 0;
+  // Row stores are held back to the end of the tile when the registers allow it (no user rows in flight): stores
+  // count against vmcnt like loads do, so a store issued between rounds makes the wait for the next gathered
+  // row also wait for everything issued before that store.
+#ifndef MI_EXP_DEFER
+#define MI_EXP_DEFER 1
+#endif
+  constexpr bool kDeferRows = MI_EXP_DEFER && STORE && !SCORE;
+  float4 emb_all[kDeferRows ? R : 1];
 #pragma unroll
   for (int r = 0; r < R; ++r) {
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -157,13 +167,29 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
       cnt = b0 + b1;                      // this bank's two planes ...
       cnt = cnt + dpp_f32<0x124>(cnt);    // ... + the other banks (small integers: exact in any order)
       cnt = cnt + dpp_f32<0x128>(cnt);
+      uint32_t code_lo = 0, code_hi = 0;  // BITS: the u8[8] code row of this lookup as one little-endian word
 #pragma unroll
       for (int h = 0; h < 8; ++h) {
         const float bit = bcast8(h, b0, b1);
-        acc.x = __builtin_fmaf(bit, bw[h].x, acc.x);
-        acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
-        acc.z = __builtin_fmaf(bit, bw[h].z, acc.z);
-        acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+        if (BITS) {
+          const uint32_t one = (__float_as_uint(bit) >> 23) & 1u;  // 1.0f = 0x3F800000, 0.0f = 0
+          if (h < 4) code_lo |= one << (8 * h);
+          else code_hi |= one << (8 * (h - 4));
+        }
+        if (SCORE || STORE) {
+          acc.x = __builtin_fmaf(bit, bw[h].x, acc.x);
+          acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
+          acc.z = __builtin_fmaf(bit, bw[h].z, acc.z);
+          acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+        }
+      }
+      if (BITS) {
+        if (!valid[r]) code_lo = code_hi = 0xFFFFFFFFu;  // invalid id: 0xFF bytes
+        if (FULL) {
+          if (l16 == r) { bits_lo = code_lo; bits_hi = code_hi; }
+        } else if (l16 == 0 && row[r] < B) {
+          *reinterpret_cast<uint2*>(bits + static_cast<size_t>(row[r]) * 8u) = make_uint2(code_lo, code_hi);
+        }
       }
     } else {
 #pragma unroll
@@ -208,7 +234,8 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
     if (LOOKUP && !oov[r]) emb = x[r];
     if (!valid[r]) emb = make_float4(qnan(), qnan(), qnan(), qnan());
     const bool live = FULL || row[r] < B;
-    if (STORE && live) *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (row[r] * 256u + l16 * 16u)) = emb;
+    if (STORE && !kDeferRows && live) *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (row[r] * 256u + l16 * 16u)) = emb;
+    if (STORE && kDeferRows) emb_all[r] = emb;
     if (SCORE) {
       const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
       if (FULL) {
@@ -218,6 +245,13 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
       }
     }
   }
+  if (kDeferRows) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if (FULL || row[r] < B) *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (row[r] * 256u + l16 * 16u)) = emb_all[r];
+  }
+  if (BITS && FULL && l16 < 4)  // the tile's 16 code rows (128 contiguous bytes) in one store, like the scores
+    *reinterpret_cast<uint2*>(bits + static_cast<size_t>(tile * 16u + l16 * 4u + grp) * 8u) = make_uint2(bits_lo, bits_hi);
   // ONE 16-lane store of the tile's 16 contiguous scores instead of four 4-lane stores (-0.4 us per launch:
   // the memory instructions a wave issues are worth more than its arithmetic here)
   if (SCORE && FULL && l16 < 4)
@@ -238,14 +272,15 @@ __device__ __forceinline__ void load_tile_ids(const int64_t* __restrict__ ids, u
 
 // 4 waves (256 threads) per workgroup: 1, 2, 8 and 16 waves measured 9.96 / 9.50 / 9.14 / 9.20 us against 9.09.
 constexpr int kWpb = 4, kBlk = 64 * kWpb;
-template <int H, bool SCORE, bool STORE, bool LOOKUP>
+template <int H, bool SCORE, bool STORE, bool LOOKUP, bool BITS = false>
 __global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restrict__ ids, unsigned B,
                                                        const float* __restrict__ feat, int64_t N,
                                                        const float* __restrict__ vtable, int64_t n_vocab,
                                                        const float* __restrict__ planes,
                                                        const float* __restrict__ buckets,
                                                        const float* __restrict__ other,
-                                                       float* __restrict__ score, float* __restrict__ out) {
+                                                       float* __restrict__ score, float* __restrict__ out,
+                                                       uint8_t* __restrict__ bits) {
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
   const unsigned ntiles = (B + 15) / 16;
   const unsigned nfull = B / 16;
@@ -262,7 +297,8 @@ __global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restric
   // global loads per lane (16 KiB of L1 traffic per wave) queued in front of the ids -> rows gathers
   // (-0.4 us in tools/microbench.hip).
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [2][H][64]
-  for (int i = threadIdx.x; i < 2 * H * 16; i += kBlk) {
+  constexpr bool kNeedBuckets = SCORE || STORE;  // codes-only launches have no bucket table
+  for (int i = threadIdx.x; i < (kNeedBuckets ? 2 : 1) * H * 16; i += kBlk) {
     const float* src = (i < H * 16) ? planes + i * 4 : buckets + (i - H * 16) * 4;
     *reinterpret_cast<float4*>(sw + i * 4) = *reinterpret_cast<const float4*>(src);
   }
@@ -271,14 +307,14 @@ __global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restric
 #pragma unroll
   for (int h = 0; h < H; ++h) {
     pw[h] = *reinterpret_cast<const float4*>(sw + (h * 16 + l16) * 4);
-    bw[h] = *reinterpret_cast<const float4*>(sw + (H * 16 + h * 16 + l16) * 4);
+    bw[h] = kNeedBuckets ? *reinterpret_cast<const float4*>(sw + (H * 16 + h * 16 + l16) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 
   while (tile < ntiles) {
     if (tile < nfull)
-      lsh64_tile<H, SCORE, STORE, LOOKUP, true>(tile, l16, grp, pw, bw, idc, B, feat, N, vtable, n_vocab, other, score, out);
+      lsh64_tile<H, SCORE, STORE, LOOKUP, true, BITS>(tile, l16, grp, pw, bw, idc, B, feat, N, vtable, n_vocab, other, score, out, bits);
     else
-      lsh64_tile<H, SCORE, STORE, LOOKUP, false>(tile, l16, grp, pw, bw, idc, B, feat, N, vtable, n_vocab, other, score, out);
+      lsh64_tile<H, SCORE, STORE, LOOKUP, false, BITS>(tile, l16, grp, pw, bw, idc, B, feat, N, vtable, n_vocab, other, score, out, bits);
     tile += tstep;
     if (tile < ntiles) {  // only when the grid was capped (B > 16 * 4 * kMaxGrid)
       load_tile_ids(ids, tile, B, l16, grp, idc);
@@ -286,18 +322,19 @@ __global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restric
   }
 }
 
-template <int H, bool SCORE, bool STORE, bool LOOKUP>
+template <int H, bool SCORE, bool STORE, bool LOOKUP, bool BITS = false>
 static int launch64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
                     const float* planes, const float* buckets, const float* other, float* score, float* out,
-                    hipStream_t st) {
+                    hipStream_t st, uint8_t* bits = nullptr) {
   // the kernel addresses batch rows with 32-bit byte offsets: launches of at most kMaxRows64 lookups
   constexpr int64_t kMaxRows64 = int64_t(1) << 23;  // x 256 B = 2 GiB
   for (int64_t b0 = 0; b0 < B; b0 += kMaxRows64) {
     const int64_t nb = (B - b0 < kMaxRows64) ? B - b0 : kMaxRows64;
-    const int grid = grid_for(nb, 16 * kWpb);  // kWpb waves x 16 lookups per workgroup pass  // kWpb waves x 16 lookups per workgroup pass
-    hipLaunchKernelGGL((lsh64_kernel<H, SCORE, STORE, LOOKUP>), dim3(grid), dim3(kBlk), 2 * H * 64 * sizeof(float), st,
+    const int grid = grid_for(nb, 16 * kWpb);  // kWpb waves x 16 lookups per workgroup pass
+    hipLaunchKernelGGL((lsh64_kernel<H, SCORE, STORE, LOOKUP, BITS>), dim3(grid), dim3(kBlk), 2 * H * 64 * sizeof(float), st,
                        ids + b0, static_cast<unsigned>(nb), feat, N, vtable, n_vocab, planes, buckets,
-                       other ? other + b0 * 64 : nullptr, score ? score + b0 : nullptr, out ? out + b0 * 64 : nullptr);
+                       other ? other + b0 * 64 : nullptr, score ? score + b0 : nullptr, out ? out + b0 * 64 : nullptr,
+                       bits ? bits + b0 * H : nullptr);
     if (int rc = check_launch()) return rc;
   }
   return MI_OOV_OK;
@@ -319,10 +356,16 @@ static int launch64_h(const int64_t* ids, int64_t B, const float* feat, int64_t 
 #undef MI_GO
 }
 
-// Host entry used by run_lsh (lsh.hip) when the shape qualifies: F = D = 64, 1 <= H <= 8.
+// Host entry used by run_lsh (lsh.hip) when the shape qualifies: F = D = 64, 1 <= H <= 8; `bits` (the u8[B,H] codes,
+// what the training forward keeps for its backward) only with H == 8, no score and no in-vocabulary table.
 int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
                  const float* planes, int H, const float* buckets, const float* other, float* score, float* out,
-                 hipStream_t st) {
+                 hipStream_t st, uint8_t* bits) {
+  if (bits) {
+    if (H != 8 || score || vtable) return MI_OOV_ERR_SHAPE;
+    if (out) return launch64<8, false, true, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);
+    return launch64<8, false, false, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);
+  }
   switch (H) {
 #define MI_CASE(HV) \
   case HV: return launch64_h<HV>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st);

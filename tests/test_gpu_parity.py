@@ -129,7 +129,7 @@ def test_bpr_golden(golden, oracle, ops, dev):
     assert np.allclose(fs, ref, rtol=RTOL, atol=1e-6)
 
 
-@pytest.mark.parametrize("B,N,F,H,D", [(1, 7, 64, 8, 64), (63, 100, 64, 8, 64), (4097, 3000, 64, 8, 64),
+@pytest.mark.parametrize("B,N,F,H,D", [(1, 7, 64, 8, 64), (63, 100, 64, 8, 64), (4097, 3000, 64, 8, 64), (16, 9, 64, 8, 64),
                                        (500, 400, 22, 8, 64), (333, 200, 4, 3, 1), (257, 150, 128, 16, 128),
                                        (100, 90, 200, 9, 36), (129, 77, 301, 40, 50), (64, 50, 640, 12, 256)])
 def test_lsh_shapes_vs_oracle(B, N, F, H, D, oracle, ops, dev):
@@ -149,6 +149,9 @@ def test_lsh_shapes_vs_oracle(B, N, F, H, D, oracle, ops, dev):
     o_emb, o_bits = oracle.lsh_embed(ids, feat, planes, buckets, want_bits=True)
     assert np.array_equal(bits, o_bits)
     assert bits_equal(emb, o_emb)
+    # the training forward asks for rows AND codes in one launch (ops._lsh_forward(want_bits=True))
+    emb_b, bits_b = ops._lsh_forward(T(ids, dev), T(feat, dev), T(planes, dev), T(buckets, dev), want_bits=True)
+    assert np.array_equal(bits_b.cpu().numpy(), o_bits) and bits_equal(emb_b.cpu().numpy(), o_emb)
     score, emb2 = ops.lsh_embed_score(T(ids, dev), T(feat, dev), T(planes, dev), T(buckets, dev), T(other, dev),
                                       want_emb=True)
     o_score, _ = oracle.lsh_embed_score(ids, feat, planes, buckets, other)
