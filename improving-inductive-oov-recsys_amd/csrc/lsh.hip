@@ -304,22 +304,30 @@ template <bool VEC>
 __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HB = 8;
-  float* sP = smem;
-  stage_padded(sP, p.planes, p.H, p.F, FP);
-  __syncthreads();
-
+  constexpr int R = 4;
   const int lane = threadIdx.x & 63;
   const int l16 = lane & 15;
   const int grp = lane >> 4;
   const int wv = threadIdx.x >> 6;
-  constexpr int R = 4;
   const int64_t ntiles = (p.B + 4 * R - 1) / (4 * R);
+  const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * 4 + wv;
+  // ids of the first tile before the planes are staged: the first hop of ids -> feature row -> bucket row
+  // overlaps the staging + barrier (same ordering as lsh64_kernel)
+  int64_t idn[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = tile0 * (4 * R) + r * 4 + grp;
+    idn[r] = p.ids[row < p.B ? row : p.B - 1];
+  }
+  float* sP = smem;
+  stage_padded(sP, p.planes, p.H, p.F, FP);
+  __syncthreads();
+
   const int H = static_cast<int>(p.H);
   const int nchunk = FP / 64;
   const int dchunks = static_cast<int>((p.D + 63) / 64);
 
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
-       tile += static_cast<int64_t>(gridDim.x) * 4) {
+  for (int64_t tile = tile0; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
     int64_t row[R], id[R];
     bool live[R], valid[R];
     int pop[R];
@@ -327,7 +335,7 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
     for (int r = 0; r < R; ++r) {
       row[r] = tile * (4 * R) + r * 4 + grp;
       live[r] = row[r] < p.B;
-      id[r] = p.ids[live[r] ? row[r] : p.B - 1];  // clamped, never branched on
+      id[r] = (tile == tile0) ? idn[r] : p.ids[live[r] ? row[r] : p.B - 1];  // clamped, never branched on
       valid[r] = live[r] && (static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(p.N));
       if (!valid[r]) id[r] = 0;
       pop[r] = 0;
@@ -367,9 +375,11 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
     // second dependent HBM round trip is paid once per tile, not once per lookup.
     int64_t bkt[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      bkt[r] = valid[r] ? (static_cast<int64_t>(H) + pop[r]) % p.n_buckets : -1;
-      if (p.idx && l16 == 0 && live[r]) p.idx[row[r]] = bkt[r];
+    for (int r = 0; r < R; ++r) bkt[r] = valid[r] ? (static_cast<int64_t>(H) + pop[r]) % p.n_buckets : -1;
+    if (p.idx && !p.out) {
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (l16 == 0 && live[r]) p.idx[row[r]] = bkt[r];
     }
     if (p.out) {
       for (int c = 0; c < dchunks; ++c) {
@@ -382,6 +392,11 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
           if (!valid[r]) v[r] = make_float4(qnan(), qnan(), qnan(), qnan());
           if (live[r]) store4<VEC>(p.out + row[r] * p.D, e, p.D, v[r]);
         }
+      }
+      if (p.idx) {  // after the gathers: a store between them would sit in front of their vmcnt waits
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (l16 == 0 && live[r]) p.idx[row[r]] = bkt[r];
       }
     }
   }
