@@ -441,6 +441,103 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(const float* __re
   }
 }
 
+// ---- evaluation: top-k of sparse candidate lists (uni250-style sampled ranking) --------------------------
+// The reference scatters the batch's sampled scores into a dense [users, items] matrix of -inf and runs
+// torch.topk on it (R/inductive/evaluator.py:118-134 -> R/evaluator/collector.py:158-167).  Here the dense
+// matrix never exists: segment s owns candidates [seg_ptr[s], seg_ptr[s+1]) given as (score, column); one
+// workgroup ranks them (rank sort in LDS up to 1024 candidates, radix select above) and keeps the best k
+// whose column lies in [col_lo, col_hi).  Missing entries (fewer than k valid candidates): (-inf, -1), where
+// the reference would pick arbitrary -inf columns -- which can never be positives.
+struct SegKeys {
+  const float* s;
+  const int64_t* c;
+  int64_t col_lo, col_hi;
+  __device__ __forceinline__ uint32_t operator()(int64_t i) const {
+    const int64_t col = c[i];
+    return (col >= col_lo && col < col_hi) ? order_key(s[i]) : 0u;  // 0: below every real key
+  }
+};
+
+__global__ __launch_bounds__(kBlock) void segment_topk_kernel(const float* __restrict__ scores,
+                                                              const int64_t* __restrict__ cols,
+                                                              const int64_t* __restrict__ seg_ptr, int64_t S, int k,
+                                                              int64_t col_lo, int64_t col_hi, float* __restrict__ vals,
+                                                              int64_t* __restrict__ idx) {
+  __shared__ uint64_t lc[1024];
+  const int64_t seg = blockIdx.x;
+  if (seg >= S) return;
+  const int64_t lo = seg_ptr[seg], n = seg_ptr[seg + 1] - lo;
+  float* vrow = vals + seg * k;
+  int64_t* irow = idx + seg * k;
+  const SegKeys keys{scores + lo, cols + lo, col_lo, col_hi};
+  if (n <= 0) {
+    for (int t = threadIdx.x; t < k; t += kBlock) { vrow[t] = -__builtin_inff(); irow[t] = -1; }
+    return;
+  }
+  if (n <= 1024) {
+    for (int i = threadIdx.x; i < n; i += kBlock)
+      lc[i] = (static_cast<uint64_t>(keys(i)) << 32) | (0xFFFFFFFFu - static_cast<uint32_t>(i));
+    __syncthreads();
+    emit_ranked(lc, static_cast<int>(n), static_cast<int>(n < k ? n : k), k, vrow, irow);
+  } else {
+    select_topk_row(keys, n, k, 0, vrow, irow);
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < k; t += kBlock) {  // candidate position -> column; drop the filtered ones
+    const int64_t pos = irow[t];
+    if (pos < 0) continue;
+    const int64_t col = cols[lo + pos];
+    if (col >= col_lo && col < col_hi) {
+      irow[t] = col;
+    } else {
+      irow[t] = -1;
+      vrow[t] = -__builtin_inff();
+    }
+  }
+}
+
+// rec.topk of the reference collector: out[s, j] = 1 when the j-th recommended column of segment s is one of its
+// positives, out[s, k] = number of positives (collector.py:161-166); positives are CSR (pos_ptr, pos_cols).
+__global__ __launch_bounds__(kBlock) void topk_hits_kernel(const int64_t* __restrict__ idx, int64_t S, int k,
+                                                           const int64_t* __restrict__ pos_ptr,
+                                                           const int64_t* __restrict__ pos_cols, int* __restrict__ out) {
+  const int64_t total = S * (k + 1);
+  for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
+       i += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int64_t s = i / (k + 1);
+    const int j = static_cast<int>(i % (k + 1));
+    const int64_t p0 = pos_ptr[s], p1 = pos_ptr[s + 1];
+    if (j == k) {
+      out[i] = static_cast<int>(p1 - p0);
+    } else {
+      const int64_t c = idx[s * k + j];
+      int hit = 0;
+      for (int64_t q = p0; q < p1; ++q) hit |= (pos_cols[q] == c) ? 1 : 0;
+      out[i] = (c >= 0) ? hit : 0;
+    }
+  }
+}
+
+extern "C" int mi_oov_segment_topk(const float* scores, const int64_t* cols, const int64_t* seg_ptr, int64_t S,
+                                   int64_t k, int64_t col_lo, int64_t col_hi, float* vals, int64_t* idx, void* stream) {
+  if (S < 0 || k <= 0 || k > 256) return MI_OOV_ERR_SHAPE;
+  if (S == 0) return MI_OOV_OK;
+  if (!scores || !cols || !seg_ptr || !vals || !idx) return MI_OOV_ERR_NULL;
+  hipLaunchKernelGGL(segment_topk_kernel, dim3(static_cast<unsigned>(S)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     scores, cols, seg_ptr, S, static_cast<int>(k), col_lo, col_hi, vals, idx);
+  return check_launch();
+}
+
+extern "C" int mi_oov_topk_hits(const int64_t* idx, int64_t S, int64_t k, const int64_t* pos_ptr, const int64_t* pos_cols,
+                                int32_t* out, void* stream) {
+  if (S < 0 || k <= 0) return MI_OOV_ERR_SHAPE;
+  if (S == 0) return MI_OOV_OK;
+  if (!idx || !pos_ptr || !pos_cols || !out) return MI_OOV_ERR_NULL;
+  hipLaunchKernelGGL(topk_hits_kernel, dim3(grid_for(S * (k + 1), kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), idx,
+                     S, static_cast<int>(k), pos_ptr, pos_cols, out);
+  return check_launch();
+}
+
 static size_t full_sort_lds() { return static_cast<size_t>(BM + BN) * LDK * sizeof(float); }
 
 template <bool VEC, int EPI>

@@ -179,40 +179,44 @@ def augment_with_oov(batch, cfg, user_key, item_key):
     return {k: torch.cat((batch[k], extra[k]))[perm] for k in batch}
 
 
-# ---- metrics for one positive ranked against sampled negatives ---------------------------------------------
-def rank_metrics(rank, topk):
-    """rank: int64[P], 0 = the positive scored highest.  Single-positive forms of RecBole's metrics."""
-    out = {}
-    for k in topk:
-        hit = (rank < k).float()
-        out[f"recall@{k}"] = hit.mean().item()
-        out[f"hit@{k}"] = hit.mean().item()
-        out[f"mrr@{k}"] = (hit / (rank.float() + 1)).mean().item()
-        out[f"ndcg@{k}"] = (hit / torch.log2(rank.float() + 2)).mean().item()
-    return out
-
-
+# ---- uni250 evaluation: per user, its positives followed by 250 sampled negatives per positive ------------------
 def evaluate(model, users, items, tot_items, cfg, n_users, n_items, device, gen):
-    """uni250: each (user, positive) row followed by its negatives, scored through model.predict."""
-    ukey, ikey, nneg = cfg["USER_ID_FIELD"], cfg["ITEM_ID_FIELD"], cfg["eval_negatives"]
-    per = max(1, cfg["eval_batch_size"] // (nneg + 1))
-    ranks = []
+    """Batches shaped like NegSampleEvalDataLoader's (general_dataloader.py:157-190: per user the positives first,
+    then `eval_negatives` sampled items per positive; users packed until eval_batch_size rows), scored through
+    model.predict and ranked by the sampled-ranking evaluator (evaluator.py: segment top-k + hits kernels, the
+    reference's metric arithmetic).  NaN scores (all-zero lsh codes) are ranked as torch.topk ranks them: first."""
+    from .evaluator import SampledRankingEvaluator
+    ukey, ikey, nneg = cfg["USER_ID_FIELD"], cfg["ITEM_ID_FIELD"], int(cfg["eval_negatives"])
+    ev = SampledRankingEvaluator(cfg["topk"], cfg["metrics"] or ("recall", "mrr", "ndcg", "hit", "precision"),
+                                 n_old_users=n_users, n_old_items=n_items)
+    order = torch.argsort(users, stable=True)
+    su, si = users[order], items[order]
+    uniq, counts = torch.unique_consecutive(su, return_counts=True)
+    starts = torch.cumsum(counts, 0) - counts
+    rows_per_user = (counts * (1 + nneg)).tolist()
+    lo_u, budget = 0, int(cfg["eval_batch_size"])
     with torch.no_grad():
-        for lo in range(0, len(users), per):
-            u, pos = users[lo:lo + per], items[lo:lo + per]
-            neg = torch.randint(1, tot_items, (len(u), nneg), generator=gen, device=device)
-            cand = torch.cat((pos[:, None], neg), dim=1)
-            scores = model.predict({ukey: u[:, None].expand_as(cand).reshape(-1), ikey: cand.reshape(-1)})
-            scores = scores.view(len(u), nneg + 1)
-            scores = torch.nan_to_num(scores, nan=-float("inf"))  # all-zero lsh codes embed to NaN
-            ranks.append((scores[:, 1:] > scores[:, :1]).sum(1))
-    rank = torch.cat(ranks)
-    res = {"overall": rank_metrics(rank, cfg["topk"])}
-    for name, mask in (("old_users", users < n_users), ("new_users", users >= n_users),
-                       ("old_items", items < n_items), ("new_items", items >= n_items)):
-        if mask.any():
-            res[name] = rank_metrics(rank[mask], cfg["topk"])
-    return res
+        while lo_u < len(rows_per_user):
+            hi_u, rows = lo_u + 1, rows_per_user[lo_u]
+            while hi_u < len(rows_per_user) and rows + rows_per_user[hi_u] <= budget:
+                rows += rows_per_user[hi_u]
+                hi_u += 1
+            cnt = counts[lo_u:hi_u]
+            nu = hi_u - lo_u
+            local = torch.arange(nu, device=device)
+            pos_u = torch.repeat_interleave(local, cnt)
+            pos_i = si[int(starts[lo_u]):int(starts[lo_u]) + int(cnt.sum())]
+            neg_u = torch.repeat_interleave(local, cnt * nneg)
+            neg_i = torch.randint(1, tot_items, (neg_u.numel(),), generator=gen, device=device)
+            # rows of one user are contiguous: its positives, then its negatives (stable sort by user)
+            row_idx = torch.cat((pos_u, neg_u))
+            col_idx = torch.cat((pos_i, neg_i))
+            perm = torch.sort(row_idx, stable=True).indices
+            row_idx, col_idx = row_idx[perm], col_idx[perm]
+            scores = model.predict({ukey: uniq[lo_u:hi_u][row_idx], ikey: col_idx.clone()})
+            ev.eval_batch(scores, uniq[lo_u:hi_u], row_idx, col_idx, pos_u, pos_i)
+            lo_u = hi_u
+    return ev.evaluate()
 
 
 def run(args):

@@ -541,3 +541,39 @@ def score_topk(U, E, k, n_skip_low=0):
                                        C.ptr(ws), C.stream_of(U))
     C.check(rc, "mi_oov_score_topk")
     return vals, idx
+
+
+def segment_topk(scores, cols, seg_ptr, k, col_lo=0, col_hi=None):
+    """Top-k of sparse candidate lists: what torch.topk returns on the dense -inf score matrix of
+    InductiveEvaluator.neg_sample_batch_eval (R/inductive/evaluator.py:118-134), without building it.
+    scores f32[M], cols i64[M], seg_ptr i64[S+1] -> (vals f32[S,k], idx i64[S,k]); (-inf, -1) where a segment
+    has fewer than k candidates with col_lo <= column < col_hi."""
+    scores, cols, seg_ptr = _f32(scores, "scores"), _ids(cols, "cols"), _ids(seg_ptr, "seg_ptr")
+    S = seg_ptr.numel() - 1
+    if scores.numel() != cols.numel():
+        raise ValueError(f"{scores.numel()} scores for {cols.numel()} columns")
+    if not 0 < k <= 256:
+        raise ValueError("segment_topk supports 1 <= k <= 256")
+    vals = torch.empty((S, k), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((S, k), dtype=torch.int64, device=scores.device)
+    with C.on_device(scores):
+        rc = C.lib().mi_oov_segment_topk(C.ptr(scores), C.ptr(cols), C.ptr(seg_ptr), S, k, int(col_lo),
+                                         int(col_hi) if col_hi is not None else (1 << 62), C.ptr(vals), C.ptr(idx),
+                                         C.stream_of(scores))
+    C.check(rc, "mi_oov_segment_topk")
+    return vals, idx
+
+
+def topk_hits(idx, pos_ptr, pos_cols):
+    """The collector's rec.topk block (collector.py:161-166): int32[S, k+1] = hit flags of idx[s,:] against the
+    positives of segment s (CSR) followed by the positive count."""
+    idx, pos_ptr, pos_cols = _ids(idx, "idx"), _ids(pos_ptr, "pos_ptr"), _ids(pos_cols, "pos_cols")
+    S, k = idx.shape
+    out = torch.empty((S, k + 1), dtype=torch.int32, device=idx.device)
+    if pos_cols.numel() == 0:
+        pos_cols = torch.zeros((1,), dtype=torch.int64, device=idx.device)
+    with C.on_device(idx):
+        rc = C.lib().mi_oov_topk_hits(C.ptr(idx), S, k, C.ptr(pos_ptr), C.ptr(pos_cols), C.ptr(out), C.stream_of(idx))
+    C.check(rc, "mi_oov_topk_hits")
+    return out
+

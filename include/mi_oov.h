@@ -248,6 +248,20 @@ int mi_oov_score_topk(const float* U, int64_t B, const float* E, int64_t N, int6
                       int64_t k, int64_t n_skip_low,
                       float* vals, int64_t* idx, void* workspace, void* stream);
 
+/* Evaluation (R/inductive/evaluator.py:118-134 neg_sample_batch_eval -> R/evaluator/collector.py:158-167): the
+ * reference scatters the sampled scores of a batch into a dense [users, items] matrix of -inf and calls
+ * torch.topk; here segment s (one user of the batch) owns candidates [seg_ptr[s], seg_ptr[s+1]) given as
+ * (scores[i], cols[i]) and the dense matrix never exists.  Best k (<= 256) candidates with col_lo <= column <
+ * col_hi, larger score first, NaN highest, ties -> earlier candidate; (-inf, -1) where fewer than k qualify.
+ *   scores f32[M], cols i64[M], seg_ptr i64[S+1] -> vals f32[S,k], idx i64[S,k] (item columns).              */
+int mi_oov_segment_topk(const float* scores, const int64_t* cols, const int64_t* seg_ptr, int64_t S, int64_t k,
+                        int64_t col_lo, int64_t col_hi, float* vals, int64_t* idx, void* stream);
+
+/* The collector's "rec.topk" block (collector.py:161-166): out[s,j] = 1 iff idx[s,j] is among the positives of
+ * segment s (CSR pos_ptr i64[S+1], pos_cols i64[nnz]); out[s,k] = number of positives.  out i32[S,k+1].        */
+int mi_oov_topk_hits(const int64_t* idx, int64_t S, int64_t k, const int64_t* pos_ptr, const int64_t* pos_cols,
+                     int32_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -232,3 +232,25 @@ def score_topk(U, E, k, n_skip_low=0):
     lib().oov_score_topk(_p(U), _c(U.shape[0]), _p(E), _c(E.shape[0]), _c(U.shape[1]), _c(k), _c(n_skip_low),
                          _p(vals), _p(idx))
     return vals, idx
+
+
+def segment_topk(scores, cols, seg_ptr, k, col_lo=0, col_hi=2 ** 62):
+    scores = _f32(scores)
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    seg_ptr = np.ascontiguousarray(seg_ptr, dtype=np.int64)
+    S = seg_ptr.shape[0] - 1
+    vals = np.empty((S, k), np.float32)
+    idx = np.empty((S, k), np.int64)
+    lib().oov_segment_topk(_p(scores), _p(cols), _p(seg_ptr), _c(S), _c(k), _c(col_lo), _c(col_hi), _p(vals), _p(idx))
+    return vals, idx
+
+
+def topk_hits(idx, pos_ptr, pos_cols):
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    pos_ptr = np.ascontiguousarray(pos_ptr, dtype=np.int64)
+    pos_cols = np.ascontiguousarray(pos_cols, dtype=np.int64)
+    S, k = idx.shape
+    out = np.empty((S, k + 1), np.int32)
+    lib().oov_topk_hits(_p(idx), _c(S), _c(k), _p(pos_ptr), _p(pos_cols), _p(out))
+    return out
+

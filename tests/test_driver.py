@@ -78,7 +78,7 @@ def test_end_to_end(flags, tmp_path, monkeypatch, dev):
                                      "--user_oov_buckets=8", "--item_oov_buckets=8", "--epochs=4",
                                      "--learning_rate=0.01", "--train_batch_size=512"] + flags)
     results, model = driver.run(args)
-    for slice_name in ("overall", "old_users", "new_users", "old_items", "new_items"):
+    for slice_name in ("overall", "old_users", "new_users", "old_old", "old_new", "new_old", "new_new", "old_items", "new_items"):
         assert slice_name in results
         for k, v in results[slice_name].items():
             assert np.isfinite(v) and 0.0 <= v <= 1.0, (slice_name, k, v)

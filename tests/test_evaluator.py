@@ -1,0 +1,108 @@
+"""Sampled-ranking evaluation against what the REAL reference's Collector + Evaluator
+produced for the same sparse batches (tests/golden/eval_uni.npz, made by make_golden_eval.py)."""
+import numpy as np
+import pytest
+import torch
+
+
+def _batches(z):
+    for b in range(int(z["n_batches"])):
+        yield (z[f"b{b}_scores"], z[f"b{b}_row_idx"], z[f"b{b}_col_idx"], z[f"b{b}_pos_u"], z[f"b{b}_pos_i"])
+
+
+def _ptr(group, n):
+    return np.concatenate(([0], np.cumsum(np.bincount(group, minlength=n)))).astype(np.int64)
+
+
+def test_oracle_rec_topk_and_metrics_match_reference(golden, oracle):
+    """CPU: oracle segment_topk + topk_hits == the reference collector's rec.topk block; the host-side metric
+    arithmetic == the reference Evaluator's values."""
+    import mi_oov
+    z = golden("eval_uni.npz")
+    kmax = int(z["topk"].max())
+    blocks = []
+    for scores, row, col, pu, pi in _batches(z):
+        n = int(pu[-1]) + 1
+        _, idx = oracle.segment_topk(scores, col, _ptr(row, n), kmax)
+        blocks.append(oracle.topk_hits(idx, _ptr(pu, n), pi))
+    rec = np.concatenate(blocks)
+    assert np.array_equal(rec, z["rec_topk"])
+    got = mi_oov.evaluator.topk_metrics(rec, [int(k) for k in z["topk"]])
+    for name, want in zip(z["metric_names"], z["metric_values"]):
+        assert got[str(name)] == pytest.approx(float(want), abs=1e-12), name
+
+
+def test_oracle_segment_topk_edges(oracle):
+    scores = np.array([1, 5, np.nan, 2, 9, 7, 7], np.float32)
+    cols = np.array([10, 11, 12, 13, 14, 15, 16])
+    seg = np.array([0, 4, 4, 7])  # an empty segment in the middle
+    v, i = oracle.segment_topk(scores, cols, seg, 3)
+    assert i.tolist() == [[12, 11, 13], [-1, -1, -1], [14, 15, 16]]  # NaN first, ties -> earlier candidate
+    v, i = oracle.segment_topk(scores, cols, seg, 3, 11, 16)        # column filter [11, 16)
+    assert i.tolist() == [[12, 11, 13], [-1, -1, -1], [14, 15, -1]] and np.isneginf(v[2, 2])
+
+
+@pytest.mark.gpu
+def test_gpu_rec_topk_matches_reference(golden, oracle, dev):
+    import mi_oov
+    z = golden("eval_uni.npz")
+    topk = [int(k) for k in z["topk"]]
+    col = mi_oov.evaluator.RankingCollector(topk)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    for scores, row, c, pu, pi in _batches(z):
+        col.eval_batch_collect(T(scores), T(row), T(c), T(pu), T(pi))
+    rec = col.get_data_struct().cpu().numpy()
+    assert np.array_equal(rec, z["rec_topk"])
+    got = mi_oov.evaluator.topk_metrics(rec, topk)
+    for name, want in zip(z["metric_names"], z["metric_values"]):
+        assert got[str(name)] == pytest.approx(float(want), abs=1e-12), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("S,lens,k", [(5, (0, 40), 10), (64, (900, 1200), 20), (3, (5000, 30000), 256), (300, (1, 8), 17)])
+def test_gpu_segment_topk_vs_oracle(S, lens, k, oracle, dev):
+    from mi_oov import ops
+    rng = np.random.default_rng(S + k)
+    n = rng.integers(lens[0], lens[1] + 1, S)
+    seg = np.concatenate(([0], np.cumsum(n))).astype(np.int64)
+    M = int(seg[-1])
+    scores = rng.standard_normal(M).astype(np.float32)
+    scores[rng.random(M) < 0.02] = np.nan
+    scores[rng.random(M) < 0.05] = 0.25          # ties
+    scores[rng.random(M) < 0.01] = -np.inf
+    cols = rng.integers(0, 5000, M)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    for lo, hi in ((0, None), (1000, 3500)):
+        v, i = ops.segment_topk(T(scores), T(cols), T(seg), k, lo, hi)
+        ov, oi = oracle.segment_topk(scores, cols, seg, k, lo, hi if hi is not None else 2 ** 62)
+        assert np.array_equal(i.cpu().numpy(), oi)
+        assert np.array_equal(np.nan_to_num(v.cpu().numpy(), nan=7e9), np.nan_to_num(ov, nan=7e9))
+    pos_u = np.sort(rng.integers(0, S, 4 * S))
+    pos_i = rng.integers(0, 5000, 4 * S)
+    pptr = np.concatenate(([0], np.cumsum(np.bincount(pos_u, minlength=S)))).astype(np.int64)
+    assert np.array_equal(ops.topk_hits(i, T(pptr), T(pos_i)).cpu().numpy(), oracle.topk_hits(oi, pptr, pos_i))
+
+
+@pytest.mark.gpu
+def test_gpu_collector_dedups_and_slices(dev):
+    """Duplicate (user, item) candidates count once (dense scatter semantics); item / user slices restrict
+    candidates, positives and rows."""
+    import mi_oov
+    T = lambda a, dt=torch.int64: torch.tensor(a, dtype=dt, device=dev)  # noqa: E731
+    # user 0: positive item 5 (also sampled as a negative with a higher score), user 1: positives 7 (old) and 12 (new)
+    row = T([0, 0, 0, 0, 1, 1, 1, 1, 1])
+    col = T([5, 9, 5, 11, 7, 12, 3, 10, 4])
+    sc = T([1.0, 0.5, 9.0, 2.0, 3.0, 2.5, 9.0, 8.0, 1.0], torch.float32)
+    pu, pi = T([0, 1, 1]), T([5, 7, 12])
+    c = mi_oov.evaluator.RankingCollector([2])
+    rec = c.eval_batch_collect(sc, row, col, pu, pi).cpu().numpy()
+    assert rec.tolist() == [[0, 1, 1], [0, 0, 2]]            # user 0: 11 (2.0), 5 (1.0: first occurrence kept)
+    rec = c.eval_batch_collect(sc, row, col, pu, pi, col_hi=10).cpu().numpy()    # old items only (< 10)
+    assert rec.tolist() == [[1, 0, 1], [0, 1, 1]]            # user 1: 3 (9.0), 7 (3.0); positive 12 not counted
+    rec = c.eval_batch_collect(sc, row, col, pu, pi, col_lo=10, user_mask=T([False, True], torch.bool)).cpu().numpy()
+    assert rec.tolist() == [[0, 1, 1]]                       # user 1, new items: 10 (8.0), 12 (2.5)
+    ev = mi_oov.evaluator.SampledRankingEvaluator([1, 2], ("recall", "hit"), n_old_users=1, n_old_items=10)
+    ev.eval_batch(sc, T([0, 4]), row, col, pu, pi)           # user ids 0 (old) and 4 (new)
+    res = ev.evaluate()
+    assert set(res) == {"overall", "old_users", "new_users", "old_old", "old_new", "new_old", "new_new", "old_items", "new_items"}
+    assert res["new_new"]["recall@2"] == 1.0 and res["old_old"]["hit@1"] == 1.0 and res["old_users"]["recall@2"] == 1.0
