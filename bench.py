@@ -126,7 +126,9 @@ def pipelined(args, step, per_lookup):
     together.  NOT the headline (`value` times the K steps serialised, as the contract's single-stream HIP-event
     timing implies); it shows what the same kernel delivers to a serving loop that keeps several batches in
     flight: the launch -> ids -> rows -> store chain of one batch hides under the row traffic of the others."""
-    C, K, B = args.in_flight, args.steps, args.batch
+    C, K, B = min(args.in_flight, args.steps), args.steps, args.batch
+    if C < 2:
+        return None
     with torch.no_grad():
         streams = [torch.cuda.Stream() for _ in range(C)]
         graphs = []
@@ -330,7 +332,9 @@ def main():
         }
         out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
         if world == 1 and use_graph and args.in_flight > 1:
-            out["pipelined"] = pipelined(args, step, per_lookup)
+            pl = pipelined(args, step, per_lookup)
+            if pl is not None:
+                out["pipelined"] = pl
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, feat, planes, buckets, args.cpu_seconds)
         print(json.dumps(out), flush=True)

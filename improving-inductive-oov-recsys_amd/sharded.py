@@ -36,7 +36,7 @@ def exchange_lookup(ids, rows_per_rank, width, local_fn, group=None):
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     dev = ids.device
-    owner = torch.clamp(torch.div(ids, rows_per_rank, rounding_mode="floor"), 0, world - 1)
+    owner = torch.clamp(torch.div(ids, max(1, rows_per_rank), rounding_mode="floor"), 0, world - 1)
     order = torch.argsort(owner, stable=True)
     send_ids = ids[order].contiguous()
     send_counts = torch.bincount(owner, minlength=world)
@@ -86,6 +86,50 @@ class ShardedLSHTable:
             return self._local_embed(local_ids, self.feat_local, planes, buckets)
 
         return exchange_lookup(ids, self.per, D, local_fn, self.group)
+
+
+class ShardedSLSHTable:
+    """slsh over row-sharded tables (BASELINE config 4: 1e8 x 64 features + a 1e8 x 128 bucket/item table, 8 ways).
+
+    Two owner-computes exchanges per batch, neither moving an F-wide row:
+        ids  -> owner of the FEATURE row: popcount bucket id (single_lsh_embedder.py:82-87)   8 B out, 8 B back
+        idx  -> owner of the BUCKET row:  row gather (single_lsh_embedder.py:100,108)         8 B out, 4*D B back
+    feat_local / buckets_local are this rank's contiguous row blocks (shard_bounds).  With the reference's
+    popcount ids every lookup lands in rows [bits_req, 2*bits_req] of the bucket table, i.e. on rank 0 -- the
+    second exchange is then an all-to-one; that is the reference's arithmetic, not a property of the exchange."""
+
+    def __init__(self, feat_local, n_feat_rows, buckets_local, n_buckets, group=None, local_index=None, local_gather=None):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.n_feat_rows, self.n_buckets = n_feat_rows, n_buckets
+        flo, fhi, self.per_feat = shard_bounds(n_feat_rows, self.world, self.rank)
+        blo, bhi, self.per_bucket = shard_bounds(n_buckets, self.world, self.rank)
+        if feat_local.shape[0] != fhi - flo or buckets_local.shape[0] != bhi - blo:
+            raise ValueError(f"rank {self.rank} must hold feature rows [{flo},{fhi}) and bucket rows [{blo},{bhi})")
+        self.feat_local, self.buckets_local = feat_local, buckets_local
+        if local_index is None or local_gather is None:
+            from . import ops
+            local_index = local_index or (lambda ids, feat, planes, nb: ops.slsh_index(ids, feat, planes, nb))
+            local_gather = local_gather or ops.gather_rows
+        self._local_index, self._local_gather = local_index, local_gather
+
+    def embed(self, ids, planes):
+        D = self.buckets_local.shape[1]
+
+        def index_fn(local_ids):
+            if local_ids.numel() == 0:
+                return torch.empty((0, 1), dtype=torch.int64, device=local_ids.device)
+            return self._local_index(local_ids, self.feat_local, planes, self.n_buckets).view(-1, 1)
+
+        def gather_fn(local_idx):
+            if local_idx.numel() == 0:
+                return torch.empty((0, D), dtype=torch.float32, device=local_idx.device)
+            return self._local_gather(local_idx, self.buckets_local)
+
+        idx = exchange_lookup(ids, self.per_feat, 1, index_fn, self.group).view(-1)  # -1 for ids outside the table
+        # invalid lookups (-1) go to rank 0 as local row -1, which the gather kernel answers with a NaN row
+        return exchange_lookup(idx, self.per_bucket, D, gather_fn, self.group), idx
 
 
 def merge_topk(vals, idx, k, group=None):

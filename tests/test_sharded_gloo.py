@@ -52,6 +52,34 @@ def _worker(rank, world, port, ret):
             want = oracle.lsh_embed(ids, feat, planes, buckets)
             same = got.shape == want.shape and np.array_equal(np.nan_to_num(got, nan=7.0), np.nan_to_num(want, nan=7.0))
             ok = ok and same
+        # slsh over a row-sharded feature table AND a row-sharded bucket table (BASELINE config 4), two exchanges
+        NB, D2 = 777, 20
+        planes_s = rng.standard_normal((10, F), dtype=np.float32)  # bits_req of 777 buckets
+        big = rng.standard_normal((NB, D2), dtype=np.float32)
+        blo, bhi, _ = sharded.shard_bounds(NB, world, rank)
+
+        def local_index(local_ids, feat_local, planes_t, nb):
+            _, idx = oracle.slsh_embed(local_ids.numpy(), feat_local.numpy(), planes_t.numpy(),
+                                       np.zeros((nb, 1), np.float32))
+            return torch.from_numpy(idx)
+
+        def local_gather(local_idx, rows):
+            li = local_idx.numpy()
+            out = np.full((len(li), rows.shape[1]), np.nan, np.float32)
+            okm = (li >= 0) & (li < rows.shape[0])
+            out[okm] = rows.numpy()[li[okm]]
+            return torch.from_numpy(out)
+
+        st = sharded.ShardedSLSHTable(torch.from_numpy(feat[lo:hi]), N, torch.from_numpy(big[blo:bhi]), NB,
+                                      local_index=local_index, local_gather=local_gather)
+        for name, ids in cases.items():
+            ids = ids.astype(np.int64)
+            if name == "edges":
+                ids = np.concatenate((ids, [N + 3, -2]))  # outside the table: NaN rows, index -1
+            got, gidx = st.embed(torch.from_numpy(ids), torch.from_numpy(planes_s))
+            want, widx = oracle.slsh_embed(ids, feat, planes_s, big)
+            ok = ok and np.array_equal(gidx.numpy(), widx)
+            ok = ok and np.array_equal(np.nan_to_num(got.numpy(), nan=7.0), np.nan_to_num(want, nan=7.0))
         # top-k merge over an item-sharded catalogue
         U = rng.standard_normal((9, D), dtype=np.float32)
         E = rng.standard_normal((N, D), dtype=np.float32)
