@@ -245,7 +245,7 @@ def main():
         graph = None
         if use_graph:
             for i in range(3):  # first-use initialisation outside the capture
-                step(i)
+                step(i % total)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
