@@ -167,7 +167,7 @@ def pmc_traffic(kernel_prefix):
         except (OSError, ValueError):
             continue
         for k, v in d.get("pmc_per_launch", {}).items():
-            if k.startswith(kernel_prefix) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            if k.startswith(kernel_prefix.rstrip(">")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
                 best = (2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0
     return best
 
@@ -325,7 +325,7 @@ def main():
                        "table": "row-sharded + all-to-all" if (args.sharded and world > 1) else "replicated per GPU",
                        "launches_per_step": "lsh_embed_score" if fused else "lsh_embed + rowdot",
                        "launch_mode": "one HIP graph of the K launches, replayed once" if use_graph else "one launch per step from the host"},
-            "roofline": {"bound": "hbm", "kernel": "lsh64_kernel<8, true, false, false>" if fused else "lsh64_kernel<8, false, true, false>",
+            "roofline": {"bound": "hbm", "kernel": "lsh64_kernel<8, true, false, false, false>" if fused else "lsh64_kernel<8, false, true, false, false>",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "bytes_per_lookup": per_lookup, "lookups_per_launch": B, "avg_launch_us": kern_ms * 1e3,
                          "traffic": None},

@@ -1,10 +1,9 @@
 #!/usr/bin/env python3
 """Per-kernel timing on the BASELINE-sized workloads (developer tool, GPU box only).
 
-Back-to-back launches on one stream, fresh ids per launch, HIP events at both ends (includes the
-Python launch overhead when the kernel is shorter than ~8 us; run under `rocprofv3 --kernel-trace
---stats` for kernel-only durations).  Prints one JSON line per case with the algorithmic bytes /
-flops of SURVEY.md section 8(d)."""
+Launches on one stream, fresh ids per launch, replayed as one HIP graph with HIP events at both ends (run
+under `rocprofv3 --kernel-trace --stats` for per-kernel durations: tools/profile_all.sh).  Prints one JSON
+line per case with the algorithmic bytes / flops of SURVEY.md section 8(d)."""
 import argparse
 import json
 import os
@@ -18,10 +17,31 @@ from mi_oov import ops  # noqa: E402
 
 
 def timeit(fn, n_iter, warm=5):
+    """us per launch: the n_iter launches are captured into one HIP graph and replayed (no host launch cost,
+    reproducible to ~0.01 us); ops that cannot be captured fall back to back-to-back eager launches."""
     for i in range(warm):
         fn(i)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        gr = torch.cuda.CUDAGraph()
+        keep = []
+        with torch.cuda.graph(gr):
+            for i in range(n_iter):
+                keep.append(fn(warm + i)) if i < 4 else fn(warm + i)
+        gr.replay()
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            a.record()
+            gr.replay()
+            b.record()
+            torch.cuda.synchronize()
+            t = a.elapsed_time(b) * 1e3 / n_iter
+            best = t if best is None else min(best, t)
+        return best
+    except Exception:  # noqa: BLE001 -- capture refused (a sync inside the op): time it eagerly
+        torch.cuda.synchronize()
     a.record()
     for i in range(n_iter):
         fn(warm + i)
@@ -55,6 +75,23 @@ def main():
     E = torch.randn((Ns, D), generator=g, device=dev)
     planes16 = torch.randn((16, F), generator=g, device=dev)
     buckets16 = torch.randn((16, D), generator=g, device=dev)
+    hashes = torch.rand((B, 1024), generator=g, device=dev)
+    Ws = [torch.randn((o, i_), generator=g, device=dev) / i_ ** 0.5 for i_, o in ((1024, 512), (512, 512), (512, 512), (512, D))]
+    bs = [torch.zeros((w.shape[0],), device=dev) for w in Ws]
+
+    def mlp(x):
+        for j, (w, b_) in enumerate(zip(Ws, bs)):
+            x = ops.linear_act(x, w, b_, "gelu" if j < 3 else "sigmoid")
+        return x
+
+    bits8 = (torch.rand((B, H), generator=g, device=dev) < 0.5).to(torch.uint8)
+    bits8[:, 0] = 1
+    idx9 = torch.randint(0, 9, (8, B), generator=g, device=dev)
+    gtab = torch.zeros((N, D), device=dev)
+    n_seg, per_seg = 4096, 1506  # 6 positives x (1 + 250) candidates per user
+    seg_scores = torch.randn((n_seg * per_seg,), generator=g, device=dev)
+    seg_cols = torch.randint(1, N, (n_seg * per_seg,), generator=g, device=dev)
+    seg_ptr = torch.arange(0, n_seg * per_seg + 1, per_seg, device=dev)
     # name -> (callable, units per launch, bytes per unit, flops per unit, unit)
     cases = {
         "lsh_embed H=8 (hot kernel, rows stored)": (lambda i: ops.lsh_embed(ids[i], feat, planes, buckets), B, 8 + 4 * F + 4 * D, 0),
@@ -73,6 +110,11 @@ def main():
         "broadcast_rows": (lambda i: ops.broadcast_rows(emb[0], B), B, 4 * D, 0),
         "full_sort_scores B=4096 N=50000": (lambda i: ops.full_sort_scores(U, E), Bs * Ns, 4, 2 * D),
         "score_topk k=20 B=4096 N=50000": (lambda i: ops.score_topk(U, E, 20, 1), Bs * Ns, 0, 2 * D),
+        "dhe MLP 1024-512-512-512-64 (4 x linear_act)": (lambda i: mlp(hashes), B, 0, 2 * (1024 * 512 + 2 * 512 * 512 + 512 * 64)),
+        "lsh_embed_backward H=8 (bucket-table grad)": (lambda i: ops.lsh_embed_backward(bits8, users[i % 8]), B, H + 4 * D, 0),
+        "slsh_embed_backward nb=9": (lambda i: ops.slsh_embed_backward(idx9[i % 8], users[i % 8], 9), B, 8 + 4 * D, 0),
+        "scatter_add_rows into 10M x 64 (gather backward)": (lambda i: ops.scatter_add_rows(ids[i], users[i % 8], N, out=gtab), B, 8 + 12 * D, 0),
+        "segment_topk 4096 users x 1506 candidates k=20": (lambda i: ops.segment_topk(seg_scores, seg_cols, seg_ptr, 20), seg_scores.numel(), 12, 0),
     }
     with torch.no_grad():
         for name, (fn, units, bpu, fpu) in cases.items():
