@@ -41,3 +41,25 @@ def test_argument_validation_without_gpu(lib):
     assert lib.mi_oov_mapper_map(None, 5, 9, 1, 1, None, None) == -3  # unknown hash kind
     assert lib.mi_oov_siphash24_mod(None, 5, None, 4, 1000, None, None) == -2  # mod not a power of two
     assert lib.mi_oov_col_mean_workspace(10_000_000, 64) == 1023 * 64  # <= 1024 row partitions of 9776 rows
+
+
+def test_argument_validation_of_the_widened_entry_points(lib):
+    """Error codes of the backward / evaluation / scoring entry points (all checked before any HIP call)."""
+    assert lib.mi_oov_lsh_backward_workspace(65536, 8, 64) == 1024 * 8 * 64
+    assert lib.mi_oov_lsh_backward_workspace(0, 8, 64) == 0
+    assert lib.mi_oov_lsh_embed_backward(None, None, 5, 8, 300, None, None, None) == -2      # D > 256
+    assert lib.mi_oov_lsh_embed_backward(None, None, 5, 8, 64, None, None, None) == -1       # NULL output
+    assert lib.mi_oov_slsh_embed_backward(None, None, 5, 0, 64, None, None, None) == -2      # no buckets
+    assert lib.mi_oov_scatter_add_rows(None, 0, None, 10, 64, None, None) == 0               # nothing to add
+    assert lib.mi_oov_scatter_add_rows(None, 5, None, 10, 64, None, None) == -1
+    assert lib.mi_oov_scatter_add_rows(None, 5, None, 10, 0, None, None) == -2
+    assert lib.mi_oov_segment_topk(None, None, None, 0, 10, 0, 100, None, None, None) == 0   # no segments
+    assert lib.mi_oov_segment_topk(None, None, None, 3, 257, 0, 100, None, None, None) == -2  # k > 256
+    assert lib.mi_oov_segment_topk(None, None, None, 3, 10, 0, 100, None, None, None) == -1
+    assert lib.mi_oov_topk_hits(None, 3, 0, None, None, None, None) == -2
+    assert lib.mi_oov_topk_hits(None, 3, 10, None, None, None, None) == -1
+    assert lib.mi_oov_score_topk(None, 4, None, 0, 64, 10, 0, None, None, None, None) == -2  # empty catalogue
+    assert lib.mi_oov_score_topk(None, 4, None, 100, 64, 10, 0, None, None, None, None) == -1
+    assert lib.mi_oov_score_topk_workspace(4096, 50_000, 20) > 0
+    assert lib.mi_oov_linear_act(None, 4, 16, None, None, 8, 7, None, None) in (-2, -3)       # unknown activation
+    assert lib.mi_oov_last_hip_error() == 0                                                  # nothing touched the GPU
