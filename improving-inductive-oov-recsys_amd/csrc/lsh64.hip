@@ -99,6 +99,38 @@ __device__ __forceinline__ float bcast8(int h, float b0, float b1) {
   }
 }
 
+// emb = acc / cnt, correctly rounded (0/0 -> NaN row, lsh_embedder.py:178).  cnt is a small integer (0..32),
+// so instead of four IEEE division sequences (~9 VALU each) one reciprocal rc = RN(1/cnt) is shared and each
+// quotient is refined once:  q = a rc;  e = fma(-q, cnt, a);  q' = fma(e, rc, q).
+// Verified EXHAUSTIVELY on the CPU (same IEEE fma) for cnt = 1..32 and all 2^32 values of a: q' equals
+// RN(a / cnt) except for a = -0 (acc is never -0: it starts at +0 and every step is RN(bit*w + acc)) and for a
+// handful of |a| < 2^-120 whose quotient is subnormal.  Lanes whose |acc| is below 2^-100 (including exact
+// zeros, i.e. the cnt = 0 rows) or infinite take the IEEE division.
+// rc itself: v_rcp_f32 is accurate to 1 ulp, and one Newton step y' = fma(fma(-cnt, y, 1), y, y) from a 1-ulp
+// estimate is the correctly rounded reciprocal unless the significand of cnt is all ones (Markstein); cnt = 0
+// gives NaN here, and that row takes the IEEE branch anyway.
+__device__ __forceinline__ float4 masked_mean(float4 acc, float cnt) {
+  const float y0 = __builtin_amdgcn_rcpf(cnt);
+  const float rc = __builtin_fmaf(__builtin_fmaf(-cnt, y0, 1.0f), y0, y0);
+  float4 emb;
+  {
+    float q;
+    q = acc.x * rc; emb.x = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.x), rc, q);
+    q = acc.y * rc; emb.y = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.y), rc, q);
+    q = acc.z * rc; emb.z = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.z), rc, q);
+    q = acc.w * rc; emb.w = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.w), rc, q);
+  }
+  const float amin = fminf(fminf(fabsf(acc.x), fabsf(acc.y)), fminf(fabsf(acc.z), fabsf(acc.w)));
+  const float amax = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+  if (!(amin >= 0x1p-100f) || !(amax < __builtin_inff())) {
+    emb.x = acc.x / cnt;
+    emb.y = acc.y / cnt;
+    emb.z = acc.z / cnt;
+    emb.w = acc.w / cnt;
+  }
+  return emb;
+}
+
 // One tile = 16 lookups of one wave (4 rounds x 4 groups).  FULL tiles (all 16 rows < B) skip every
 // tail clamp and liveness test; only the last tile of a launch can be partial.
 template <int H, bool SCORE, bool STORE, bool LOOKUP, bool FULL, bool BITS = false>
@@ -203,34 +235,7 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
         acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
       }
     }
-    // emb = acc / cnt, correctly rounded (0/0 -> NaN row, lsh_embedder.py:178).  cnt is an integer in
-    // [0, 8], so instead of four IEEE division sequences (~9 VALU each) one reciprocal r = RN(1/cnt)
-    // is shared and each quotient is refined once:  q = a r;  e = fma(-q, cnt, a);  q' = fma(e, r, q).
-    // Verified EXHAUSTIVELY on the CPU (same IEEE fma) for cnt = 1..8 and all 2^32 values of a: q'
-    // equals RN(a / cnt) except for a = -0 (acc is never -0: it starts at +0 and every step is
-    // RN(bit*w + acc)) and for |a| < 2^-124 with cnt = 6 (result subnormal).  Lanes whose |acc| is
-    // below 2^-100 (including exact zeros, i.e. the cnt = 0 rows) or infinite take the IEEE division.
-    // rc itself: v_rcp_f32 is accurate to 1 ulp, and one Newton step y' = fma(fma(-cnt, y, 1), y, y) from a
-    // 1-ulp estimate is the correctly rounded reciprocal unless the significand of cnt is all ones (Markstein);
-    // cnt = 0 gives NaN here, and that row takes the IEEE branch below anyway.
-    const float y0 = __builtin_amdgcn_rcpf(cnt);
-    const float rc = __builtin_fmaf(__builtin_fmaf(-cnt, y0, 1.0f), y0, y0);
-    float4 emb;
-    {
-      float q;
-      q = acc.x * rc; emb.x = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.x), rc, q);
-      q = acc.y * rc; emb.y = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.y), rc, q);
-      q = acc.z * rc; emb.z = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.z), rc, q);
-      q = acc.w * rc; emb.w = __builtin_fmaf(__builtin_fmaf(-q, cnt, acc.w), rc, q);
-    }
-    const float amin = fminf(fminf(fabsf(acc.x), fabsf(acc.y)), fminf(fabsf(acc.z), fabsf(acc.w)));
-    const float amax = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
-    if (!(amin >= 0x1p-100f) || !(amax < __builtin_inff())) {
-      emb.x = acc.x / cnt;
-      emb.y = acc.y / cnt;
-      emb.z = acc.z / cnt;
-      emb.w = acc.w / cnt;
-    }
+    float4 emb = masked_mean(acc, cnt);
     if (LOOKUP && !oov[r]) emb = x[r];
     if (!valid[r]) emb = make_float4(qnan(), qnan(), qnan(), qnan());
     const bool live = FULL || row[r] < B;
@@ -322,6 +327,137 @@ __global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restric
   }
 }
 
+// ---- 8 < H <= 32: the same tile, planes taken eight at a time ------------------------------------------------
+// The plane / bucket slices no longer fit in VGPRs for the whole kernel (2 x H float4 per lane), so they stay in
+// LDS (zero-padded to a multiple of 8 planes) and each group of 8 is read into the same 16 float4 registers per
+// tile; the four gathered rows stay in registers across the groups, the bucket-row chain acc = fma(bit_h, W[h],
+// acc) runs over h = 0..H-1 in order and the bit counts add up, so the result is bit-identical to the generic
+// kernel (lsh_fused_kernel) at roughly half its time (H = 16: 18.2 -> ~10.5 us).  Padding planes project to +0,
+// whose bit would be 1: their lanes are masked to 0 in the last group.
+template <bool SCORE, bool STORE, bool LOOKUP>
+__global__ __launch_bounds__(kBlk, 4) void lsh64g_kernel(const int64_t* __restrict__ ids, unsigned B,
+                                                        const float* __restrict__ feat, int64_t N,
+                                                        const float* __restrict__ vtable, int64_t n_vocab,
+                                                        const float* __restrict__ planes,
+                                                        const float* __restrict__ buckets, int H,
+                                                        const float* __restrict__ other,
+                                                        float* __restrict__ score, float* __restrict__ out) {
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const unsigned ntiles = (B + 15) / 16;
+  const unsigned tstep = gridDim.x * kWpb;
+  const int G = (H + 7) / 8, HP = G * 8;
+  unsigned tile = blockIdx.x * kWpb + wv;
+  int64_t idc[4];
+  load_tile_ids(ids, tile, B, l16, grp, idc);
+
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [2][HP][64], rows >= H zero
+  for (int i = threadIdx.x; i < 2 * HP * 16; i += kBlk) {
+    const int h = (i < HP * 16) ? i / 16 : (i - HP * 16) / 16;
+    const float* src = (i < HP * 16) ? planes + i * 4 : buckets + (i - HP * 16) * 4;
+    *reinterpret_cast<float4*>(sw + i * 4) = (h < H) ? *reinterpret_cast<const float4*>(src) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  __syncthreads();
+  // which planes of the last group exist: the lane's bank holds planes {0,2,1,3}[bank] (t0) and 4 + that (t1)
+  const int bank = l16 >> 2;
+  const int pl = ((bank & 1) << 1) | (bank >> 1);
+  const int hl = H - (G - 1) * 8;  // 1..8 planes in the last group
+  const float last0 = (pl < hl) ? 1.f : 0.f, last1 = (4 + pl < hl) ? 1.f : 0.f;
+
+  while (tile < ntiles) {
+    unsigned row[R];
+    bool valid[R], oov[R];
+    float4 x[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      oov[r] = !LOOKUP || idc[r] >= n_vocab;
+      valid[r] = oov[r] ? static_cast<uint64_t>(idc[r]) < static_cast<uint64_t>(N) : idc[r] >= 0;
+      const float* base = oov[r] ? feat : vtable;
+      x[r] = *reinterpret_cast<const float4*>(base + (valid[r] ? idc[r] : 0) * 64 + l16 * 4);
+    }
+    float4 acc[R];
+    float cnt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      acc[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+      cnt[r] = 0.f;
+    }
+    for (int g = 0; g < G; ++g) {
+      float4 pw[8], bw[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) {
+        pw[h] = *reinterpret_cast<const float4*>(sw + ((g * 8 + h) * 16 + l16) * 4);
+        bw[h] = *reinterpret_cast<const float4*>(sw + ((HP + g * 8 + h) * 16 + l16) * 4);
+      }
+      const float m0 = (g == G - 1) ? last0 : 1.f, m1 = (g == G - 1) ? last1 : 1.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float p[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) p[h] = dot4_fma(x[r], pw[h], 0.f);
+        float t0, t1;
+        rows8_sum(p, t0, t1);
+        const float b0 = ((t0 < 0.f) ? 0.f : 1.f) * m0;  // >= 0, +-0 and NaN -> 1 (torch_hash.py:57-59)
+        const float b1 = ((t1 < 0.f) ? 0.f : 1.f) * m1;
+        cnt[r] = cnt[r] + (b0 + b1);  // per-bank share; the banks are added up once, after the last group
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+          const float bit = bcast8(h, b0, b1);
+          acc[r].x = __builtin_fmaf(bit, bw[h].x, acc[r].x);
+          acc[r].y = __builtin_fmaf(bit, bw[h].y, acc[r].y);
+          acc[r].z = __builtin_fmaf(bit, bw[h].z, acc[r].z);
+          acc[r].w = __builtin_fmaf(bit, bw[h].w, acc[r].w);
+        }
+      }
+    }
+    float sc_all = 0.f;
+    const bool full = tile * 16 + 16 <= B;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float c = cnt[r];
+      c = c + dpp_f32<0x124>(c);
+      c = c + dpp_f32<0x128>(c);
+      float4 emb = masked_mean(acc[r], c);
+      if (LOOKUP && !oov[r]) emb = x[r];
+      if (!valid[r]) emb = make_float4(qnan(), qnan(), qnan(), qnan());
+      const bool live = row[r] < B;
+      if (STORE && live) *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (row[r] * 256u + l16 * 16u)) = emb;
+      if (SCORE) {
+        const float4 u = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(other) +
+                                                          ((live ? row[r] : B - 1) * 256u + l16 * 16u));
+        const float sdot = row16_sum(dot4_muladd(u, emb, 0.f));
+        if (full) {
+          if (l16 == r) sc_all = sdot;
+        } else if (l16 == 0 && live) {
+          *reinterpret_cast<float*>(reinterpret_cast<char*>(score) + row[r] * 4u) = sdot;
+        }
+      }
+    }
+    if (SCORE && full && l16 < 4)
+      *reinterpret_cast<float*>(reinterpret_cast<char*>(score) + (tile * 16u + l16 * 4u + grp) * 4u) = sc_all;
+    tile += tstep;
+    if (tile < ntiles) load_tile_ids(ids, tile, B, l16, grp, idc);
+  }
+}
+
+template <bool SCORE, bool STORE, bool LOOKUP>
+static int launch64g(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
+                     const float* planes, const float* buckets, int H, const float* other, float* score, float* out,
+                     hipStream_t st) {
+  constexpr int64_t kMaxRows64 = int64_t(1) << 23;
+  const int HP = (H + 7) / 8 * 8;
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxRows64) {
+    const int64_t nb = (B - b0 < kMaxRows64) ? B - b0 : kMaxRows64;
+    const int grid = grid_for(nb, 16 * kWpb);
+    hipLaunchKernelGGL((lsh64g_kernel<SCORE, STORE, LOOKUP>), dim3(grid), dim3(kBlk), 2 * HP * 64 * sizeof(float), st,
+                       ids + b0, static_cast<unsigned>(nb), feat, N, vtable, n_vocab, planes, buckets, H,
+                       other ? other + b0 * 64 : nullptr, score ? score + b0 : nullptr, out ? out + b0 * 64 : nullptr);
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
+}
+
 template <int H, bool SCORE, bool STORE, bool LOOKUP, bool BITS = false>
 static int launch64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
                     const float* planes, const float* buckets, const float* other, float* score, float* out,
@@ -361,6 +497,19 @@ static int launch64_h(const int64_t* ids, int64_t B, const float* feat, int64_t 
 int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
                  const float* planes, int H, const float* buckets, const float* other, float* score, float* out,
                  hipStream_t st, uint8_t* bits) {
+  if (H > 8) {  // 9..32 planes: groups of eight through LDS (no codes output on this path)
+    if (H > 32 || bits) return MI_OOV_ERR_SHAPE;
+#define MI_GOG(S, T, L) return launch64g<S, T, L>(ids, B, feat, N, vtable, n_vocab, planes, buckets, H, other, score, out, st)
+    if (vtable) {
+      if (score && out) MI_GOG(true, true, true);
+      if (score) MI_GOG(true, false, true);
+      MI_GOG(false, true, true);
+    }
+    if (score && out) MI_GOG(true, true, false);
+    if (score) MI_GOG(true, false, false);
+    MI_GOG(false, true, false);
+#undef MI_GOG
+  }
   if (bits) {
     if (H != 8 || score || vtable) return MI_OOV_ERR_SHAPE;
     if (out) return launch64<8, false, true, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);

@@ -131,6 +131,7 @@ def test_bpr_golden(golden, oracle, ops, dev):
 
 @pytest.mark.parametrize("B,N,F,H,D", [(1, 7, 64, 8, 64), (63, 100, 64, 8, 64), (4097, 3000, 64, 8, 64), (16, 9, 64, 8, 64),
                                        (500, 400, 22, 8, 64), (333, 200, 4, 3, 1), (257, 150, 128, 16, 128),
+                                       (4099, 3000, 64, 16, 64), (1000, 500, 64, 27, 64), (77, 60, 64, 32, 64),
                                        (100, 90, 200, 9, 36), (129, 77, 301, 40, 50), (64, 50, 640, 12, 256)])
 def test_lsh_shapes_vs_oracle(B, N, F, H, D, oracle, ops, dev):
     rng = np.random.default_rng(B * 31 + F)
@@ -168,7 +169,8 @@ def test_lsh_shapes_vs_oracle(B, N, F, H, D, oracle, ops, dev):
     assert np.array_equal(ops.slsh_index(T(ids, dev), T(feat, dev), T(planes, dev), nb).cpu().numpy(), o_idx)
 
 
-@pytest.mark.parametrize("F,H,D", [(64, 8, 64), (64, 3, 64), (64, 12, 64), (22, 8, 64), (64, 8, 32)])
+@pytest.mark.parametrize("F,H,D", [(64, 8, 64), (64, 3, 64), (64, 12, 64), (22, 8, 64), (64, 8, 32), (64, 9, 64),
+                                   (64, 16, 64), (64, 24, 64), (64, 31, 64), (64, 32, 64), (64, 33, 64)])
 def test_lookup_and_lookup_score_vs_oracle(F, H, D, oracle, ops, dev):
     """BPR lookups (in-vocab rows spliced with lsh rows) and the lookup fused with BPR.predict;
     (64, <=8, 64) takes the register-resident kernel, the others the generic LDS kernel."""
@@ -195,7 +197,7 @@ def test_lookup_and_lookup_score_vs_oracle(F, H, D, oracle, ops, dev):
     assert bits_equal(s2.cpu().numpy(), oracle.rowdot(other, want))
 
 
-@pytest.mark.parametrize("H", [3, 6, 7, 8])
+@pytest.mark.parametrize("H", [3, 6, 7, 8, 13, 24, 32])
 def test_lsh_division_extremes(H, oracle, ops, dev):
     """The hot kernel divides by the code's popcount with a shared reciprocal + one fma refinement and
     falls back to IEEE division for tiny / zero / infinite sums: sweep bucket tables whose entries are
@@ -218,7 +220,7 @@ def test_lsh_division_extremes(H, oracle, ops, dev):
         emb = ops.lsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(W, dev)).cpu().numpy()
         want, bits = oracle.lsh_embed(ids, feat, planes, W, want_bits=True)
         assert bits_equal(emb, want), f"scale {s}"
-        assert len(set(bits.sum(1).tolist())) >= H  # (almost) every popcount occurs
+        assert len(set(bits.sum(1).tolist())) >= min(H, 14)  # (almost) every popcount occurs (binomial tails thin out)
 
 
 def test_empty_batches(ops, dev):
