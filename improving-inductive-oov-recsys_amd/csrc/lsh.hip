@@ -448,6 +448,9 @@ int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, co
                  const float* planes, int H, const float* buckets, const float* other, float* score, float* out,
                  hipStream_t st, uint8_t* bits);
 
+int launch_slsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes, int H,
+                  const float* buckets, int64_t n_buckets, int64_t D, float* out, int64_t* idx, hipStream_t st);
+
 static bool lsh64_enabled() {
   static const bool on = [] {
     const char* e = getenv("MI_OOV_LSH64");  // developer A/B knob; default on
@@ -542,7 +545,9 @@ extern "C" int mi_oov_slsh_embed(const int64_t* ids, int64_t B, const float* fea
   const size_t lds = static_cast<size_t>(H) * FP * sizeof(float);
   if (static_cast<int64_t>(lds) > kLdsLimit) return MI_OOV_ERR_SHAPE;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool vec = (F % 4 == 0) && (p.D % 4 == 0) && aligned16(feat) && (!out || (aligned16(out) && aligned16(buckets)));
+  const bool vec = (F % 4 == 0) && aligned16(feat) && (!out || (p.D % 4 == 0 && aligned16(out) && aligned16(buckets)));
+  if (vec && F == 64 && H <= 32 && (!out || D == 64 || D == 128) && aligned16(planes) && lsh64_enabled())
+    return launch_slsh64(ids, B, feat, N, planes, static_cast<int>(H), buckets, n_buckets, D, out, idx, st);
   const int grid = grid_for(B, 64);
   if (vec) {
     auto k = slsh_kernel<true>;

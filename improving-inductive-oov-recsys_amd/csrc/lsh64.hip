@@ -458,6 +458,129 @@ static int launch64g(const int64_t* ids, int64_t B, const float* feat, int64_t N
   return MI_OOV_OK;
 }
 
+// ---- slsh on the hot tile: F = 64, up to 32 planes, D = 64 or 128 -------------------------------------------------
+// single_lsh_embedder.py:82-109: idx = (bits_req + popcount) % n_buckets, out = buckets[idx].  Same tile, same
+// bank-masked reduce as above with the planes taken eight at a time from LDS; only the per-bank bit counts are
+// kept.  Three dependent hops (ids -> feature rows -> bucket rows); the R bucket-row gathers of a tile are issued
+// together and the tile's 16 bucket ids leave in one store.
+template <int DCH>
+__global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const int64_t* __restrict__ ids, unsigned B,
+                                                        const float* __restrict__ feat, int64_t N,
+                                                        const float* __restrict__ planes, int H,
+                                                        const float* __restrict__ buckets, int64_t n_buckets,
+                                                        float* __restrict__ out, int64_t* __restrict__ idx) {
+  constexpr int R = 4;
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const unsigned ntiles = (B + 15) / 16;
+  const unsigned tstep = gridDim.x * kWpb;
+  const int G = (H + 7) / 8, HP = G * 8;
+  unsigned tile = blockIdx.x * kWpb + wv;
+  int64_t idc[4];
+  load_tile_ids(ids, tile, B, l16, grp, idc);
+
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [HP][64], rows >= H zero
+  for (int i = threadIdx.x; i < HP * 16; i += kBlk)
+    *reinterpret_cast<float4*>(sw + i * 4) = (i / 16 < H) ? *reinterpret_cast<const float4*>(planes + i * 4)
+                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  __syncthreads();
+  const int bank = l16 >> 2;
+  const int pl = ((bank & 1) << 1) | (bank >> 1);
+  const int hl = H - (G - 1) * 8;
+  const float last0 = (pl < hl) ? 1.f : 0.f, last1 = (4 + pl < hl) ? 1.f : 0.f;
+
+  while (tile < ntiles) {
+    unsigned row[R];
+    bool valid[R];
+    float4 x[R];
+    float cnt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      row[r] = tile * (4 * R) + r * 4 + grp;
+      valid[r] = static_cast<uint64_t>(idc[r]) < static_cast<uint64_t>(N);
+      x[r] = *reinterpret_cast<const float4*>(feat + (valid[r] ? idc[r] : 0) * 64 + l16 * 4);
+      cnt[r] = 0.f;
+    }
+    for (int g = 0; g < G; ++g) {
+      float4 pw[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) pw[h] = *reinterpret_cast<const float4*>(sw + ((g * 8 + h) * 16 + l16) * 4);
+      const float m0 = (g == G - 1) ? last0 : 1.f, m1 = (g == G - 1) ? last1 : 1.f;
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        float p[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) p[h] = dot4_fma(x[r], pw[h], 0.f);
+        float t0, t1;
+        rows8_sum(p, t0, t1);
+        cnt[r] = cnt[r] + (((t0 < 0.f) ? 0.f : 1.f) * m0 + ((t1 < 0.f) ? 0.f : 1.f) * m1);
+      }
+    }
+    // (2 ** bits).sum(1) = one or two per plane = H + popcount (single_lsh_embedder.py:86)
+    int64_t bkt[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      float c = cnt[r];
+      c = c + dpp_f32<0x124>(c);
+      c = c + dpp_f32<0x128>(c);
+      const int64_t v = H + static_cast<int>(c);  // <= 64
+      bkt[r] = valid[r] ? (v < n_buckets ? v : static_cast<int64_t>(static_cast<uint32_t>(v) % static_cast<uint32_t>(n_buckets)))
+                        : -1;
+    }
+    const bool full = tile * 16 + 16 <= B;
+    if (out) {
+      float4 v[R][DCH];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < DCH; ++c)
+          v[r][c] = *reinterpret_cast<const float4*>(buckets + (valid[r] ? bkt[r] : 0) * (64 * DCH) + c * 64 + l16 * 4);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int c = 0; c < DCH; ++c) {
+          if (!valid[r]) v[r][c] = make_float4(qnan(), qnan(), qnan(), qnan());
+          if (row[r] < B)
+            *reinterpret_cast<float4*>(out + static_cast<size_t>(row[r]) * (64 * DCH) + c * 64 + l16 * 4) = v[r][c];
+        }
+    }
+    if (idx) {
+      if (full) {
+        int64_t mine = bkt[0];
+        if (l16 == 1) mine = bkt[1];
+        if (l16 == 2) mine = bkt[2];
+        if (l16 == 3) mine = bkt[3];
+        if (l16 < 4) idx[tile * 16u + l16 * 4u + grp] = mine;
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+          if (l16 == 0 && row[r] < B) idx[row[r]] = bkt[r];
+      }
+    }
+    tile += tstep;
+    if (tile < ntiles) load_tile_ids(ids, tile, B, l16, grp, idc);
+  }
+}
+
+// Host entry used by mi_oov_slsh_embed (lsh.hip) when F = 64, H <= 32 and D is 64 or 128 (or no rows are wanted).
+int launch_slsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes, int H,
+                  const float* buckets, int64_t n_buckets, int64_t D, float* out, int64_t* idx, hipStream_t st) {
+  constexpr int64_t kMaxRows = int64_t(1) << 22;  // 32-bit row arithmetic inside the kernel
+  const int HP = (H + 7) / 8 * 8;
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxRows) {
+    const int64_t nb = (B - b0 < kMaxRows) ? B - b0 : kMaxRows;
+    const int grid = grid_for(nb, 16 * kWpb);
+    if (out && D == 128)
+      hipLaunchKernelGGL((slsh64_kernel<2>), dim3(grid), dim3(kBlk), HP * 64 * sizeof(float), st, ids + b0,
+                         static_cast<unsigned>(nb), feat, N, planes, H, buckets, n_buckets, out + b0 * D, idx ? idx + b0 : nullptr);
+    else
+      hipLaunchKernelGGL((slsh64_kernel<1>), dim3(grid), dim3(kBlk), HP * 64 * sizeof(float), st, ids + b0,
+                         static_cast<unsigned>(nb), feat, N, planes, H, buckets, n_buckets, out ? out + b0 * D : nullptr,
+                         idx ? idx + b0 : nullptr);
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
+}
+
 template <int H, bool SCORE, bool STORE, bool LOOKUP, bool BITS = false>
 static int launch64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
                     const float* planes, const float* buckets, const float* other, float* score, float* out,

@@ -365,3 +365,24 @@ def test_slsh_backward_and_scatter(B, nb, D, oracle, ops, dev):
     want = base.astype(np.float64)
     np.add.at(want, idx2[keep], g[keep].astype(np.float64))
     assert np.abs(out - want).max() <= RTOL * np.abs(want).max()
+
+
+@pytest.mark.parametrize("B,H,D,nb", [(4099, 3, 64, 8), (1000, 10, 64, 1000), (65, 27, 128, 100_000), (16, 32, 128, 40),
+                                      (333, 8, 128, 5), (50, 9, 96, 77)])
+def test_slsh_hot_tile_vs_oracle(B, H, D, nb, oracle, ops, dev):
+    """slsh at F = 64 with up to 32 planes and D = 64 / 128 takes slsh64_kernel (planes eight at a time, bank-masked
+    reduce); D = 96 stays on the generic kernel.  Bucket ids identical, rows verbatim, invalid ids -> -1 / NaN."""
+    rng = np.random.default_rng(B + H)
+    N = 3000
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    feat[0] = 0
+    planes = rng.standard_normal((H, 64), dtype=np.float32)
+    big = rng.standard_normal((nb, D), dtype=np.float32)
+    ids = rng.integers(0, N, size=B, dtype=np.int64)
+    ids[0] = 0
+    if B > 20:
+        ids[7], ids[11] = N + 1, -5
+    want, widx = oracle.slsh_embed(ids, feat, planes, big)
+    got = ops.slsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(big, dev)).cpu().numpy()
+    assert bits_equal(got, want)
+    assert np.array_equal(ops.slsh_index(T(ids, dev), T(feat, dev), T(planes, dev), nb).cpu().numpy(), widx)

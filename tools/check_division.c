@@ -1,0 +1,33 @@
+// exhaustive check of the shared-reciprocal division for integer divisors c: q' = fma(fma(-q, c, a), rc, q), q = a*rc, rc = RN(1/c)
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+int main(int argc, char** argv) {
+  int c0 = atoi(argv[1]), c1 = atoi(argv[2]);
+  for (int ci = c0; ci <= c1; ++ci) {
+    const float c = (float)ci, rc = 1.0f / c;
+    long long bad = 0, bad_guarded = 0;
+    uint32_t first = 0;
+#pragma omp parallel for reduction(+ : bad, bad_guarded) schedule(static)
+    for (long long i = 0; i < (1LL << 32); ++i) {
+      const uint32_t u = (uint32_t)i;
+      const float a = u2f(u);
+      if (a != a) continue;
+      const float q = a * rc;
+      const float q2 = fmaf(fmaf(-q, c, a), rc, q);
+      const float w = a / c;
+      if (f2u(q2) != f2u(w)) {
+        ++bad;
+        const float aa = fabsf(a);
+        if (aa >= 0x1p-100f && aa < INFINITY) { ++bad_guarded; first = u; }
+      }
+    }
+    printf("c=%2d  mismatches %lld, of which inside the fast-path guard (2^-100 <= |a| < inf): %lld %08x\n", ci, bad, bad_guarded, first);
+    fflush(stdout);
+  }
+  return 0;
+}
