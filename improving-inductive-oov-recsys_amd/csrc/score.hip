@@ -676,3 +676,69 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
   }
   return MI_OOV_OK;
 }
+
+// ---- full-sort evaluation with per-user exclusions (history masks) ---------------------------------------------
+// InductiveEvaluator.eval_batch (R/inductive/evaluator.py:70-96) sets scores[:, 0] and scores[history_index] to -inf
+// before the collector's topk.  Here: top-(k + h_max) through mi_oov_score_topk (fused, nothing materialised), then
+// one pass per row that walks the ranked candidates and keeps the first k whose column is not in the row's sorted
+// exclusion list -- at most h_max of the k + h_max best can be excluded, so the first k survivors are the answer.
+__global__ __launch_bounds__(kBlock) void topk_exclude_kernel(const float* __restrict__ vals2, const int64_t* __restrict__ idx2,
+                                                              int64_t B, int k2, int k, const int64_t* __restrict__ excl_ptr,
+                                                              const int64_t* __restrict__ excl_cols,
+                                                              float* __restrict__ vals, int64_t* __restrict__ idx) {
+  __shared__ int wave_tot[kBlock / 64];
+  const int64_t row = blockIdx.x;
+  if (row >= B) return;
+  const int64_t e0 = excl_ptr[row], e1 = excl_ptr[row + 1];
+  const int t = threadIdx.x;  // k2 <= 256 = kBlock: one candidate per thread
+  bool keep = false;
+  int64_t c = -1;
+  float v = -__builtin_inff();
+  if (t < k2) {
+    c = idx2[row * k2 + t];
+    v = vals2[row * k2 + t];
+    keep = c >= 0;
+    int64_t lo = e0, hi = e1;  // binary search in the sorted exclusion list
+    while (keep && lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      const int64_t m = excl_cols[mid];
+      if (m == c) keep = false;
+      else if (m < c) lo = mid + 1;
+      else hi = mid;
+    }
+  }
+  int total;
+  const int pos = block_excl_scan(keep ? 1 : 0, wave_tot, total);
+  if (keep && pos < k) {
+    vals[row * k + pos] = v;
+    idx[row * k + pos] = c;
+  }
+  for (int j = total + t; j < k; j += kBlock) {  // fewer than k admissible columns
+    vals[row * k + j] = -__builtin_inff();
+    idx[row * k + j] = -1;
+  }
+}
+
+extern "C" int64_t mi_oov_score_topk_excl_workspace(int64_t B, int64_t N, int64_t k, int64_t h_max) {
+  if (B <= 0 || N <= 0 || k <= 0 || h_max < 0 || k + h_max > 256) return 0;
+  const int64_t k2 = k + h_max;
+  return align256(mi_oov_score_topk_workspace(B, N, k2)) + align256(B * k2 * 4) + align256(B * k2 * 8);
+}
+
+extern "C" int mi_oov_score_topk_excl(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                                      int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols, int64_t h_max,
+                                      float* vals, int64_t* idx, void* workspace, void* stream) {
+  if (k <= 0 || h_max < 0 || k + h_max > 256) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!excl_ptr || !excl_cols || !workspace || !vals || !idx) return MI_OOV_ERR_NULL;
+  const int64_t k2 = k + h_max;
+  char* ws = static_cast<char*>(workspace);
+  const int64_t off_v = align256(mi_oov_score_topk_workspace(B, N, k2));
+  float* vals2 = reinterpret_cast<float*>(ws + off_v);
+  int64_t* idx2 = reinterpret_cast<int64_t*>(ws + off_v + align256(B * k2 * 4));
+  if (int rc = mi_oov_score_topk(U, B, E, N, D, k2, n_skip_low, vals2, idx2, workspace, stream)) return rc;
+  hipLaunchKernelGGL(topk_exclude_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), vals2,
+                     idx2, B, static_cast<int>(k2), static_cast<int>(k), excl_ptr, excl_cols, vals, idx);
+  return check_launch();
+}
+

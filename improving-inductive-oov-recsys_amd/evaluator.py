@@ -82,6 +82,33 @@ class RankingCollector:
         return rec
 
 
+class FullSortCollector(RankingCollector):
+    """'rec.topk' for full-sort batches (InductiveEvaluator.eval_batch, R/inductive/evaluator.py:70-96): the scores
+    U @ E.T are never materialised; column 0 (padding) and each user's history are excluded inside the fused top-k
+    (`mi_oov_score_topk_excl`), the hit flags come from `mi_oov_topk_hits`."""
+
+    def eval_batch_collect_full(self, U, E, history_index, positive_u, positive_i, n_skip_low=1):
+        """U f32[n_users, D] user rows of the batch, E f32[n_items, D] the catalogue (model.get_*_embedding output);
+        history_index = (rows, cols) as produced by FullSortEvalDataLoader, or None."""
+        dev = U.device
+        n_users = U.shape[0]
+        if history_index is None:
+            hu = hi = torch.zeros((0,), dtype=torch.int64, device=dev)
+        else:
+            hu, hi = (t.to(dev) for t in history_index)
+        key = hu * (E.shape[0] + 1) + hi
+        order = torch.sort(key).indices  # by user, then column: the exclusion lists must ascend
+        hu, hi = hu[order], hi[order]
+        positive_u, positive_i = positive_u.to(dev), positive_i.to(dev)
+        if positive_u.numel() > 1 and bool((positive_u[1:] < positive_u[:-1]).any()):
+            o = torch.sort(positive_u, stable=True).indices
+            positive_u, positive_i = positive_u[o], positive_i[o]
+        _, idx = ops.score_topk_excl(U, E, self.topk[-1], _csr_ptr(hu, n_users), hi, n_skip_low=n_skip_low)
+        rec = ops.topk_hits(idx, _csr_ptr(positive_u, n_users), positive_i)
+        self.blocks.append(rec)
+        return rec
+
+
 def topk_metrics(rec_topk, topk, metrics=("recall", "hit", "precision", "ndcg", "mrr", "map"), decimal_place=4):
     """recbole's TopkMetric family on a rec.topk block int[U, kmax+1] (metrics.py:36-235): per-user curves for
     k = 1..kmax, users whose curve contains NaN (no positives) dropped, mean, rounded."""

@@ -577,3 +577,49 @@ def topk_hits(idx, pos_ptr, pos_cols):
     C.check(rc, "mi_oov_topk_hits")
     return out
 
+
+def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
+    """top-k of U @ E.T per user with scores[:, :n_skip_low] and the user's excluded columns (history) treated as
+    -inf (InductiveEvaluator.eval_batch, R/inductive/evaluator.py:92-95), without materialising the scores.
+    excl_ptr i64[B+1], excl_cols i64[nnz] ascending within a row.  Users are processed in groups such that
+    k + (longest history of the group) <= 256; users with longer histories go through the materialising path."""
+    U, E = _f32(U, "U"), _f32(E, "E")
+    excl_ptr, excl_cols = _ids(excl_ptr, "excl_ptr"), _ids(excl_cols, "excl_cols")
+    B, N = U.shape[0], E.shape[0]
+    vals = torch.empty((B, k), dtype=torch.float32, device=U.device)
+    idx = torch.empty((B, k), dtype=torch.int64, device=U.device)
+    if B == 0:
+        return vals, idx
+    lens = excl_ptr[1:] - excl_ptr[:-1]
+    longest = int(lens.max()) if h_max is None else int(h_max)
+    if excl_cols.numel() == 0:
+        excl_cols = torch.zeros((1,), dtype=torch.int64, device=U.device)
+    lib = C.lib()
+    if k + longest <= 256:
+        ws = torch.empty((max(int(lib.mi_oov_score_topk_excl_workspace(B, N, k, longest)), 16),), dtype=torch.uint8, device=U.device)
+        with C.on_device(U):
+            rc = lib.mi_oov_score_topk_excl(C.ptr(U), B, C.ptr(E), N, U.shape[1], k, int(n_skip_low), C.ptr(excl_ptr),
+                                            C.ptr(excl_cols), longest, C.ptr(vals), C.ptr(idx), C.ptr(ws), C.stream_of(U))
+        C.check(rc, "mi_oov_score_topk_excl")
+        return vals, idx
+    # long histories: fused path for the users that fit, materialised scores + mask for the rest
+    short = lens <= 256 - k
+    for sel, fused in ((short, True), (~short, False)):
+        rows = torch.nonzero(sel).view(-1)
+        if rows.numel() == 0:
+            continue
+        sub_ptr = torch.cat((torch.zeros(1, dtype=torch.int64, device=U.device), torch.cumsum(lens[rows], 0)))
+        take = torch.cat([torch.arange(int(excl_ptr[r]), int(excl_ptr[r + 1]), device=U.device) for r in rows.tolist()]) \
+            if int(sub_ptr[-1]) else torch.zeros((0,), dtype=torch.int64, device=U.device)
+        sub_cols = excl_cols[take] if take.numel() else torch.zeros((1,), dtype=torch.int64, device=U.device)
+        if fused:
+            v, i = score_topk_excl(U[rows], E, k, sub_ptr, sub_cols, n_skip_low, int(lens[rows].max()))
+        else:
+            S = full_sort_scores(U[rows], E).view(rows.numel(), N)
+            S[:, :n_skip_low] = -float("inf")
+            if take.numel():
+                S[torch.repeat_interleave(torch.arange(rows.numel(), device=U.device), lens[rows]), sub_cols] = -float("inf")
+            v, i = torch.topk(S, k, dim=1)
+        vals[rows], idx[rows] = v, i
+    return vals, idx
+

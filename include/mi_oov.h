@@ -262,6 +262,17 @@ int mi_oov_segment_topk(const float* scores, const int64_t* cols, const int64_t*
 int mi_oov_topk_hits(const int64_t* idx, int64_t S, int64_t k, const int64_t* pos_ptr, const int64_t* pos_cols,
                      int32_t* out, void* stream);
 
+/* mi_oov_score_topk with per-user exclusions: what the collector's topk sees after InductiveEvaluator.eval_batch has
+ * set scores[:,0] and scores[history_index] to -inf (R/inductive/evaluator.py:92-95).  excl_ptr i64[B+1] / excl_cols
+ * i64[nnz] is the CSR of excluded columns, ASCENDING within a row; h_max >= the longest row; k + h_max <= 256
+ * (longer histories: score in chunks of users, or materialise with mi_oov_full_sort_scores).  Top-(k + h_max) through
+ * the fused two-pass kernel, then one filter pass; nothing [B,N]-sized is written.
+ *   workspace: mi_oov_score_topk_excl_workspace(B, N, k, h_max) bytes, 16-byte aligned.                         */
+int64_t mi_oov_score_topk_excl_workspace(int64_t B, int64_t N, int64_t k, int64_t h_max);
+int mi_oov_score_topk_excl(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                           int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols, int64_t h_max,
+                           float* vals, int64_t* idx, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

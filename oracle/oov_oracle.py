@@ -254,3 +254,14 @@ def topk_hits(idx, pos_ptr, pos_cols):
     lib().oov_topk_hits(_p(idx), _c(S), _c(k), _p(pos_ptr), _p(pos_cols), _p(out))
     return out
 
+
+def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0):
+    U, E = _f32(U), _f32(E)
+    excl_ptr = np.ascontiguousarray(excl_ptr, dtype=np.int64)
+    excl_cols = np.ascontiguousarray(excl_cols, dtype=np.int64)
+    vals = np.empty((U.shape[0], k), np.float32)
+    idx = np.empty((U.shape[0], k), np.int64)
+    lib().oov_score_topk_excl(_p(U), _c(U.shape[0]), _p(E), _c(E.shape[0]), _c(U.shape[1]), _c(k), _c(n_skip_low),
+                              _p(excl_ptr), _p(excl_cols), _p(vals), _p(idx))
+    return vals, idx
+

@@ -84,6 +84,41 @@ def main():
     out["n_batches"] = np.array(len(blocks))
     np.savez_compressed(os.path.join(HERE, "eval_uni.npz"), **out)
     print("eval_uni.npz rec.topk", rec.shape, dict(result))
+    full_sort_fixture(cfg)
+
+
+def full_sort_fixture(cfg):
+    """InductiveEvaluator.eval_batch (R/inductive/evaluator.py:70-96) on a full-sort batch: dense scores = U @ E.T
+    (what BPR.full_sort_predict returns), column 0 and the users' history set to -inf, then the collector."""
+    cfg = FakeConfig({**cfg, "eval_args": {"mode": "full"}})
+    collector, evaluator = Collector(cfg), Evaluator(cfg)
+    g = torch.Generator().manual_seed(21)
+    n_users, n_items, D = 37, 800, 64
+    U, E = torch.randn((n_users, D), generator=g), torch.randn((n_items, D), generator=g)
+    rng = np.random.default_rng(22)
+    hist_u, hist_i, pos_u, pos_i = [], [], [], []
+    for u in range(n_users):
+        items = rng.choice(np.arange(1, n_items), size=int(rng.integers(3, 60)), replace=False)
+        n_pos = int(rng.integers(1, 5))
+        pos_u += [u] * n_pos
+        pos_i += items[:n_pos].tolist()
+        hist_u += [u] * (len(items) - n_pos)
+        hist_i += items[n_pos:].tolist()
+    U[torch.tensor(pos_u)] += 0.35 * E[torch.tensor(pos_i)]   # positives tend to rank high
+    scores = (U @ E.T).view(-1, n_items)
+    scores[:, 0] = -np.inf
+    scores[torch.tensor(hist_u), torch.tensor(hist_i)] = -np.inf
+    top2 = torch.topk(scores, 21, dim=1).values
+    gap = float(((top2[:, :-1] - top2[:, 1:]) / top2[:, :-1].abs()).min())
+    collector.eval_batch_collect(scores, None, torch.tensor(pos_u), torch.tensor(pos_i))
+    struct = collector.get_data_struct()
+    result = evaluator.evaluate(struct)
+    np.savez_compressed(os.path.join(HERE, "eval_full.npz"), U=U.numpy(), E=E.numpy(), hist_u=np.array(hist_u),
+                        hist_i=np.array(hist_i), pos_u=np.array(pos_u), pos_i=np.array(pos_i),
+                        rec_topk=struct.get("rec.topk").numpy(), topk=np.array(cfg["topk"]),
+                        metric_names=np.array(list(result.keys())),
+                        metric_values=np.array([float(v) for v in result.values()]), min_rel_gap=np.array(gap))
+    print("eval_full.npz min relative gap inside the top 21:", gap, {k: float(v) for k, v in list(result.items())[:4]})
 
 
 if __name__ == "__main__":

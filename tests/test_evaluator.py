@@ -106,3 +106,57 @@ def test_gpu_collector_dedups_and_slices(dev):
     res = ev.evaluate()
     assert set(res) == {"overall", "old_users", "new_users", "old_old", "old_new", "new_old", "new_new", "old_items", "new_items"}
     assert res["new_new"]["recall@2"] == 1.0 and res["old_old"]["hit@1"] == 1.0 and res["old_users"]["recall@2"] == 1.0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,k,hmax", [(70, 3000, 10, 40), (9, 1300, 5, 0), (130, 4159, 20, 200), (40, 2500, 10, 600)])
+def test_gpu_full_sort_topk_with_history_vs_oracle(B, N, k, hmax, oracle, dev):
+    """Full-sort evaluation: column 0 and every user's history masked (evaluator.py:92-95) inside the fused top-k;
+    histories longer than 256 - k fall back to materialised scores for those users."""
+    from mi_oov import ops
+    rng = np.random.default_rng(B + N)
+    U = rng.standard_normal((B, 64), dtype=np.float32)
+    E = rng.standard_normal((N, 64), dtype=np.float32)
+    lens = rng.integers(0, hmax + 1, B)
+    lens[0] = hmax
+    ptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    cols = np.concatenate([np.sort(rng.choice(np.arange(1, N), size=n, replace=False)) for n in lens] + [np.zeros(0, np.int64)])
+    # make sure masking matters: put each user's best items into its history
+    _, best = oracle.score_topk(U, E, 3, 1)
+    for b in range(B):
+        if lens[b] >= 3:
+            seg = cols[ptr[b]:ptr[b + 1]]
+            seg[:3] = best[b]
+            cols[ptr[b]:ptr[b + 1]] = np.sort(np.unique(np.concatenate((seg, best[b])))[:lens[b]]) if len(np.unique(seg)) == lens[b] else np.sort(seg)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    v, i = ops.score_topk_excl(T(U), T(E), k, T(ptr), T(cols.astype(np.int64)), n_skip_low=1)
+    ov, oi = oracle.score_topk_excl(U, E, k, ptr, cols, 1)
+    i = i.cpu().numpy()
+    assert np.array_equal(i, oi)
+    assert np.array_equal(v.cpu().numpy(), ov)
+    for b in range(B):  # nothing excluded is ever recommended
+        assert not np.intersect1d(i[b], cols[ptr[b]:ptr[b + 1]]).size and 0 not in i[b]
+
+
+def test_oracle_full_sort_rec_topk_matches_reference(golden, oracle):
+    import mi_oov
+    z = golden("eval_full.npz")
+    n_users, n_items = z["U"].shape[0], z["E"].shape[0]
+    order = np.lexsort((z["hist_i"], z["hist_u"]))
+    hu, hi = z["hist_u"][order], z["hist_i"][order]
+    _, idx = oracle.score_topk_excl(z["U"], z["E"], int(z["topk"].max()), _ptr(hu, n_users), hi, 1)
+    rec = oracle.topk_hits(idx, _ptr(z["pos_u"], n_users), z["pos_i"])
+    assert np.array_equal(rec, z["rec_topk"])
+    got = mi_oov.evaluator.topk_metrics(rec, [int(k) for k in z["topk"]])
+    for name, want in zip(z["metric_names"], z["metric_values"]):
+        assert got[str(name)] == pytest.approx(float(want), abs=1e-12), name
+
+
+@pytest.mark.gpu
+def test_gpu_full_sort_rec_topk_matches_reference(golden, dev):
+    import mi_oov
+    z = golden("eval_full.npz")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    col = mi_oov.evaluator.FullSortCollector([int(k) for k in z["topk"]])
+    rec = col.eval_batch_collect_full(T(z["U"]), T(z["E"]), (T(z["hist_u"]), T(z["hist_i"])), T(z["pos_u"]), T(z["pos_i"]))
+    assert np.array_equal(rec.cpu().numpy(), z["rec_topk"])
