@@ -1,3 +1,5 @@
+// Exhaustive check (all 2^32 float dividends) of the shared-reciprocal division used by masked_mean() in
+// improving-inductive-oov-recsys_amd/csrc/lsh64.hip for integer divisors c0..c1; results: tools/check_division.txt
 // exhaustive check of the shared-reciprocal division for integer divisors c: q' = fma(fma(-q, c, a), rc, q), q = a*rc, rc = RN(1/c)
 #include <math.h>
 #include <stdint.h>
