@@ -386,3 +386,29 @@ def test_slsh_hot_tile_vs_oracle(B, H, D, nb, oracle, ops, dev):
     got = ops.slsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(big, dev)).cpu().numpy()
     assert bits_equal(got, want)
     assert np.array_equal(ops.slsh_index(T(ids, dev), T(feat, dev), T(planes, dev), nb).cpu().numpy(), widx)
+
+
+def test_hot_kernel_chunked_launch_over_8m_lookups(ops, dev):
+    """B above 2^23 lookups is split into several launches (32-bit row arithmetic inside the kernel): the result must
+    equal the concatenation of two independent calls on the halves, for the score, row and slsh variants."""
+    g = torch.Generator(device=dev).manual_seed(9)
+    N, B = 100_000, (1 << 23) + 4099
+    feat = torch.randn((N, 64), generator=g, device=dev)
+    planes, buckets = torch.randn((8, 64), generator=g, device=dev), torch.randn((8, 64), generator=g, device=dev)
+    ids = torch.randint(0, N, (B,), generator=g, device=dev)
+    users = torch.randn((B, 64), generator=g, device=dev)
+    h = B // 2 + 5
+    s = ops.lsh_embed_score(ids, feat, planes, buckets, users)
+    s2 = torch.cat((ops.lsh_embed_score(ids[:h], feat, planes, buckets, users[:h]),
+                    ops.lsh_embed_score(ids[h:], feat, planes, buckets, users[h:].contiguous())))
+    assert torch.equal(torch.nan_to_num(s), torch.nan_to_num(s2))
+    del users, s, s2
+    e = ops.lsh_embed(ids, feat, planes, buckets)
+    assert torch.equal(torch.nan_to_num(e[h:]), torch.nan_to_num(ops.lsh_embed(ids[h:], feat, planes, buckets)))
+    assert torch.equal(torch.nan_to_num(e[-3:]), torch.nan_to_num(ops.lsh_embed(ids[-3:], feat, planes, buckets)))
+    del e
+    big = torch.randn((1000, 64), generator=g, device=dev)
+    p10 = torch.randn((10, 64), generator=g, device=dev)
+    r = ops.slsh_embed(ids, feat, p10, big)
+    assert torch.equal(r[h:], ops.slsh_embed(ids[h:], feat, p10, big))
+    assert torch.equal(ops.slsh_index(ids, feat, p10, 1000)[-5:], ops.slsh_index(ids[-5:], feat, p10, 1000))

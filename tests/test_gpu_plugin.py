@@ -368,3 +368,28 @@ def test_lsh_scorer_and_graph_replay(mi, dev):
     graph.replay()
     torch.cuda.synchronize()
     assert torch.equal(torch.nan_to_num(buf), torch.nan_to_num(torch.stack(want)))
+
+
+def test_backward_kernels_full_size_properties(mi, dev):
+    """BASELINE batch (65536 lookups): the bucket-table gradients are deterministic (bit-identical across runs),
+    match a float64 evaluation of the autograd formula, and the row scatter-add matches index_add_."""
+    from mi_oov import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    B, H, D = 65536, 8, 64
+    bits = (torch.rand((B, H), generator=g, device=dev) < 0.5).to(torch.uint8)
+    bits[bits.sum(1) == 0, 0] = 1
+    grad = torch.randn((B, D), generator=g, device=dev)
+    a = ops.lsh_embed_backward(bits, grad)
+    assert torch.equal(a, ops.lsh_embed_backward(bits, grad))
+    w = bits.double()
+    want = (w / w.sum(1, keepdim=True)).t() @ grad.double()
+    assert (a.double() - want).abs().max() <= 1e-5 * want.abs().max()
+    idx = torch.randint(0, 9, (B,), generator=g, device=dev)
+    s = ops.slsh_embed_backward(idx, grad, 9)
+    assert torch.equal(s, ops.slsh_embed_backward(idx, grad, 9))
+    want = torch.zeros((9, D), dtype=torch.float64, device=dev).index_add_(0, idx, grad.double())
+    assert (s.double() - want).abs().max() <= 1e-5 * want.abs().max()
+    rows = torch.randint(0, 1_000_000, (B,), generator=g, device=dev)
+    got = ops.scatter_add_rows(rows, grad, 1_000_000)
+    want = torch.zeros((1_000_000, D), device=dev).index_add_(0, rows, grad)
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
