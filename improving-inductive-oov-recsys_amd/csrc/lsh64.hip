@@ -153,7 +153,9 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
   // ids -> rows chain and the first thing the VALU waits for -- and the sequential rows of the other side behind
   // them (needed only by the score at the end of each round): 9.57 us with the user rows first, 9.10 us this
   // way.  The compiler is free to reorder independent loads, hence the scheduling barrier between the groups.
-  // Non-temporal loads (streaming rows, no reuse) changed nothing for the gathers and cost 0.3 us on the user rows.
+  // Non-temporal loads (streaming rows, no reuse) changed nothing for the gathers and cost 0.3 us on the user rows;
+  // requesting 1 / 2 / 4 of the user rows before the ids have landed costs 0.03 / 0.07 / 4 us (their traffic delays
+  // everybody's ids).
   float4 x[R];
   float4 u[SCORE ? R : 1];
 #pragma unroll
