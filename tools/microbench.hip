@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <map>
 #include <chrono>
 #include <vector>
 
@@ -356,6 +357,124 @@ __global__ __launch_bounds__(256) void stamped2_kernel(const int64_t* __restrict
 #undef STAMP
 }
 
+
+// product-ordered probe with the stamps held in registers (no stores until the end) + where the wave ran
+__global__ __launch_bounds__(256, 4) void stamped3_kernel(const int64_t* __restrict__ ids, int64_t B,
+                                                         const float* __restrict__ feat, const float* __restrict__ planes,
+                                                         const float* __restrict__ buckets, const float* __restrict__ other,
+                                                         float* __restrict__ score, unsigned long long* __restrict__ stamps) {
+  constexpr int H = 8, R = 4;
+  __shared__ __attribute__((aligned(16))) float sw[2 * H * 64];
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const unsigned long long t0 = wall_clock64();
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wv;
+  int64_t row[R], id[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    row[r] = tile * (4 * R) + r * 4 + grp;
+    if (row[r] >= B) row[r] = B - 1;
+    id[r] = ids[row[r]];
+  }
+  for (int i = threadIdx.x; i < 2 * H * 16; i += 256) {
+    const float* src = (i < H * 16) ? planes + i * 4 : buckets + (i - H * 16) * 4;
+    *reinterpret_cast<float4*>(sw + i * 4) = *reinterpret_cast<const float4*>(src);
+  }
+  __syncthreads();
+  float4 pw[H], bw[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    pw[h] = *reinterpret_cast<const float4*>(sw + (h * 16 + l16) * 4);
+    bw[h] = *reinterpret_cast<const float4*>(sw + (H * 16 + h * 16 + l16) * 4);
+  }
+  long long idsum = 0;
+#pragma unroll
+  for (int r = 0; r < R; ++r) idsum += id[r];
+  asm volatile("" ::"v"(idsum));
+  const unsigned long long t1 = wall_clock64();
+  float4 x[R], u[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) x[r] = *reinterpret_cast<const float4*>(feat + id[r] * 64 + l16 * 4);
+  asm volatile("" ::: "memory");
+#pragma unroll
+  for (int r = 0; r < R; ++r) u[r] = *reinterpret_cast<const float4*>(other + row[r] * 64 + l16 * 4);
+  unsigned long long t2 = 0;
+  float sc = 0.f;
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    asm volatile("" ::"v"(x[r].x));
+    if (r == 0) t2 = wall_clock64();
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cnt = 0.f;
+#pragma unroll
+    for (int h = 0; h < H; ++h) {
+      const float s = row16_sum(dot4_fma(x[r], pw[h], 0.f));
+      const float bit = (s < 0.f) ? 0.f : 1.f;
+      cnt = cnt + bit;
+      acc.x = __builtin_fmaf(bit, bw[h].x, acc.x); acc.y = __builtin_fmaf(bit, bw[h].y, acc.y);
+      acc.z = __builtin_fmaf(bit, bw[h].z, acc.z); acc.w = __builtin_fmaf(bit, bw[h].w, acc.w);
+    }
+    const float rc = __builtin_amdgcn_rcpf(cnt);
+    acc.x *= rc; acc.y *= rc; acc.z *= rc; acc.w *= rc;
+    const float s = row16_sum(dot4_muladd(u[r], acc, 0.f));
+    if (l16 == r) sc = s;
+  }
+  if (l16 < 4) score[tile * 16 + l16 * 4 + grp] = sc;
+  asm volatile("" ::"v"(sc));
+  const unsigned long long t3 = wall_clock64();
+  if (lane == 0) {
+    unsigned long long* o = stamps + 6 * ((size_t)blockIdx.x * 4 + wv);
+    o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+    o[4] = __builtin_amdgcn_s_getreg((15 << 11) | (0 << 6) | 4);   // HW_ID bits [15:0]
+    o[5] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);   // XCC_ID bits [3:0]
+  }
+}
+
+static void run_stamps3(const int64_t* ids, int64_t B, const float* feat, const float* planes2, const float* buckets2,
+                        const float* users2, float* score2) {
+  const int grid = (int)(B / 64), nw = grid * 4;
+  unsigned long long* st;
+  CK(hipMalloc(&st, (size_t)nw * 6 * 8));
+  for (int i = 0; i < 50; ++i)
+    hipLaunchKernelGGL(stamped3_kernel, dim3(grid), dim3(256), 0, 0, ids + (int64_t)i * B, B, feat, planes2, buckets2,
+                       users2 + (int64_t)(i % 8) * B * 64, score2, st);
+  CK(hipDeviceSynchronize());
+  std::vector<unsigned long long> hs((size_t)nw * 6);
+  CK(hipMemcpy(hs.data(), st, hs.size() * 8, hipMemcpyDeviceToHost));
+  unsigned long long base = ~0ull, end = 0;
+  for (int w = 0; w < nw; ++w) { if (hs[6 * w] < base) base = hs[6 * w]; if (hs[6 * w + 3] > end) end = hs[6 * w + 3]; }
+  printf("stamped3 (product order, stamps in registers): first start -> last end = %.2f us\n", (end - base) / 100.0);
+  const char* names[4] = {"start", "ids landed", "x[0] landed", "done"};
+  for (int k = 0; k < 4; ++k) {
+    std::vector<double> v(nw);
+    for (int w = 0; w < nw; ++w) v[w] = (hs[6 * w + k] - base) / 100.0;
+    std::sort(v.begin(), v.end());
+    printf("  %-12s  min %6.2f  p10 %6.2f  p50 %6.2f  p90 %6.2f  p99 %6.2f  max %6.2f us\n", names[k], v[0], v[nw / 10], v[nw / 2],
+           v[nw * 9 / 10], v[nw * 99 / 100], v[nw - 1]);
+  }
+  // where do the slow waves sit?  group by (xcc, se, sh, cu) and report waves per CU + done time per CU
+  std::map<unsigned, std::vector<double>> percu;
+  for (int w = 0; w < nw; ++w) {
+    const unsigned hw = (unsigned)hs[6 * w + 4], xcc = (unsigned)hs[6 * w + 5];
+    const unsigned cu = (hw >> 8) & 0xF, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
+    percu[(xcc << 12) | (se << 8) | (sh << 4) | cu].push_back((hs[6 * w + 3] - base) / 100.0);
+  }
+  std::map<int, int> hist;
+  double worst = 0; unsigned worst_key = 0;
+  for (auto& kv : percu) {
+    hist[(int)kv.second.size()]++;
+    double m = *std::max_element(kv.second.begin(), kv.second.end());
+    if (m > worst) { worst = m; worst_key = kv.first; }
+  }
+  printf("  distinct CUs seen: %zu; waves per CU histogram:", percu.size());
+  for (auto& kv : hist) printf("  %d waves x %d CUs", kv.first, kv.second);
+  printf("\n  slowest CU key %05x: %zu waves, last done %.2f us\n", worst_key, percu[worst_key].size(), worst);
+  // done time as a function of waves per CU
+  std::map<int, std::pair<double, int>> bycount;
+  for (auto& kv : percu) { auto& e = bycount[(int)kv.second.size()]; e.first += *std::max_element(kv.second.begin(), kv.second.end()); e.second++; }
+  for (auto& kv : bycount) printf("  CUs with %2d waves: mean last-done %.2f us\n", kv.first, kv.second.first / kv.second.second);
+  CK(hipFree(st));
+}
+
 template <int ORDER>
 static void run_stamps2(const int64_t* ids, int64_t B, const float* feat, const float* planes2, const float* buckets2,
                         const float* users2, float* score2) {
@@ -456,6 +575,8 @@ int main(int argc, char** argv) {
     float *planes2, *buckets2, *users2, *score2;
     CK(hipMalloc(&planes2, 2048)); CK(hipMalloc(&buckets2, 2048)); CK(hipMalloc(&users2, 8 * B * 64 * 4)); CK(hipMalloc(&score2, B * 4));
     CK(hipMemset(planes2, 0, 2048)); CK(hipMemset(buckets2, 0, 2048)); CK(hipMemset(users2, 0, 8 * B * 64 * 4));
+    run_stamps3(ids, B, feat, planes2, buckets2, users2, score2);
+    if (getenv("MB_STAMPS3_ONLY")) return 0;
     run_stamps2<0>(ids, B, feat, planes2, buckets2, users2, score2);
     run_stamps2<1>(ids, B, feat, planes2, buckets2, users2, score2);
     run_stamps2<2>(ids, B, feat, planes2, buckets2, users2, score2);
