@@ -16,7 +16,7 @@ from .embedders import (AbstractInductiveEmbedder, DeepHashEmbedder, DNNEmbedder
                         SingleLSHInductiveEmbedder, TorchLSHash, ZeroEmbedder)
 from .factory import get_inductive_embedder, get_inductive_mapper  # noqa: F401
 from .mapper import AbstractInductiveMapper, RandomOOVInductiveMapper  # noqa: F401
-from .model import BPR, InductiveGeneralRecommender  # noqa: F401
+from .model import BPR, DirectAU, InductiveGeneralRecommender  # noqa: F401
 
 __version__ = "0.1.0"
 

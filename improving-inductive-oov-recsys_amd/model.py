@@ -189,3 +189,53 @@ class BPR(InductiveGeneralRecommender):
         without ever materialising [B, n_items]."""
         user_e = self.get_user_embedding(interaction[self.USER_ID])
         return ops.score_topk(user_e, self.item_embedding.weight, k, 1 if skip_padding else 0)
+
+
+class DirectAU(BPR):
+    """DirectAU with the OOV splice (R/model/general_recommender/directau.py:25-186): the second general recommender
+    that calls the plugin (get_user_embedding / get_item_embedding at :132,167 are BPR's lookups verbatim, so the
+    kernels behind them are the same); rows are L2-normalised before the alignment / uniformity loss and before
+    the row dot of `predict`.  The loss arithmetic (pdist, norms, logs) is ordinary torch on [B, D] rows."""
+
+    def __init__(self, config, dataset, inductive_mapper=None, inductive_embedder=None):
+        super().__init__(config, dataset, inductive_mapper, inductive_embedder)
+        self.gamma = config["gamma"]
+        self.detach = config["detach"] if "detach" in config else False
+        self.restore_user_e = None
+        self.restore_item_e = None
+        self.other_parameter_name = ["restore_user_e", "restore_item_e"]
+
+    def forward(self, user, item):
+        user_e, item_e = self.get_user_embedding(user), self.get_item_embedding(item)
+        return torch.nn.functional.normalize(user_e, dim=-1), torch.nn.functional.normalize(item_e, dim=-1)
+
+    @staticmethod
+    def alignment(x, y, alpha=2):
+        return (x - y).norm(p=2, dim=1).pow(alpha).mean()
+
+    @staticmethod
+    def uniformity(x, t=2):
+        return torch.pdist(x, p=2).pow(2).mul(-t).exp().mean().log()
+
+    def calculate_loss(self, interaction):
+        if self.restore_user_e is not None or self.restore_item_e is not None:
+            self.restore_user_e, self.restore_item_e = None, None
+        user_e, item_e = self.forward(interaction[self.USER_ID], interaction[self.ITEM_ID])
+        align = self.alignment(user_e, item_e)
+        uniform = self.gamma * (self.uniformity(user_e) + self.uniformity(item_e)) / 2
+        return align + uniform
+
+    def predict(self, interaction):
+        user_e, item_e = self.forward(interaction[self.USER_ID], interaction[self.ITEM_ID])
+        return ops.rowdot(user_e, item_e)
+
+    def full_sort_predict(self, interaction):
+        raise NotImplementedError()  # as the reference (directau.py:172)
+
+    def ind_full_sort_predict(self, interaction, item_ids):  # un-normalised, as the reference (directau.py:181-186)
+        user_e = self.get_user_embedding(interaction[self.USER_ID])
+        return ops.full_sort_scores(user_e, self.get_item_embedding(item_ids)).view(-1)
+
+    def full_sort_topk(self, interaction, k, skip_padding=True):
+        raise NotImplementedError()
+

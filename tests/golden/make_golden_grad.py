@@ -71,6 +71,49 @@ def one_case(tag, build, n_users, n_items, n_new_u, n_new_i, D, n_ub, n_ib, seed
     print(f"{tag}: B={len(users)} loss={float(loss):.6f} |grad| = {grads}")
 
 
+def directau_case(out, n_users, n_items, n_new_u, n_new_i, D):
+    """The second caller of the plugin: the reference's DirectAU (+lsh) on a mixed in-vocabulary / OOV batch:
+    normalised rows, predict, alignment + uniformity loss and every table gradient."""
+    from recbole.model.general_recommender.directau import DirectAU
+    tag, seed = "directau", 750
+    uf = mg.features(n_new_u, [("a", 1, "float"), ("v", 9, "float")], seed, "user_id")
+    itf = mg.features(n_new_i, [("y", 1, "float"), ("w", 20, "float")], seed + 1, "item_id")
+    torch.manual_seed(seed + 2)
+    emb = mg.LSHInductiveEmbedder(uf, itf, n_users, n_items, 8, 8, D, "cpu", PRIME_PAD, "per-feature", mg.InductiveFeatureCache())
+    cfg = mg.FakeConfig(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device="cpu", embedding_size=D,
+                        add_oov_buckets=True, user_oov_buckets=8, item_oov_buckets=8, oov_freeze_embedding=False, gamma=0.7)
+    torch.manual_seed(seed + 3)
+    model = DirectAU(cfg, mg.FakeDataset(n_users, n_items), None, emb)
+    model.train()
+    emb.set_train()
+    g = torch.Generator().manual_seed(seed + 4)
+    users = torch.randint(1, n_new_u, (200,), generator=g)
+    items = torch.randint(1, n_new_i, (200,), generator=g)
+    with torch.no_grad():
+        ok = (emb._hash_users(torch.arange(n_new_u)).sum(1) > 0)[users] & (emb._hash_items(torch.arange(n_new_i)).sum(1) > 0)[items]
+    users, items = users[ok], items[ok]
+    u_in = torch.where(users >= n_users, users + PRIME_PAD, users)
+    i_in = torch.where(items >= n_items, items + PRIME_PAD, items)
+    inter = Interaction({"user_id": u_in.clone(), "item_id": i_in.clone()})
+    loss = model.calculate_loss(inter)
+    loss.backward()
+    with torch.no_grad():
+        ue, ie = model.forward(u_in.clone(), i_in.clone())
+        pred = model.predict(Interaction({"user_id": u_in.clone(), "item_id": i_in.clone()}))
+    out[f"{tag}__users"], out[f"{tag}__items"] = mg.np_(u_in), mg.np_(i_in)
+    out[f"{tag}__loss"], out[f"{tag}__pred"] = mg.np_(loss), mg.np_(pred)
+    out[f"{tag}__user_e"], out[f"{tag}__item_e"] = mg.np_(ue), mg.np_(ie)
+    for name, p in model.named_parameters():
+        key = name.replace(".", "_")
+        out[f"{tag}__w__{key}"] = mg.np_(p)
+        out[f"{tag}__g__{key}"] = mg.np_(p.grad) if p.grad is not None else np.zeros((0,), np.float32)
+    out[f"{tag}__user_feat"], out[f"{tag}__item_feat"] = mg.np_(emb.user_feature_mat), mg.np_(emb.item_feature_mat)
+    out[f"{tag}__user_planes"] = mg.np_(emb.user_lsh.uniform_planes[0].data)
+    out[f"{tag}__item_planes"] = mg.np_(emb.item_lsh.uniform_planes[0].data)
+    out[f"{tag}__dims"] = np.array([n_users, n_items, n_new_u, n_new_i, D, 8, 8])
+    print(f"directau: B={len(users)} loss={float(loss.detach()):.6f}")
+
+
 def main():
     torch.set_num_threads(4)
     out = {}
@@ -91,6 +134,7 @@ def main():
     one_case("mapper", lambda uf, itf: (mg.RandomOOVInductiveMapper(uf, itf, n_users, n_items, 8, 8, D, "cpu", PRIME_PAD,
                                                                    "3round"), None),
              *args, 8, 8, 740, out)
+    directau_case(out, n_users, n_items, n_new_u, n_new_i, D)
     np.savez_compressed(os.path.join(HERE, "bpr_grad.npz"), **out)
     print("bpr_grad.npz", os.path.getsize(os.path.join(HERE, "bpr_grad.npz")), "bytes")
 

@@ -393,3 +393,41 @@ def test_backward_kernels_full_size_properties(mi, dev):
     got = ops.scatter_add_rows(rows, grad, 1_000_000)
     want = torch.zeros((1_000_000, D), device=dev).index_add_(0, rows, grad)
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-5)
+
+
+def test_directau_matches_reference(mi, golden, dev):
+    """The plugin's second caller (directau.py:132,167): normalised rows, predict, alignment + uniformity loss and
+    the table gradients of one training batch against the REAL reference DirectAU (+lsh, prime-padded OOV ids)."""
+    z = golden("bpr_grad.npz")
+    tag = "directau"
+    n_users, n_items, n_new_u, n_new_i, D, n_ub, n_ib = (int(v) for v in z[tag + "__dims"])
+    cfg = Cfg(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device=dev, embedding_size=D,
+              add_oov_buckets=True, user_oov_buckets=n_ub, item_oov_buckets=n_ib, oov_freeze_embedding=False, gamma=0.7)
+    ft_u = mi.FeatureTable({"id": torch.arange(n_new_u), "f": torch.zeros(n_new_u, 10)})
+    ft_i = mi.FeatureTable({"id": torch.arange(n_new_i), "f": torch.zeros(n_new_i, 21)})
+    emb = mi.LSHInductiveEmbedder(ft_u, ft_i, n_users, n_items, n_ub, n_ib, D, dev, PRIME_PAD, "none", mi.InductiveFeatureCache())
+    emb.user_feature_mat, emb.item_feature_mat = T(z[tag + "__user_feat"], dev), T(z[tag + "__item_feat"], dev)
+    emb.load_state_dict({"user_lsh.uniform_planes.0": T(z[tag + "__user_planes"], dev),
+                         "item_lsh.uniform_planes.0": T(z[tag + "__item_planes"], dev)})
+    model = mi.DirectAU(cfg, DS(n_users, n_items), None, emb).to(dev)
+    names = ["user_embedding_weight", "item_embedding_weight", "user_oov_buckets_weight", "item_oov_buckets_weight"]
+    with torch.no_grad():
+        for n in names:
+            getattr(model, n[:-len("_weight")]).weight.copy_(T(z[f"{tag}__w__{n}"], dev))
+    users, items = T(z[tag + "__users"], dev), T(z[tag + "__items"], dev)
+    model.train()
+    emb.set_train()
+    loss = model.calculate_loss({"user_id": users.clone(), "item_id": items.clone()})
+    loss.backward()
+    assert abs(loss.item() - float(z[tag + "__loss"])) <= 1e-5 * abs(float(z[tag + "__loss"]))
+    for n in names:
+        ref = z[f"{tag}__g__{n}"]
+        got = getattr(model, n[:-len("_weight")]).weight.grad.cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), n
+    with torch.no_grad():
+        ue, ie = model.forward(users.clone(), items.clone())
+        pred = model.predict({"user_id": users.clone(), "item_id": items.clone()})
+    assert close(ue.cpu().numpy(), z[tag + "__user_e"]) and close(ie.cpu().numpy(), z[tag + "__item_e"])
+    assert np.allclose(pred.cpu().numpy(), z[tag + "__pred"], rtol=RTOL, atol=1e-6)
+    with pytest.raises(NotImplementedError):
+        model.full_sort_predict({"user_id": users[:4]})
