@@ -31,7 +31,7 @@ import torch
 
 from .embedders import FeatureTable
 from .factory import get_inductive_embedder, get_inductive_mapper
-from .model import BPR
+from .model import BPR, DirectAU
 
 
 # ---- command line: `--k=v` typed, bare `--k` -> True (S/utils/parse.py:44-61) --------------------------
@@ -221,8 +221,9 @@ def evaluate(model, users, items, tot_items, cfg, n_users, n_items, device, gen)
 
 def run(args):
     cfg = Config({**DEFAULTS, **args})
-    if cfg["model"] not in (None, "BPR"):
-        raise NotImplementedError(f"model {cfg['model']}: only BPR's lookup/scoring path is built (SURVEY.md section 2.1)")
+    if cfg["model"] not in (None, "BPR", "DirectAU"):
+        raise NotImplementedError(f"model {cfg['model']}: only the general recommenders that call the plugin (BPR, "
+                                  "DirectAU) are built (SURVEY.md section 2.1)")
     if not torch.cuda.is_available():
         raise RuntimeError("run_recbole needs an MI355X (ROCm device): the path has no CPU fallback")
     device = torch.device("cuda", int(cfg["gpu_id"] or 0))
@@ -244,7 +245,10 @@ def run(args):
 
     embedder = get_inductive_embedder(cfg, ds, user_num=n_users, item_num=n_items)
     mapper = get_inductive_mapper(cfg, ds, user_num=n_users, item_num=n_items)
-    model = BPR(cfg, _VocabView(n_users, n_items, ukey, ikey), mapper, embedder).to(device)
+    model_cls = DirectAU if cfg["model"] == "DirectAU" else BPR
+    if cfg["gamma"] is None:
+        cfg["gamma"] = 1.0  # R/properties/model/DirectAU.yaml
+    model = model_cls(cfg, _VocabView(n_users, n_items, ukey, ikey), mapper, embedder).to(device)
     opt = torch.optim.Adam([p for p in model.parameters() if p.requires_grad], lr=cfg["learning_rate"])
     gen = torch.Generator(device=device).manual_seed(seed)
     print(f"dataset {cfg['dataset']}: {ds.user_num} users ({n_users} in vocabulary), {ds.item_num} items "

@@ -69,14 +69,16 @@ def test_atomic_loader(tmp_path):
     ["--inductive_embedder=knn"],
     ["--inductive_embedder=mean"],
     ["--inductive_mapper=random", "--add_oov_buckets"],
+    ["--model=DirectAU", "--inductive_embedder=lsh", "--add_oov_buckets", "--train_oov", "--gamma=0.5"],
 ])
 def test_end_to_end(flags, tmp_path, monkeypatch, dev):
     from mi_oov import driver
     monkeypatch.chdir(tmp_path)  # dhe writes ./hash_keys
     root = write_dataset(str(tmp_path))
-    args = driver.custom_parse_args(["x", "--dataset=toy", f"--data_path={root}", "--model=BPR", "--embedding_size=32",
+    base = [] if any(f.startswith("--model=") for f in flags) else ["--model=BPR"]
+    args = driver.custom_parse_args(["x", "--dataset=toy", f"--data_path={root}", "--embedding_size=32",
                                      "--user_oov_buckets=8", "--item_oov_buckets=8", "--epochs=4",
-                                     "--learning_rate=0.01", "--train_batch_size=512"] + flags)
+                                     "--learning_rate=0.01", "--train_batch_size=512"] + base + flags)
     results, model = driver.run(args)
     for slice_name in ("overall", "old_users", "new_users", "old_old", "old_new", "new_old", "new_new", "old_items", "new_items"):
         assert slice_name in results
