@@ -7,6 +7,8 @@
 // precision), so the result equals oracle/oov_oracle.c::oov_full_sort_scores exactly.
 // With K = D = 64 the GEMM is output-bound as much as MFMA-bound (32 flop per stored byte), so the
 // tile is chosen for full-width coalesced stores: 128 x 128 per workgroup, 64 x 64 per wave.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace mi_oov {
@@ -58,11 +60,19 @@ struct TopkArgs {
   uint32_t* tilemax;    // [B, NT] best order key per 64-column tile (0 = no valid column)
   int64_t NT;
   const uint32_t* tau;  // [B] lower bound of the k-th best key
-  int* cnt;             // [B] candidates appended so far
-  uint64_t* cand;       // [B, cap] (key << 32) | (0xFFFFFFFF - column)
+  int* cnt;             // [B, kSeg] candidates appended so far, per segment (see below)
+  uint64_t* cand;       // [B, kSeg, kSegCap] (key << 32) | (0xFFFFFFFF - column)
+  int seg_width;        // 128-column blocks per segment
   int cap;
   int64_t n_skip_low;
+  int col_stride;  // TILEMAX pass: only every col_stride-th 128-column block is visited (0/1 = all)
 };
+
+// A row's candidate list is cut into kSeg segments, each fed by every kSeg-th 128-column block and with its own
+// counter: the filter pass appends with one global atomic per candidate, and ~100 appends to ONE counter per row
+// from hundreds of workgroups serialise in L2 (the filter pass went from 330 to 550 us when the sampled first pass
+// let 160 instead of 40 candidates per row through); 64 counters per row do not.
+constexpr int kSeg = 64, kSegCap = 16;  // 64 x 16 = the 1024 candidates the finalize kernel can rank
 
 // Order: larger value first, NaN above everything (torch.topk), ties -> lower column index.
 __device__ __forceinline__ uint32_t order_key(float v) {
@@ -97,7 +107,7 @@ __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __res
   const int lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;
   const int i32 = lane & 31, hh = lane >> 5;
-  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * BN;
+  const int64_t n0 = static_cast<int64_t>(blockIdx.x) * BN * ((EPI == EPI_TILEMAX && ta.col_stride > 1) ? ta.col_stride : 1);
   const int64_t b0 = static_cast<int64_t>(blockIdx.y) * BM;
 
   f32x16 acc[2][2];
@@ -168,26 +178,53 @@ __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __res
           const uint32_t o = __shfl_xor(best, off, 64);
           best = o > best ? o : best;
         }
-        if (i32 == 0 && row < B && n0 + wn * 64 < N) ta.tilemax[row * ta.NT + (n0 + wn * 64) / 64] = best;
+        // compact index: the visited blocks are numbered consecutively (blockIdx.x), two 64-column tiles each;
+        // a tile that lies entirely beyond N records 0 ("no valid column")
+        if (i32 == 0 && row < B) ta.tilemax[row * ta.NT + blockIdx.x * 2 + wn] = (n0 + wn * 64 < N) ? best : 0u;
       }
   } else if constexpr (EPI == EPI_FILTER) {
+    // Candidates (key >= tau) are first collected in LDS -- the operand tiles are dead by now -- and appended to the
+    // rows' global lists in one sweep at the end: a global atomic with return stalls its wave for a full round
+    // trip, and with ~0.4 candidates per row per block a wave would eat a dozen of those one after another.
+    constexpr int WCAP = 1024;
+    __syncthreads();  // every wave is done reading sA / sB
+    int* wcnt = reinterpret_cast<int*>(smem);
+    int* wrow = reinterpret_cast<int*>(smem) + 4;
+    uint64_t* wbuf = reinterpret_cast<uint64_t*>(smem + 4 + WCAP);
+    if (tid == 0) *wcnt = 0;
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int lrow = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        const int64_t row = b0 + lrow;
         const uint32_t tau = (row < B) ? ta.tau[row] : 0xFFFFFFFFu;
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           const int64_t col = n0 + wn * 64 + n * 32 + i32;
           const uint32_t key = order_key(acc[m][n][r]);
           if (row < B && col < N && col >= ta.n_skip_low && key >= tau) {
-            const int pos = atomicAdd(&ta.cnt[row], 1);
-            if (pos < ta.cap)
-              ta.cand[row * ta.cap + pos] = (static_cast<uint64_t>(key) << 32) | (0xFFFFFFFFu - static_cast<uint32_t>(col));
+            const uint64_t packed = (static_cast<uint64_t>(key) << 32) | (0xFFFFFFFFu - static_cast<uint32_t>(col));
+            const int p = atomicAdd(wcnt, 1);
+            if (p < WCAP) {
+              wrow[p] = lrow;
+              wbuf[p] = packed;
+            } else {  // more than WCAP candidates in one 128 x 128 tile: append directly
+              const int64_t seg = row * kSeg + blockIdx.x % kSeg;
+              const int pos = atomicAdd(&ta.cnt[seg], 1);
+              if (pos < kSegCap) ta.cand[seg * kSegCap + pos] = packed;
+            }
           }
         }
       }
+    __syncthreads();
+    const int nw = *wcnt < WCAP ? *wcnt : WCAP;
+    for (int i = tid; i < nw; i += kBlock) {
+      const int64_t seg = (b0 + wrow[i]) * kSeg + blockIdx.x % kSeg;  // interleaved: clustered good columns spread out
+      const int pos = atomicAdd(&ta.cnt[seg], 1);
+      if (pos < kSegCap) ta.cand[seg * kSegCap + pos] = wbuf[i];
+    }
   } else {
 #pragma unroll
     for (int m = 0; m < 2; ++m)
@@ -412,8 +449,21 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const float* __rest
 // fused path, between the two GEMM passes: tau[row] = k-th best of the row's tile maxima
 __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __restrict__ tilemax, int64_t B, int64_t NT,
                                                           int k, uint32_t* __restrict__ tau) {
+  __shared__ uint32_t sk[1024];
   const int64_t row = blockIdx.x;
   if (row >= B) return;
+  if (NT <= 1024) {  // rank by counting: the key that has exactly k-1 keys ahead of it (ties: lower index first)
+    const int n = static_cast<int>(NT);
+    for (int i = threadIdx.x; i < n; i += kBlock) sk[i] = tilemax[row * NT + i];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += kBlock) {
+      const uint32_t me = sk[i];
+      int ahead = 0;
+      for (int j = 0; j < n; ++j) ahead += (sk[j] > me || (sk[j] == me && j < i)) ? 1 : 0;
+      if (ahead == k - 1) tau[row] = me;
+    }
+    return;
+  }
   uint32_t T;
   int need_eq;
   radix_kth(U32Keys{tilemax + row * NT}, 0, NT, k, T, need_eq);
@@ -426,15 +476,32 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
 __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(const float* __restrict__ U, const float* __restrict__ E,
                                                                int64_t B, int64_t N, int64_t D, int k,
                                                                int64_t n_skip_low, const int* __restrict__ cnt,
-                                                               const uint64_t* __restrict__ cand, int cap,
+                                                               const uint64_t* __restrict__ cand,
                                                                float* __restrict__ vals, int64_t* __restrict__ idx) {
-  __shared__ uint64_t lc[1024];
+  __shared__ uint64_t lc[kSeg * kSegCap];
+  __shared__ int seg_off[kSeg + 1];
+  __shared__ int overflow;
   const int64_t row = blockIdx.x;
   if (row >= B) return;
-  const int n = cnt[row];
-  if (n <= cap) {
-    for (int i = threadIdx.x; i < n; i += kBlock) lc[i] = cand[row * cap + i];
+  if (threadIdx.x == 0) {
+    int n = 0, over = 0;
+    for (int g = 0; g < kSeg; ++g) {
+      const int c = cnt[row * kSeg + g];
+      over |= (c > kSegCap);
+      seg_off[g] = n;
+      n += c < kSegCap ? c : kSegCap;
+    }
+    seg_off[kSeg] = n;
+    overflow = over;
+  }
+  __syncthreads();
+  if (!overflow) {
+    for (int i = threadIdx.x; i < kSeg * kSegCap; i += kBlock) {
+      const int g = i / kSegCap, j = i % kSegCap;
+      if (j < seg_off[g + 1] - seg_off[g]) lc[seg_off[g] + j] = cand[(row * kSeg + g) * kSegCap + j];
+    }
     __syncthreads();
+    const int n = seg_off[kSeg];
     emit_ranked(lc, n, n < k ? n : k, k, vals + row * k, idx + row * k);
   } else {
     select_topk_row(DotKeys{U + row * D, E, D}, N, k, n_skip_low, vals + row * k, idx + row * k);
@@ -543,7 +610,9 @@ static size_t full_sort_lds() { return static_cast<size_t>(BM + BN) * LDK * size
 template <bool VEC, int EPI>
 static int launch_tiled(const float* U, int64_t B, const float* E, int64_t N, int64_t D, const float* bias, float* S,
                         int64_t ldS, hipStream_t st, TopkArgs ta = TopkArgs{}) {
-  const dim3 grid(static_cast<unsigned>((N + BN - 1) / BN), static_cast<unsigned>((B + BM - 1) / BM));
+  int64_t nblk = (N + BN - 1) / BN;
+  if (EPI == EPI_TILEMAX && ta.col_stride > 1) nblk = (nblk + ta.col_stride - 1) / ta.col_stride;
+  const dim3 grid(static_cast<unsigned>(nblk), static_cast<unsigned>((B + BM - 1) / BM));
   const size_t lds = full_sort_lds();
   auto k = full_sort_kernel<VEC, EPI>;
   if (int rc = set_lds(k, lds)) return rc;
@@ -602,17 +671,31 @@ extern "C" int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const flo
 
 // Fused path layout inside the workspace (all regions 256-B aligned).
 struct FusedLayout {
-  int64_t NT, cap, off_tilemax, off_tau, off_cnt, off_cand, bytes;
+  int64_t NT, cap, stride, seg_width, off_tilemax, off_tau, off_cnt, off_cand, bytes;
 };
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k) {
   FusedLayout L;
-  L.NT = (N + 63) / 64;
-  L.cap = 4 * k < 256 ? 256 : 4 * k;  // <= 1024 for k <= 256
+  // Pass 1 only needs a LOWER bound of the k-th best score, and the k-th best of any subset of the columns is
+  // one: it visits every `stride`-th 128-column block (1/stride of the GEMM work).  The filter pass then lets
+  // about k * stride candidates per row through instead of ~2k, so the lists get the full 1024 entries the
+  // finalize kernel can rank, and stride is capped so that the expected count stays below half of that; the
+  // sampled blocks must still hold at least 2k tiles.  Results are unchanged: every true top-k entry has a
+  // score >= tau and the finalize kernel ranks exactly.
+  const int64_t nblk = (N + BN - 1) / BN;
+  static const int64_t max_stride = [] { const char* e = getenv("MI_OOV_TOPK_STRIDE"); return e ? atoll(e) : 8LL; }();
+  int64_t stride = max_stride;
+  if (stride > 256 / k) stride = 256 / k;  // ~k * stride candidates per row: a quarter of the 1024 slots
+  if (stride > nblk / k) stride = nblk / k;  // sampled 64-column tiles: 2 * nblk / stride >= 2k
+  if (stride < 1) stride = 1;
+  L.stride = stride;
+  L.NT = 2 * ((nblk + stride - 1) / stride);
+  L.cap = kSeg * kSegCap;
+  L.seg_width = (nblk + kSeg - 1) / kSeg;
   L.off_tilemax = 0;
   L.off_tau = align256(L.off_tilemax + B * L.NT * 4);
   L.off_cnt = align256(L.off_tau + B * 4);
-  L.off_cand = align256(L.off_cnt + B * 4);
+  L.off_cand = align256(L.off_cnt + B * kSeg * 4);
   L.bytes = align256(L.off_cand + B * L.cap * 8);
   return L;
 }
@@ -642,8 +725,10 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
     ta.cnt = reinterpret_cast<int*>(ws + L.off_cnt);
     ta.cand = reinterpret_cast<uint64_t*>(ws + L.off_cand);
     ta.cap = static_cast<int>(L.cap);
+    ta.seg_width = static_cast<int>(L.seg_width);
     ta.n_skip_low = n_skip_low;
-    if (hipMemsetAsync(ta.cnt, 0, static_cast<size_t>(B) * 4, st) != hipSuccess) {
+    ta.col_stride = static_cast<int>(L.stride);
+    if (hipMemsetAsync(ta.cnt, 0, static_cast<size_t>(B) * kSeg * 4, st) != hipSuccess) {
       check_launch();
       return MI_OOV_ERR_LAUNCH;
     }
@@ -658,7 +743,7 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
              : launch_tiled<false, EPI_FILTER>(U, B, E, N, D, nullptr, nullptr, 0, st, ta);
     if (rc) return rc;
     hipLaunchKernelGGL(topk_finalize_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, U, E, B, N, D,
-                       static_cast<int>(k), n_skip_low, ta.cnt, ta.cand, ta.cap, vals, idx);
+                       static_cast<int>(k), n_skip_low, ta.cnt, ta.cand, vals, idx);
     return check_launch();
   }
   float* S = static_cast<float*>(workspace);
