@@ -431,3 +431,33 @@ def test_directau_matches_reference(mi, golden, dev):
     assert np.allclose(pred.cpu().numpy(), z[tag + "__pred"], rtol=RTOL, atol=1e-6)
     with pytest.raises(NotImplementedError):
         model.full_sort_predict({"user_id": users[:4]})
+
+
+def test_dhe_full_size_properties(mi, oracle, dev):
+    """BASELINE config 3 shape (65536 ids x 1024 SipHash keys -> 1024-512-512-512-64 MLP): the hash matrix is
+    checked exactly on 64 sampled rows against the oracle, the MLP output bit for bit on the same rows (the tiled
+    MFMA kernel runs the oracle's k-ordered fmaf chain), and both are deterministic."""
+    from mi_oov import ops
+    g = torch.Generator(device=dev).manual_seed(12)
+    B, K, D = 65536, 1024, 64
+    ids = torch.randint(5_000_000, 10_000_000, (B,), generator=g, device=dev)
+    keys = torch.randint(0, 256, (K, 16), generator=g, device=dev, dtype=torch.uint8)
+    hm = ops.siphash24_mod(ids, keys)
+    assert hm.shape == (B, K) and torch.equal(hm, ops.siphash24_mod(ids, keys))
+    rows = torch.randint(0, B, (64,), generator=g, device=dev)
+    want = oracle.siphash24_mod(ids[rows].cpu().numpy(), keys.cpu().numpy())
+    assert np.array_equal(hm[rows].cpu().numpy(), want)
+    dims = [(K, 512), (512, 512), (512, 512), (512, D)]
+    Ws = [torch.randn((o, i), generator=g, device=dev) / (i ** 0.5) for i, o in dims]
+    bs = [0.1 * torch.randn((o,), generator=g, device=dev) for _, o in dims]
+    x = hm / 16777216.0
+    y = x
+    for j, (w, b) in enumerate(zip(Ws, bs)):
+        y = ops.linear_act(y, w, b, "gelu" if j < 3 else "sigmoid")
+    ref = x[rows].cpu().numpy()
+    for j, (w, b) in enumerate(zip(Ws, bs)):
+        ref = oracle.linear_act(ref, w.cpu().numpy(), b.cpu().numpy(), 1 if j < 3 else 2)
+    got = y[rows].cpu().numpy()
+    # the activations go through expf / erff, whose device and host implementations differ in the last ulp
+    assert np.abs(got - ref).max() <= 2e-6
+    assert (got > 0).all() and (got < 1).all()
