@@ -477,7 +477,7 @@ static int run_lsh(LshParams p, void* stream) {
   // without score / in-vocabulary table (the training forward and TorchLSHash.hash_points)
   const bool d_ok = want_emb ? (p.D == 64 && aligned16(p.buckets)) : true;
   const bool bits_ok = !p.bits || (p.H == 8 && !p.score && !p.table && (reinterpret_cast<uintptr_t>(p.bits) & 7u) == 0);
-  const bool h_ok = p.H <= 8 || (p.H <= 32 && want_emb && !p.bits);  // 9..32 planes: lsh64g_kernel, embeddings only
+  const bool h_ok = p.H <= 8 || (p.H <= 64 && want_emb && !p.bits);  // 9..64 planes: lsh64g_kernel, embeddings only
   if (vec && p.F == 64 && d_ok && h_ok && bits_ok && aligned16(p.planes) && lsh64_enabled())
     return launch_lsh64(p.ids, p.B, p.feat, p.N, p.table, p.n_vocab, p.planes, static_cast<int>(p.H), p.buckets,
                         p.other, p.score, p.out, st, p.bits);

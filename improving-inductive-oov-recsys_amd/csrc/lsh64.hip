@@ -122,7 +122,7 @@ __device__ __forceinline__ float4 masked_mean(float4 acc, float cnt) {
   }
   const float amin = fminf(fminf(fabsf(acc.x), fabsf(acc.y)), fminf(fabsf(acc.z), fabsf(acc.w)));
   const float amax = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
-  if (!(amin >= 0x1p-100f) || !(amax < __builtin_inff())) {
+  if (!(amin >= 0x1p-100f) || !(amax < __builtin_inff()) || !(cnt <= 32.f)) {  // divisors above 32: not verified
     emb.x = acc.x / cnt;
     emb.y = acc.y / cnt;
     emb.z = acc.z / cnt;
@@ -329,7 +329,7 @@ __global__ __launch_bounds__(kBlk, 4) void lsh64_kernel(const int64_t* __restric
   }
 }
 
-// ---- 8 < H <= 32: the same tile, planes taken eight at a time ------------------------------------------------
+// ---- 8 < H <= 64: the same tile, planes taken eight at a time ------------------------------------------------
 // The plane / bucket slices no longer fit in VGPRs for the whole kernel (2 x H float4 per lane), so they stay in
 // LDS (zero-padded to a multiple of 8 planes) and each group of 8 is read into the same 16 float4 registers per
 // tile; the four gathered rows stay in registers across the groups, the bucket-row chain acc = fma(bit_h, W[h],
@@ -622,8 +622,8 @@ static int launch64_h(const int64_t* ids, int64_t B, const float* feat, int64_t 
 int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
                  const float* planes, int H, const float* buckets, const float* other, float* score, float* out,
                  hipStream_t st, uint8_t* bits) {
-  if (H > 8) {  // 9..32 planes: groups of eight through LDS (no codes output on this path)
-    if (H > 32 || bits) return MI_OOV_ERR_SHAPE;
+  if (H > 8) {  // 9..64 planes: groups of eight through LDS (no codes output on this path)
+    if (H > 64 || bits) return MI_OOV_ERR_SHAPE;
 #define MI_GOG(S, T, L) return launch64g<S, T, L>(ids, B, feat, N, vtable, n_vocab, planes, buckets, H, other, score, out, st)
     if (vtable) {
       if (score && out) MI_GOG(true, true, true);

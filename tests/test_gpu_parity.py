@@ -170,7 +170,8 @@ def test_lsh_shapes_vs_oracle(B, N, F, H, D, oracle, ops, dev):
 
 
 @pytest.mark.parametrize("F,H,D", [(64, 8, 64), (64, 3, 64), (64, 12, 64), (22, 8, 64), (64, 8, 32), (64, 9, 64),
-                                   (64, 16, 64), (64, 24, 64), (64, 31, 64), (64, 32, 64), (64, 33, 64)])
+                                   (64, 16, 64), (64, 24, 64), (64, 31, 64), (64, 32, 64), (64, 33, 64), (64, 48, 64),
+                                   (64, 64, 64), (64, 65, 64)])
 def test_lookup_and_lookup_score_vs_oracle(F, H, D, oracle, ops, dev):
     """BPR lookups (in-vocab rows spliced with lsh rows) and the lookup fused with BPR.predict;
     (64, <=8, 64) takes the register-resident kernel, the others the generic LDS kernel."""
@@ -197,7 +198,7 @@ def test_lookup_and_lookup_score_vs_oracle(F, H, D, oracle, ops, dev):
     assert bits_equal(s2.cpu().numpy(), oracle.rowdot(other, want))
 
 
-@pytest.mark.parametrize("H", [3, 6, 7, 8, 13, 24, 32])
+@pytest.mark.parametrize("H", [3, 6, 7, 8, 13, 24, 32, 47, 64])
 def test_lsh_division_extremes(H, oracle, ops, dev):
     """The hot kernel divides by the code's popcount with a shared reciprocal + one fma refinement and
     falls back to IEEE division for tiny / zero / infinite sums: sweep bucket tables whose entries are
