@@ -122,7 +122,11 @@ __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __res
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-  // K loop.  A register-prefetched (software-pipelined) variant measured SLOWER on MI355X (full sort
+  // K loop.  Measured and dropped for D = 64: a "strip" kernel (user rows staged once per workgroup, the next block of
+  // E prefetched into registers during the MFMAs, 2 x 34 KB LDS, 2 workgroups per CU): 358 vs 363 us for the full sort,
+  // 547 vs 461 us for the fused top-k (221-256 VGPRs) -- the tile loop is not waiting for its operands; the f32 matrix
+  // cores at their sustained clock are the bound.
+  // A register-prefetched (software-pipelined) variant measured SLOWER on MI355X (full sort
   // 442 vs 362 us, dhe MLP 1.53 vs 1.49 ms): with 36 KB of LDS four workgroups share a CU and already
   // overlap one another's staging with MFMA work, while the extra 32 VGPRs of prefetch cost occupancy.
   for (int kc = 0; kc < D; kc += KC) {
