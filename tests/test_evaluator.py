@@ -160,3 +160,26 @@ def test_gpu_full_sort_rec_topk_matches_reference(golden, dev):
     col = mi_oov.evaluator.FullSortCollector([int(k) for k in z["topk"]])
     rec = col.eval_batch_collect_full(T(z["U"]), T(z["E"]), (T(z["hist_u"]), T(z["hist_i"])), T(z["pos_u"]), T(z["pos_i"]))
     assert np.array_equal(rec.cpu().numpy(), z["rec_topk"])
+
+
+def test_topk_metrics_edge_cases():
+    """Users without positives give NaN recall rows, which the reference drops from the mean of that metric only
+    (base_metric.py:74-79); an all-miss block gives zeros; MAP / NDCG cap their ideal at min(positives, k)."""
+    import mi_oov
+    rec = np.array([[1, 0, 1, 2],      # 2 positives, hits at ranks 1 and 3
+                    [0, 0, 0, 0],      # no positives at all -> recall NaN (0/0), dropped for recall only
+                    [0, 1, 0, 5]])     # 5 positives, one hit at rank 2
+    m = mi_oov.evaluator.topk_metrics(rec, [1, 3], ("recall", "hit", "precision", "mrr", "ndcg"), decimal_place=6)
+    assert m["recall@1"] == pytest.approx((0.5 + 0.0) / 2) and m["recall@3"] == pytest.approx((1.0 + 0.2) / 2)
+    assert m["hit@1"] == pytest.approx(1 / 3, abs=1e-6) and m["hit@3"] == pytest.approx(2 / 3, abs=1e-6)
+    assert m["precision@3"] == pytest.approx((2 / 3 + 0 + 1 / 3) / 3, abs=1e-6)
+    assert m["mrr@3"] == pytest.approx((1.0 + 0.0 + 0.5) / 3, abs=1e-6)
+    idcg2 = 1 + 1 / np.log2(3)
+    dcg_a = 1 + 1 / np.log2(4)
+    idcg3 = idcg2 + 1 / np.log2(4)
+    # the user without positives is NOT dropped from ndcg: the reference's `idcg[row, idx:] = idcg[row, idx - 1]` wraps to the
+    # last column for idx = 0 (metrics.py:206-207), so its ideal is non-zero and its ndcg is 0
+    want = (dcg_a / idcg2 + 0.0 + (1 / np.log2(3)) / idcg3) / 3
+    assert m["ndcg@3"] == pytest.approx(want, abs=1e-6)
+    zero = mi_oov.evaluator.topk_metrics(np.array([[0, 0, 3]]), [2], ("recall", "hit"))
+    assert zero == {"recall@2": 0.0, "hit@2": 0.0}
