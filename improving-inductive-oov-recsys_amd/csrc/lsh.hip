@@ -58,22 +58,29 @@ template <int FC, int DC, bool VEC, int R>
 __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int FP = FC * 64, DP = DC * 64;
+  const int lane = threadIdx.x & 63;
+  const int l16 = lane & 15;
+  const int grp = lane >> 4;
+  const int wv = threadIdx.x >> 6;
+  const int64_t ntiles = (p.B + 4 * R - 1) / (4 * R);
+  const int64_t tile0 = static_cast<int64_t>(blockIdx.x) * 4 + wv;
+  // ids of the first tile before the weights are staged (as in lsh64_kernel): the first hop overlaps the staging
+  int64_t idn[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int64_t row = tile0 * (4 * R) + r * 4 + grp;
+    idn[r] = p.ids[row < p.B ? row : p.B - 1];
+  }
   float* sP = smem;
   float* sW = smem + p.H * FP;
   stage_padded(sP, p.planes, p.H, p.F, FP);
   if (p.buckets) stage_padded(sW, p.buckets, p.H, p.D, DP);
   __syncthreads();
 
-  const int lane = threadIdx.x & 63;
-  const int l16 = lane & 15;
-  const int grp = lane >> 4;
-  const int wv = threadIdx.x >> 6;
-  const int64_t ntiles = (p.B + 4 * R - 1) / (4 * R);
   const int H = static_cast<int>(p.H);
   const bool want_emb = (p.out != nullptr) || (p.score != nullptr);
 
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
-       tile += static_cast<int64_t>(gridDim.x) * 4) {
+  for (int64_t tile = tile0; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
     int64_t row[R];
     int64_t id[R];
     bool live[R], valid[R], oov[R];
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
     for (int r = 0; r < R; ++r) {
       row[r] = tile * (4 * R) + r * 4 + grp;
       live[r] = row[r] < p.B;
-      id[r] = p.ids[live[r] ? row[r] : p.B - 1];
+      id[r] = (tile == tile0) ? idn[r] : p.ids[live[r] ? row[r] : p.B - 1];
     }
 #pragma unroll
     for (int r = 0; r < R; ++r) {
