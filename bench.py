@@ -332,7 +332,10 @@ def main():
         }
         out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
         if world == 1 and use_graph and args.in_flight > 1:
-            pl = pipelined(args, step, per_lookup)
+            try:  # an extra, never allowed to cost the headline line
+                pl = pipelined(args, step, per_lookup)
+            except Exception as e:  # noqa: BLE001
+                pl = {"error": f"{type(e).__name__}: {e}"}
             if pl is not None:
                 out["pipelined"] = pl
         if world == 1 and not args.no_cpu_baseline:
