@@ -339,7 +339,11 @@ def main():
             if pl is not None:
                 out["pipelined"] = pl
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, feat, planes, buckets, args.cpu_seconds)
+            try:
+                out["cpu_baseline"] = cpu_baseline(args, feat, planes, buckets, args.cpu_seconds)
+            except Exception as e:  # noqa: BLE001 -- the GPU line is still worth printing
+                out["cpu_baseline"] = {"value": None, "unit": "lookups/s", "cores": host_cores(), "kind": "port",
+                                       "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
