@@ -63,3 +63,15 @@ def test_argument_validation_of_the_widened_entry_points(lib):
     assert lib.mi_oov_score_topk_workspace(4096, 50_000, 20) > 0
     assert lib.mi_oov_linear_act(None, 4, 16, None, None, 8, 7, None, None) in (-2, -3)       # unknown activation
     assert lib.mi_oov_last_hip_error() == 0                                                  # nothing touched the GPU
+
+
+def test_header_is_plain_c(tmp_path):
+    """include/mi_oov.h must be consumable from C (the drop-in boundary has no C++ or torch types)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "use_header.c"
+    src.write_text('#include "mi_oov.h"\nint main(void) { return mi_oov_version() == 0; }\n')
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", f"-I{root}/include", str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
