@@ -41,8 +41,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=200)
+    # defaults: 20000 timed steps = 0.17 s on the GPU, so that the two barrier + synchronize fences around the timed
+    # region (~0.9 ms together) stay below 1 % of it; 22000 distinct id batches = 11.5 GB of the 288 GB
+    ap.add_argument("--steps", type=int, default=20000)
+    ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed pre-warm-up that lets the GPU leave its idle clock (sclk idles at ~500 MHz and "
                          "needs tens of ms of load to ramp; 200 x 11 us steps alone are over before it does)")

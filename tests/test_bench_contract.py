@@ -50,4 +50,4 @@ def test_defaults_finish_in_minutes(monkeypatch):
     bench = _bench()
     monkeypatch.setattr(sys, "argv", ["bench.py"])
     a = bench.parse()
-    assert a.gpus == 1 and a.steps * 10e-6 < 1.0 and a.batch == 65536 and a.items == 10_000_000 and a.hashes == 8
+    assert a.gpus == 1 and a.steps * 10e-6 < 1.0 and a.steps >= 2000 and a.batch == 65536 and a.items == 10_000_000 and a.hashes == 8
