@@ -11,6 +11,7 @@ rm -rf $out/${tag}_all_trace
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_all_trace -- python3 tools/tune.py > $out/${tag}_all_cases.log 2>&1 || { tail -5 $out/${tag}_all_cases.log; exit 2; }
 python3 tools/summarize_profile.py --trace $out/${tag}_all_trace --out $out/${tag}_all_kernels.json \
   --command "rocprofv3 --kernel-trace --stats -- python3 tools/tune.py" > /dev/null
+rm -f $out/${tag}_all_trace/*/*kernel_trace.csv
 python3 - <<PY
 import json
 p = "$out/${tag}_all_kernels.json"

@@ -17,5 +17,6 @@ python3 tools/summarize_profile.py --trace $out/${tag}_trace --pmc $out/${tag}_p
   --command "rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline ; rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE -- python3 bench.py --steps 50 --warmup 10 --no-cpu-baseline" > /dev/null
 (head -1 $out/${tag}_trace/*/*kernel_stats.csv; grep mi_oov $out/${tag}_trace/*/*kernel_stats.csv) | cut -c1-400 > $out/${tag}_bench_kernel_stats.csv
 grep '"metric"' $out/${tag}_trace.log | tail -1 > $out/${tag}_bench_line_under_rocprof.json
+rm -f $out/${tag}_trace/*/*kernel_trace.csv $out/${tag}_pmc_fetch/*/*counter_collection.csv $out/${tag}_pmc_write/*/*counter_collection.csv  # raw per-launch rows: 100+ MB
 cat $out/${tag}_bench_kernel_stats.csv
 python3 -c "import json; d=json.load(open('$out/${tag}_bench_line_under_rocprof.json')); print('bench under rocprof: avg_launch_us', d['roofline']['avg_launch_us'], 'value', d['value'])"
