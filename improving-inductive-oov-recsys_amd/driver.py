@@ -93,12 +93,55 @@ def _remap(values):
     return vocab
 
 
+def _remap_in_order(*token_lists):
+    """token -> id in order of first appearance over the lists (0 = [PAD]): RecBole's remap over the concatenated
+    benchmark files (R/data/dataset/dataset.py `_remap_ID_all`), which is what puts every training-time id below
+    every inductive-only id in an `X_ind` dataset (S/perform_hashing.py:101-138)."""
+    vocab = {}
+    for tokens in token_lists:
+        for t in tokens:
+            if t not in vocab:
+                vocab[t] = len(vocab) + 1
+    return vocab
+
+
 class AtomicDataset:
-    def __init__(self, name, data_path, user_field="user_id", item_field="item_id"):
+    """`<name>.inter` (+ `.user`, `.item`), or -- with `benchmark_filename=[train, ..., test]` as in the reference's
+    inductive datasets (`benchmark_filename: ['train', 'empty', 'test_filt']`) -- the pre-split files
+    `<name>.<part>.inter`: ids are then numbered by first appearance, train first, so `n_train_users/items` is the
+    size of the transductive vocabulary and everything above it is out-of-vocabulary; `split` holds the part of
+    every interaction."""
+
+    def __init__(self, name, data_path, user_field="user_id", item_field="item_id", benchmark_filename=None):
         root = os.path.join(data_path, name)
-        inames, _, icols = _read_atomic(os.path.join(root, f"{name}.inter"))
-        users_raw, items_raw = icols[inames.index(user_field)], icols[inames.index(item_field)]
-        self.uvocab, self.ivocab = _remap(users_raw), _remap(items_raw)
+        self.split = None
+        if benchmark_filename:
+            parts = [p for p in benchmark_filename]
+            users_raw, items_raw, split = [], [], []
+            per_part = []
+            for k, part in enumerate(parts):
+                inames, _, icols = _read_atomic(os.path.join(root, f"{name}.{part}.inter"))
+                u, i = icols[inames.index(user_field)], icols[inames.index(item_field)]
+                per_part.append((u, i))
+                users_raw += u
+                items_raw += i
+                split += [k] * len(u)
+            self.uvocab = _remap_in_order(*(u for u, _ in per_part))
+            self.ivocab = _remap_in_order(*(i for _, i in per_part))
+            for path, field, vocab in ((os.path.join(root, f"{name}.user"), user_field, self.uvocab),
+                                       (os.path.join(root, f"{name}.item"), item_field, self.ivocab)):
+                if os.path.exists(path):  # entities that only occur in the feature files come last
+                    names, _, raw = _read_atomic(path)
+                    for t in raw[names.index(field)]:
+                        if t not in vocab:
+                            vocab[t] = len(vocab) + 1
+            self.split = np.array(split, dtype=np.int64)
+            self.n_train_users = len(set(per_part[0][0])) + 1
+            self.n_train_items = len(set(per_part[0][1])) + 1
+        else:
+            inames, _, icols = _read_atomic(os.path.join(root, f"{name}.inter"))
+            users_raw, items_raw = icols[inames.index(user_field)], icols[inames.index(item_field)]
+            self.uvocab, self.ivocab = _remap(users_raw), _remap(items_raw)
         self.user_num, self.item_num = len(self.uvocab) + 1, len(self.ivocab) + 1
         self.inter_user = np.array([self.uvocab[u] for u in users_raw], dtype=np.int64)
         self.inter_item = np.array([self.ivocab[i] for i in items_raw], dtype=np.int64)
@@ -233,11 +276,20 @@ def run(args):
     np.random.seed(seed)
     torch.manual_seed(seed)
     ukey, ikey = cfg["USER_ID_FIELD"], cfg["ITEM_ID_FIELD"]
-    ds = AtomicDataset(cfg["dataset"], cfg["data_path"], ukey, ikey)
-    n_users = max(2, int(ds.user_num * (1 - cfg["oov_fraction"])))
-    n_items = max(2, int(ds.item_num * (1 - cfg["oov_fraction"])))
-    rng = np.random.default_rng(seed)
-    is_test = rng.random(len(ds.inter_user)) < 0.1
+    bench_files = cfg["benchmark_filename"]
+    if isinstance(bench_files, str):
+        bench_files = [p.strip(" '\"[]") for p in bench_files.split(",") if p.strip(" '\"[]")]
+    ds = AtomicDataset(cfg["dataset"], cfg["data_path"], ukey, ikey, benchmark_filename=bench_files)
+    if ds.split is not None:  # pre-split inductive dataset: vocabulary = what the train part contains
+        n_users, n_items = ds.n_train_users, ds.n_train_items
+        is_test = ds.split == ds.split.max()
+        keep = (ds.split == 0) | is_test
+        ds.inter_user, ds.inter_item, is_test = ds.inter_user[keep], ds.inter_item[keep], is_test[keep]
+    else:
+        n_users = max(2, int(ds.user_num * (1 - cfg["oov_fraction"])))
+        n_items = max(2, int(ds.item_num * (1 - cfg["oov_fraction"])))
+        rng = np.random.default_rng(seed)
+        is_test = rng.random(len(ds.inter_user)) < 0.1
     tu = torch.from_numpy(ds.inter_user[~is_test]).to(device)
     ti = torch.from_numpy(ds.inter_item[~is_test]).to(device)
     eu = torch.from_numpy(ds.inter_user[is_test]).to(device)
@@ -256,6 +308,7 @@ def run(args):
           f"{type(embedder).__name__ if embedder else None}, mapper {type(mapper).__name__ if mapper else None}")
 
     bs = int(cfg["train_batch_size"])
+    neg_hi = n_items if ds.split is not None else ds.item_num  # pre-split: negatives from the training catalogue
     for epoch in range(int(cfg["epochs"])):
         t0, total, nb = time.time(), 0.0, 0
         perm = torch.randperm(len(tu), generator=gen, device=device)
@@ -266,7 +319,7 @@ def run(args):
             for lo in range(0, len(perm), bs):
                 idx = perm[lo:lo + bs]
                 batch = {ukey: tu[idx], ikey: ti[idx],
-                         cfg["NEG_PREFIX"] + ikey: torch.randint(1, ds.item_num, (len(idx),), generator=gen, device=device)}
+                         cfg["NEG_PREFIX"] + ikey: torch.randint(1, neg_hi, (len(idx),), generator=gen, device=device)}
                 if phase == "oov":
                     if random.random() > cfg["oov_train_ratio"]:
                         continue

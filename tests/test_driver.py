@@ -34,6 +34,46 @@ def write_dataset(root, name="toy", n_users=300, n_items=400, n_inter=20000, see
     return root
 
 
+def write_split_dataset(root, name="toy_ind", n_users=300, n_items=400, n_inter=20000, seed=1):
+    """The reference's inductive layout (S/perform_hashing.py:101-138): <name>.train.inter / .empty.inter /
+    .test_filt.inter; the last 20 % of the users and items only ever appear in the test part."""
+    base = write_dataset(root, "tmp_src", n_users, n_items, n_inter, seed)
+    src = os.path.join(base, "tmp_src")
+    d = os.path.join(root, name)
+    os.makedirs(d, exist_ok=True)
+    lines = open(os.path.join(src, "tmp_src.inter")).read().splitlines()
+    header, rows = lines[0], lines[1:]
+    new_u = {f"u{u}" for u in range(int(0.8 * n_users), n_users)}
+    new_i = {f"i{i}" for i in range(int(0.8 * n_items), n_items)}
+    rng = np.random.default_rng(seed)
+    train, test = [], []
+    for r in rows:
+        u, i = r.split("\t")[:2]
+        (test if (u in new_u or i in new_i or rng.random() < 0.05) else train).append(r)
+    for part, content in (("train", train), ("empty", []), ("test_filt", test)):
+        with open(os.path.join(d, f"{name}.{part}.inter"), "w") as f:
+            f.write("\n".join([header] + content) + "\n")
+    for ext in ("user", "item"):
+        with open(os.path.join(d, f"{name}.{ext}"), "w") as f:
+            f.write(open(os.path.join(src, f"tmp_src.{ext}")).read())
+    return root, len({r.split("\t")[0] for r in train}), len({r.split("\t")[1] for r in train})
+
+
+def test_pre_split_inductive_dataset(tmp_path):
+    """benchmark_filename = [train, empty, test_filt]: ids numbered by first appearance, train first, so the
+    transductive vocabulary is a prefix and every test-only entity is out-of-vocabulary."""
+    from mi_oov import driver
+    root, n_tu, n_ti = write_split_dataset(str(tmp_path))
+    ds = driver.AtomicDataset("toy_ind", root, benchmark_filename=["train", "empty", "test_filt"])
+    assert ds.n_train_users == n_tu + 1 and ds.n_train_items == n_ti + 1
+    tr, te = ds.split == 0, ds.split == 2
+    assert tr.sum() + te.sum() == len(ds.split) and not (ds.split == 1).any()
+    assert ds.inter_user[tr].max() < ds.n_train_users and ds.inter_item[tr].max() < ds.n_train_items
+    assert ds.inter_user[te].max() >= ds.n_train_users and ds.inter_item[te].max() >= ds.n_train_items  # OOV in the test part
+    assert ds.user_num == 301 and ds.item_num == 401           # feature-file-only entities are appended
+    assert len(ds.get_user_feature()) == ds.user_num and ds.get_item_feature()["vec"].shape == (ds.item_num, 4)
+
+
 def test_parse_args_like_reference():
     from mi_oov import driver
     a = driver.custom_parse_args(["run_recbole.py", "--dataset=ml-100k", "--model=BPR", "--embedding_size=64",
@@ -70,13 +110,18 @@ def test_atomic_loader(tmp_path):
     ["--inductive_embedder=mean"],
     ["--inductive_mapper=random", "--add_oov_buckets"],
     ["--model=DirectAU", "--inductive_embedder=lsh", "--add_oov_buckets", "--train_oov", "--gamma=0.5"],
+    ["--dataset=toy_ind", "--benchmark_filename=train,empty,test_filt", "--inductive_embedder=lsh", "--add_oov_buckets",
+     "--train_oov"],
 ])
 def test_end_to_end(flags, tmp_path, monkeypatch, dev):
     from mi_oov import driver
     monkeypatch.chdir(tmp_path)  # dhe writes ./hash_keys
     root = write_dataset(str(tmp_path))
+    if any(f.startswith("--dataset=") for f in flags):
+        write_split_dataset(str(tmp_path))
     base = [] if any(f.startswith("--model=") for f in flags) else ["--model=BPR"]
-    args = driver.custom_parse_args(["x", "--dataset=toy", f"--data_path={root}", "--embedding_size=32",
+    base += [] if any(f.startswith("--dataset=") for f in flags) else ["--dataset=toy"]
+    args = driver.custom_parse_args(["x", f"--data_path={root}", "--embedding_size=32",
                                      "--user_oov_buckets=8", "--item_oov_buckets=8", "--epochs=4",
                                      "--learning_rate=0.01", "--train_batch_size=512"] + base + flags)
     results, model = driver.run(args)
