@@ -309,7 +309,13 @@ def run(args):
 
     bs = int(cfg["train_batch_size"])
     neg_hi = n_items if ds.split is not None else ds.item_num  # pre-split: negatives from the training catalogue
-    for epoch in range(int(cfg["epochs"])):
+    if cfg["load_checkpoint"]:
+        # reference checkpoints keep their tensors under 'state_dict' next to a pickled Config (trainer.py:304-313):
+        # only the tensors are read (weights_only), whichever of the two layouts the file has
+        blob = torch.load(cfg["load_checkpoint"], map_location=device, weights_only=True)
+        model.load_state_dict(blob["state_dict"] if isinstance(blob, dict) and "state_dict" in blob else blob)
+        print(f"loaded {cfg['load_checkpoint']}")
+    for epoch in range(0 if cfg["eval_only"] else int(cfg["epochs"])):
         t0, total, nb = time.time(), 0.0, 0
         perm = torch.randperm(len(tu), generator=gen, device=device)
         oov_pass = bool(cfg["train_oov"]) and bool(cfg["oov_only_epoch"])
@@ -337,6 +343,9 @@ def run(args):
             if phase == "oov":
                 model.set_oov_eval()
         print(f"epoch {epoch}: loss {total / max(1, nb):.4f} over {nb} batches, {time.time() - t0:.2f}s")
+    if cfg["save_checkpoint"]:
+        torch.save({"state_dict": model.state_dict()}, cfg["save_checkpoint"])  # tensors only: weights_only-loadable
+        print(f"saved {cfg['save_checkpoint']}")
     model.eval()
     model.set_oov_eval()
     results = evaluate(model, eu, ei, ds.item_num, cfg, n_users, n_items, device, gen)

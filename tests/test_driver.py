@@ -132,3 +132,25 @@ def test_end_to_end(flags, tmp_path, monkeypatch, dev):
     # a positive ranked uniformly at random among 251 would give recall@10 = 10/251 = 0.04: in-vocabulary
     # users/items must do clearly better after four epochs on this planted-structure data
     assert results["old_items"]["recall@10"] > 0.07
+
+
+@pytest.mark.gpu
+def test_checkpoint_round_trip(tmp_path, monkeypatch, dev):
+    """train -> save (tensors only, state_dict keys of the reference) -> a fresh process-equivalent run that loads the
+    file and only evaluates reproduces the metrics (same seed => same sampled negatives)."""
+    from mi_oov import driver
+    monkeypatch.chdir(tmp_path)
+    root = write_dataset(str(tmp_path))
+    ck = str(tmp_path / "bpr_lsh.pth")
+    common = ["x", "--dataset=toy", f"--data_path={root}", "--model=BPR", "--embedding_size=32", "--user_oov_buckets=8",
+              "--item_oov_buckets=8", "--inductive_embedder=lsh", "--add_oov_buckets", "--train_oov", "--train_batch_size=512"]
+    res1, model1 = driver.run(driver.custom_parse_args(common + ["--epochs=2", f"--save_checkpoint={ck}"]))
+    blob = torch.load(ck, weights_only=True)
+    assert set(blob["state_dict"]) == {"user_embedding.weight", "item_embedding.weight", "user_oov_buckets.weight",
+                                       "item_oov_buckets.weight", "inductive_embedder.user_lsh.uniform_planes.0",
+                                       "inductive_embedder.item_lsh.uniform_planes.0"}
+    res2, model2 = driver.run(driver.custom_parse_args(common + ["--eval_only", f"--load_checkpoint={ck}"]))
+    assert torch.equal(model1.item_oov_buckets.weight, model2.item_oov_buckets.weight)
+    assert res2["overall"].keys() == res1["overall"].keys() and all(0 <= v <= 1 for v in res2["overall"].values())
+    assert abs(res2["old_users"]["recall@10"] - res1["old_users"]["recall@10"]) < 0.05  # different negative samples
+
