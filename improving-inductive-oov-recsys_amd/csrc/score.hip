@@ -56,14 +56,15 @@ __device__ __forceinline__ void load8_split(const float* M, int64_t row, int64_t
 // short lists.  The GEMM passes replace the 0.8 GB write plus four re-reads of the materialised path.  Pass 1 only
 // visits every 8th 128-column block (the k-th best tile maximum of a SUBSET of the columns is still a lower
 // bound), candidates are collected in LDS and appended in one sweep per tile into 64 interleaved per-row
-// segments, tau is found by rank counting: 4096 x 50000 x 64, k = 20: 0.47 ms (two full passes + one list per
-// row: 0.76 ms).
+// segments, tau is found by rank counting: 4096 x 50000 x 64, k = 20: 0.45 ms (two full passes + one list per
+// row: 0.76 ms).  The filter compares each score with tau as a float (one v_cmp per element); keys are built only for the survivors.
 enum { EPI_NONE = 0, EPI_BIAS = 1, EPI_BIAS_GELU = 2, EPI_BIAS_SIGMOID = 3, EPI_TILEMAX = 4, EPI_FILTER = 5 };
 
 struct TopkArgs {
   uint32_t* tilemax;    // [B, NT] best order key per 64-column tile (0 = no valid column)
   int64_t NT;
   const uint32_t* tau;  // [B] lower bound of the k-th best key
+  const float* tauf;    // [B] the same bound as a float threshold: a score passes iff !(score < tauf)
   int* cnt;             // [B, kSeg] candidates appended so far, per segment (see below)
   uint64_t* cand;       // [B, kSeg, kSegCap] (key << 32) | (0xFFFFFFFF - column)
   int seg_width;        // 128-column blocks per segment
@@ -207,12 +208,15 @@ __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __res
       for (int r = 0; r < 16; ++r) {
         const int lrow = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
         const int64_t row = b0 + lrow;
-        const uint32_t tau = (row < B) ? ta.tau[row] : 0xFFFFFFFFu;
+        // one float compare per score instead of a key conversion + integer compare (the epilogue is a third of this
+        // pass): !(s < tauf) is true for s >= tauf and for NaN scores, which rank first.  A superset of key >= tau (it
+        // also lets -0 through when tau is +0): harmless, the finalize kernel ranks by key.
+        const float tauf = (row < B) ? ta.tauf[row] : __builtin_inff();
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
           const int64_t col = n0 + wn * 64 + n * 32 + i32;
-          const uint32_t key = order_key(acc[m][n][r]);
-          if (row < B && col < N && col >= ta.n_skip_low && key >= tau) {
+          if (!(acc[m][n][r] < tauf) && row < B && col < N && col >= ta.n_skip_low) {
+            const uint32_t key = order_key(acc[m][n][r]);
             const uint64_t packed = (static_cast<uint64_t>(key) << 32) | (0xFFFFFFFFu - static_cast<uint32_t>(col));
             const int p = atomicAdd(wcnt, 1);
             if (p < WCAP) {
@@ -455,8 +459,14 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const float* __rest
 }
 
 // fused path, between the two GEMM passes: tau[row] = k-th best of the row's tile maxima
+__device__ __forceinline__ float tau_as_float(uint32_t key) {
+  if (key == 0xFFFFFFFFu) return __builtin_inff();   // the k-th best is NaN: only +inf and NaN scores can matter
+  if (key == 0u) return -__builtin_inff();           // no valid column seen: everything passes
+  return key_to_float(key);
+}
+
 __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __restrict__ tilemax, int64_t B, int64_t NT,
-                                                          int k, uint32_t* __restrict__ tau) {
+                                                          int k, uint32_t* __restrict__ tau, float* __restrict__ tauf) {
   __shared__ uint32_t sk[1024];
   const int64_t row = blockIdx.x;
   if (row >= B) return;
@@ -468,14 +478,20 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
       const uint32_t me = sk[i];
       int ahead = 0;
       for (int j = 0; j < n; ++j) ahead += (sk[j] > me || (sk[j] == me && j < i)) ? 1 : 0;
-      if (ahead == k - 1) tau[row] = me;
+      if (ahead == k - 1) {
+        tau[row] = me;
+        tauf[row] = tau_as_float(me);
+      }
     }
     return;
   }
   uint32_t T;
   int need_eq;
   radix_kth(U32Keys{tilemax + row * NT}, 0, NT, k, T, need_eq);
-  if (threadIdx.x == 0) tau[row] = T;
+  if (threadIdx.x == 0) {
+    tau[row] = T;
+    tauf[row] = tau_as_float(T);
+  }
 }
 
 // fused path, after the filter pass: rank the row's short candidate list; a list that overflowed its
@@ -679,7 +695,7 @@ extern "C" int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const flo
 
 // Fused path layout inside the workspace (all regions 256-B aligned).
 struct FusedLayout {
-  int64_t NT, cap, stride, seg_width, off_tilemax, off_tau, off_cnt, off_cand, bytes;
+  int64_t NT, cap, stride, seg_width, off_tilemax, off_tau, off_tauf, off_cnt, off_cand, bytes;
 };
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k) {
@@ -702,7 +718,8 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k) {
   L.seg_width = (nblk + kSeg - 1) / kSeg;
   L.off_tilemax = 0;
   L.off_tau = align256(L.off_tilemax + B * L.NT * 4);
-  L.off_cnt = align256(L.off_tau + B * 4);
+  L.off_tauf = align256(L.off_tau + B * 4);
+  L.off_cnt = align256(L.off_tauf + B * 4);
   L.off_cand = align256(L.off_cnt + B * kSeg * 4);
   L.bytes = align256(L.off_cand + B * L.cap * 8);
   return L;
@@ -730,6 +747,7 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
     ta.tilemax = reinterpret_cast<uint32_t*>(ws + L.off_tilemax);
     ta.NT = L.NT;
     ta.tau = reinterpret_cast<uint32_t*>(ws + L.off_tau);
+    ta.tauf = reinterpret_cast<float*>(ws + L.off_tauf);
     ta.cnt = reinterpret_cast<int*>(ws + L.off_cnt);
     ta.cand = reinterpret_cast<uint64_t*>(ws + L.off_cand);
     ta.cap = static_cast<int>(L.cap);
@@ -745,7 +763,7 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
                  : launch_tiled<false, EPI_TILEMAX>(U, B, E, N, D, nullptr, nullptr, 0, st, ta);
     if (rc) return rc;
     hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, L.NT,
-                       static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau));
+                       static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf));
     if ((rc = check_launch())) return rc;
     rc = vec ? launch_tiled<true, EPI_FILTER>(U, B, E, N, D, nullptr, nullptr, 0, st, ta)
              : launch_tiled<false, EPI_FILTER>(U, B, E, N, D, nullptr, nullptr, 0, st, ta);
