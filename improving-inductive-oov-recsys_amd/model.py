@@ -8,6 +8,8 @@ Every per-batch tensor op of the reference's get_*_embedding / predict / full_so
 libmi_oov kernel here (gather, splice, lsh, row dot, f32-MFMA scoring).  Training orchestration
 (Trainer, optimisers, samplers) is out of scope and stays whatever drives this module.
 """
+import os
+
 import torch
 from torch import nn
 
@@ -25,6 +27,9 @@ def xavier_normal_initialization(module):
         nn.init.xavier_normal_(module.weight.data)
         if module.bias is not None:
             nn.init.constant_(module.bias.data, 0)
+
+
+_SYNC_FREE_TRAIN = os.environ.get("MI_OOV_TRAIN_LOOKUP", "1") != "0"  # developer A/B knob (tools/train_step_time.py)
 
 
 class BPRLoss(nn.Module):
@@ -113,6 +118,13 @@ class BPR(InductiveGeneralRecommender):
             planes = (emb.user_lsh if user else emb.item_lsh).uniform_planes[0].data
             buckets = (self.user_oov_buckets if user else self.item_oov_buckets).weight
             return ops.lsh_lookup(ids, table, feat, planes, buckets)
+        if isinstance(emb, LSHInductiveEmbedder) and torch.is_grad_enabled() and _SYNC_FREE_TRAIN:
+            # training with the lsh plugin: one sync-free path (no boolean-mask indexing), same values and gradients
+            feat = emb.user_feature_mat if user else emb.item_feature_mat
+            planes = (emb.user_lsh if user else emb.item_lsh).uniform_planes[0].data
+            buckets = (self.user_oov_buckets if user else self.item_oov_buckets).weight
+            feat_ids = torch.where(ids >= emb.prime_pad, ids - emb.prime_pad, ids) if emb.training else ids
+            return ops.lsh_train_lookup(ids, feat_ids, table, feat, planes, buckets)
         oov_mask = ids >= n_vocab
         oov_ids = ids[oov_mask]  # fresh copy: the embedder may strip prime_pad in place
         if oov_ids.numel() == 0:

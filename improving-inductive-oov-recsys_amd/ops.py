@@ -164,6 +164,42 @@ class LshScorer:
                         C.raw_stream(self._idx))
 
 
+class _LshTrainLookup(torch.autograd.Function):
+    """BPR.get_*_embedding with an lsh plugin UNDER AUTOGRAD (bpr.py:48-125 + lsh_embedder.py:133-179), without the
+    reference's boolean-mask indexing (each `ids[mask]` is a device -> host sync) and its zeros / scatter / scatter
+    splice: every row gets both the table gather and the lsh embedding of its feature row, one elementwise select
+    keeps the right one, and the backward sends each gradient row to the table (in-vocabulary) or through the
+    deterministic lsh backward (out-of-vocabulary).  `feat_ids` are the ids with the prime pad stripped."""
+
+    @staticmethod
+    def forward(ctx, ids, feat_ids, table, feat, planes, buckets):
+        n_vocab = table.shape[0]
+        oov = ids >= n_vocab
+        emb, bits = _lsh_forward(feat_ids, feat, planes, buckets, want_bits=True)
+        rows = _gather_rows_forward(ids, table)  # NaN rows where ids >= n_vocab: never selected
+        out = torch.where(oov[:, None], emb, rows)
+        # rows that are not lsh rows must not reach the lsh backward with a 0/0: give them a one-plane code
+        first = torch.zeros((1, bits.shape[1]), dtype=bits.dtype, device=bits.device)
+        first[0, 0] = 1
+        safe = torch.where(oov[:, None], bits, first)  # (no boolean-mask assignment: that would sync)
+        ctx.save_for_backward(ids, oov, safe)
+        ctx.n_vocab = n_vocab
+        ctx.need = (table.requires_grad, buckets.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, oov, bits = ctx.saved_tensors
+        g = g.contiguous()
+        gt = scatter_add_rows(ids, g, ctx.n_vocab) if ctx.need[0] else None  # ids >= n_vocab skipped by the kernel
+        gb = lsh_embed_backward(bits, g * oov[:, None].to(g.dtype)) if ctx.need[1] else None
+        return None, None, gt, None, None, gb
+
+
+def lsh_train_lookup(ids, feat_ids, table, feat, planes, buckets):
+    return _LshTrainLookup.apply(_ids(ids), _ids(feat_ids, "feat_ids"), table, feat, planes, buckets)
+
+
 def lsh_lookup(ids, table, feat, planes, buckets):
     """BPR.get_*_embedding with an lsh plugin in one launch (bpr.py:48-125).  Inference only."""
     ids, table, feat, planes, buckets = (_ids(ids), _f32(table, "table"), _f32(feat, "feat"),
