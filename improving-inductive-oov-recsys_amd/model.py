@@ -14,7 +14,7 @@ import torch
 from torch import nn
 
 from . import ops
-from .embedders import LSHInductiveEmbedder
+from .embedders import LSHInductiveEmbedder, SingleLSHInductiveEmbedder
 
 
 def xavier_normal_initialization(module):
@@ -125,6 +125,17 @@ class BPR(InductiveGeneralRecommender):
             buckets = (self.user_oov_buckets if user else self.item_oov_buckets).weight
             feat_ids = torch.where(ids >= emb.prime_pad, ids - emb.prime_pad, ids) if emb.training else ids
             return ops.lsh_train_lookup(ids, feat_ids, table, feat, planes, buckets)
+        if torch.is_grad_enabled() and _SYNC_FREE_TRAIN and (emb is None or isinstance(emb, SingleLSHInductiveEmbedder)):
+            buckets = (self.user_oov_buckets if user else self.item_oov_buckets).weight
+            if emb is None:  # mapper only: the mapped id itself addresses the bucket table (bpr.py:75,122)
+                idx = ids - n_vocab
+            else:
+                feat = emb.user_feature_mat if user else emb.item_feature_mat
+                planes = (emb.user_lsh if user else emb.item_lsh).uniform_planes[0].data
+                feat_ids = torch.where(ids >= emb.prime_pad, ids - emb.prime_pad, ids) if emb.training else ids
+                idx = ops.slsh_index(feat_ids, feat, planes, buckets.shape[0])
+            idx = torch.where(ids >= n_vocab, idx, torch.full_like(idx, -1))
+            return ops.bucket_train_lookup(ids, idx, table, buckets)
         oov_mask = ids >= n_vocab
         oov_ids = ids[oov_mask]  # fresh copy: the embedder may strip prime_pad in place
         if oov_ids.numel() == 0:

@@ -196,6 +196,33 @@ class _LshTrainLookup(torch.autograd.Function):
         return None, None, gt, None, None, gb
 
 
+class _BucketTrainLookup(torch.autograd.Function):
+    """The same sync-free select for plugins whose OOV row is ONE bucket row (slsh: single_lsh_embedder.py:100,108;
+    the random mapper without embedder: bpr.py:75,122): out = buckets[idx] where the id is out of vocabulary, table[id]
+    elsewhere; `idx` is -1 on in-vocabulary rows, which both backward kernels skip."""
+
+    @staticmethod
+    def forward(ctx, ids, idx, table, buckets):
+        oov = ids >= table.shape[0]
+        out = torch.where(oov[:, None], _gather_rows_forward(idx, buckets), _gather_rows_forward(ids, table))
+        ctx.save_for_backward(ids, idx)
+        ctx.shapes = (table.shape[0], buckets.shape[0])
+        ctx.need = (table.requires_grad, buckets.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, idx = ctx.saved_tensors
+        g = g.contiguous()
+        gt = scatter_add_rows(ids, g, ctx.shapes[0]) if ctx.need[0] else None
+        gb = slsh_embed_backward(idx, g, ctx.shapes[1]) if ctx.need[1] else None
+        return None, None, gt, gb
+
+
+def bucket_train_lookup(ids, idx, table, buckets):
+    return _BucketTrainLookup.apply(_ids(ids), _ids(idx, "idx"), table, buckets)
+
+
 def lsh_train_lookup(ids, feat_ids, table, feat, planes, buckets):
     return _LshTrainLookup.apply(_ids(ids), _ids(feat_ids, "feat_ids"), table, feat, planes, buckets)
 
