@@ -78,6 +78,24 @@ struct TopkArgs {
 // from hundreds of workgroups serialise in L2 (the filter pass went from 330 to 550 us when the sampled first pass
 // let 160 instead of 40 candidates per row through); 64 counters per row do not.
 constexpr int kSeg = 64, kSegCap = 16;  // 64 x 16 = the 1024 candidates the finalize kernel can rank
+// A segment that is full spills into the row's overflow list (one more counter per row, kept behind the B x kSeg
+// segment counters; its entries behind the B x kSeg x kSegCap segment slots): with ~200 candidates per row a 17th
+// entry in one of 64 segments happens about once per few thousand rows, and the exact fallback for a row whose
+// candidates were lost re-scores the whole catalogue in one workgroup (6.5 ms at N = 50000).
+constexpr int kOvfCap = 128;
+struct TopkArgs;
+__device__ __forceinline__ void append_candidate(const TopkArgs& ta, int64_t B, int64_t row, unsigned blk, uint64_t packed);
+
+__device__ __forceinline__ void append_candidate(const TopkArgs& ta, int64_t B, int64_t row, unsigned blk, uint64_t packed) {
+  const int64_t seg = row * kSeg + blk % kSeg;  // interleaved: clustered good columns spread over the segments
+  const int pos = atomicAdd(&ta.cnt[seg], 1);
+  if (pos < kSegCap) {
+    ta.cand[seg * kSegCap + pos] = packed;
+  } else {
+    const int p2 = atomicAdd(&ta.cnt[B * kSeg + row], 1);
+    if (p2 < kOvfCap) ta.cand[B * kSeg * kSegCap + row * kOvfCap + p2] = packed;
+  }
+}
 
 // Order: larger value first, NaN above everything (torch.topk), ties -> lower column index.
 __device__ __forceinline__ uint32_t order_key(float v) {
@@ -223,9 +241,7 @@ __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __res
               wrow[p] = lrow;
               wbuf[p] = packed;
             } else {  // more than WCAP candidates in one 128 x 128 tile: append directly
-              const int64_t seg = row * kSeg + blockIdx.x % kSeg;
-              const int pos = atomicAdd(&ta.cnt[seg], 1);
-              if (pos < kSegCap) ta.cand[seg * kSegCap + pos] = packed;
+              append_candidate(ta, B, row, blockIdx.x, packed);
             }
           }
         }
@@ -233,9 +249,7 @@ __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __res
     __syncthreads();
     const int nw = *wcnt < WCAP ? *wcnt : WCAP;
     for (int i = tid; i < nw; i += kBlock) {
-      const int64_t seg = (b0 + wrow[i]) * kSeg + blockIdx.x % kSeg;  // interleaved: clustered good columns spread out
-      const int pos = atomicAdd(&ta.cnt[seg], 1);
-      if (pos < kSegCap) ta.cand[seg * kSegCap + pos] = wbuf[i];
+      append_candidate(ta, B, b0 + wrow[i], blockIdx.x, wbuf[i]);
     }
   } else {
 #pragma unroll
@@ -465,8 +479,30 @@ __device__ __forceinline__ float tau_as_float(uint32_t key) {
   return key_to_float(key);
 }
 
+// bf16 prefilter (see bf16_tile_kernel): eps[row] = 1.05 * 2^-8 * |u_row| * max|e| (+ the subnormal term),
+// thr[row] = tauf - 2 eps: tauf is the k-th best bf16 tile maximum, so the true k-th best score is >= tauf - eps, and a
+// column that reaches it has a bf16 score >= tauf - 2 eps.  -inf when the bound is not finite.
+struct Bf16Bound {
+  const float* u2;         // [B] squared row norms of U
+  const uint32_t* e2max;   // max squared row norm of E (float bits)
+  float* thr;              // [B] out
+  float* eps;              // [B] out
+  int dbg;                 // TIMING EXPERIMENT ONLY
+};
+__device__ __forceinline__ void bf16_threshold(const Bf16Bound& bb, int64_t row, float tauf) {
+  if (bb.dbg) { bb.thr[row] = __builtin_inff(); bb.eps[row] = 0.f; return; }
+  // + what flushing subnormal bf16 operands to zero could cost: 2^-126 * sqrt(D) * (|u| + |e|), D <= 64
+  const float nu = sqrtf(bb.u2[row]), ne = sqrtf(__uint_as_float(*bb.e2max));
+  const float eps = 1.05f * 0x1p-8f * nu * ne + 0x1p-123f * (nu + ne) + 1e-30f;
+  const float t = tauf - 2.f * eps;
+  const bool ok = eps < __builtin_inff() && t == t;
+  bb.thr[row] = ok ? t : -__builtin_inff();
+  bb.eps[row] = ok ? eps : __builtin_inff();
+}
+
 __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __restrict__ tilemax, int64_t B, int64_t NT,
-                                                          int k, uint32_t* __restrict__ tau, float* __restrict__ tauf) {
+                                                          int k, uint32_t* __restrict__ tau, float* __restrict__ tauf,
+                                                          Bf16Bound bb) {
   __shared__ uint32_t sk[1024];
   const int64_t row = blockIdx.x;
   if (row >= B) return;
@@ -481,6 +517,7 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
       if (ahead == k - 1) {
         tau[row] = me;
         tauf[row] = tau_as_float(me);
+        if (bb.thr) bf16_threshold(bb, row, tau_as_float(me));
       }
     }
     return;
@@ -491,6 +528,7 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
   if (threadIdx.x == 0) {
     tau[row] = T;
     tauf[row] = tau_as_float(T);
+    if (bb.thr) bf16_threshold(bb, row, tau_as_float(T));
   }
 }
 
@@ -502,8 +540,8 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(const float* __re
                                                                int64_t n_skip_low, const int* __restrict__ cnt,
                                                                const uint64_t* __restrict__ cand,
                                                                float* __restrict__ vals, int64_t* __restrict__ idx) {
-  __shared__ uint64_t lc[kSeg * kSegCap];
-  __shared__ int seg_off[kSeg + 1];
+  __shared__ uint64_t lc[kSeg * kSegCap + kOvfCap];
+  __shared__ int seg_off[kSeg + 2];
   __shared__ int overflow;
   const int64_t row = blockIdx.x;
   if (row >= B) return;
@@ -511,11 +549,14 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(const float* __re
     int n = 0, over = 0;
     for (int g = 0; g < kSeg; ++g) {
       const int c = cnt[row * kSeg + g];
-      over |= (c > kSegCap);
+      (void)over;
       seg_off[g] = n;
       n += c < kSegCap ? c : kSegCap;
     }
     seg_off[kSeg] = n;
+    const int oc = cnt[B * kSeg + row];  // the row's overflow list: only ITS overflow loses candidates
+    over = (oc > kOvfCap);
+    seg_off[kSeg + 1] = n + (oc < kOvfCap ? oc : kOvfCap);
     overflow = over;
   }
   __syncthreads();
@@ -524,8 +565,10 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_kernel(const float* __re
       const int g = i / kSegCap, j = i % kSegCap;
       if (j < seg_off[g + 1] - seg_off[g]) lc[seg_off[g] + j] = cand[(row * kSeg + g) * kSegCap + j];
     }
+    for (int j = threadIdx.x; j < seg_off[kSeg + 1] - seg_off[kSeg]; j += kBlock)
+      lc[seg_off[kSeg] + j] = cand[B * kSeg * kSegCap + row * kOvfCap + j];
     __syncthreads();
-    const int n = seg_off[kSeg];
+    const int n = seg_off[kSeg + 1];
     emit_ranked(lc, n, n < k ? n : k, k, vals + row * k, idx + row * k);
   } else {
     select_topk_row(DotKeys{U + row * D, E, D}, N, k, n_skip_low, vals + row * k, idx + row * k);
@@ -629,6 +672,413 @@ extern "C" int mi_oov_topk_hits(const int64_t* idx, int64_t S, int64_t k, const 
   return check_launch();
 }
 
+// ---- bf16 prefilter for the second pass of the fused top-k (D = 64) ------------------------------------------------------
+// The filter pass only has to decide which (row, column) pairs MAY belong to the top-k: the exact f32 score of the few
+// hundred survivors per row is recomputed by the finalize kernel anyway.  So the pass runs on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16: 16 x the f32 MFMA rate; operands converted to bf16 while they are staged) with a threshold
+// lowered by a bound on the bf16 error:
+//     |s_bf16 - s_f32| <= (2^-8 + 2^-17 + 2 D 2^-24) * sum_d |u_d e_d|  <=  1.02 * 2^-8 * |u| * |e|      (Cauchy-Schwarz)
+// (each operand rounds to 8 significant bits: relative 2^-9; f32 accumulation on both sides).  With eps_row =
+// 1.05 * 2^-8 * |u_row| * max_j |e_j| every column whose exact score reaches tau has a bf16 score >= tau - eps_row, so
+// the candidate set is a superset of the exact one and the final top-k is bit-identical to the all-f32 path's (the
+// finalize kernel recomputes every candidate's score with the oracle's fmaf chain and ranks exactly; the bound also
+// carries a term for subnormal operands that the matrix cores may flush).  Non-finite norms
+// give eps = inf/NaN -> threshold -inf: everything passes, the row overflows and takes the exact fallback.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+constexpr int BLD = 72;  // bf16 elements per LDS row: 64 + 8 (144 B: staggers the banks, keeps 16-B alignment)
+
+// one pass over a matrix with 64-float rows: bf16 copy of every row + squared row norms (16 lanes per row); out[row] if
+// out, and the maximum over the rows into *maxbits (float bits, atomicMax on the unsigned image: valid for non-negative
+// floats, NaN images sort above +inf).  One global atomic per workgroup and at most 512 workgroups: atomics on one
+// address serialise at ~5 ns each (one per row took 140 us, one per 16 rows 26 us at N = 50000).
+constexpr int kNormGrid = 512;
+__global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __restrict__ M, int64_t rows,
+                                                              __bf16* __restrict__ Mb, float* __restrict__ out,
+                                                              uint32_t* __restrict__ maxbits, uint32_t* __restrict__ zero_this,
+                                                              int* __restrict__ zero_rows) {
+  __shared__ uint32_t bmax;
+  if (threadIdx.x == 0) bmax = 0u;
+  if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0u;  // the NEXT launch's accumulator
+  __syncthreads();
+  const int l16 = threadIdx.x & 15;
+  const int64_t per = kBlock / 16;
+  uint32_t mine = 0u;
+  for (int64_t r = static_cast<int64_t>(blockIdx.x) * per + (threadIdx.x >> 4); r < rows; r += static_cast<int64_t>(gridDim.x) * per) {
+    const float4 v = *reinterpret_cast<const float4*>(M + r * 64 + l16 * 4);
+    uint2 pk;
+    pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v.x), static_cast<__bf16>(v.y)});
+    pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v.z), static_cast<__bf16>(v.w)});
+    *reinterpret_cast<uint2*>(Mb + r * 64 + l16 * 4) = pk;
+    float s = v.x * v.x;
+    s = __builtin_fmaf(v.y, v.y, s);
+    s = __builtin_fmaf(v.z, v.z, s);
+    s = __builtin_fmaf(v.w, v.w, s);
+    s = row16_sum(s);
+    if (l16 == 0) {
+      if (out) out[r] = s;
+      if (zero_rows) zero_rows[r] = 0;
+      const uint32_t bits = __float_as_uint(s);
+      mine = bits > mine ? bits : mine;
+    }
+  }
+  if (maxbits) {
+    if (l16 == 0 && mine) atomicMax(&bmax, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && bmax) atomicMax(maxbits, bmax);
+  }
+}
+
+// Candidate lists of the bf16 filter pass.  Strip s of a 128-row block is walked by exactly one workgroup, so the list
+// (row, s) has ONE writer: its counter lives in that workgroup's LDS and the entries go out as plain stores -- the
+// filter pass does no global atomics (one per candidate, ~0.85 M per launch, cost it 50 us).  Lists that run over
+// (clustered good columns, runs of equal scores) spill into the row's shared overflow list, and a row whose overflow
+// list runs over as well takes the exact fallback in the finalize kernel.
+struct StripLists {
+  int* cnt;        // [B, ns] entries of list (row, strip), written once by the owner
+  uint64_t* cand;  // [B, ns, cap] (bf16 key << 32) | (0xFFFFFFFF - column)
+  int* ovf_cnt;    // [B] zeroed per launch
+  uint64_t* ovf;   // [B, kOvfCap]
+  int ns, cap;
+};
+
+// A workgroup keeps its 128 user rows in LDS and walks a strip of column blocks (blocks s, s + ns, s + 2 ns, ...: a
+// cluster of good columns is spread over the strips, and with ns a multiple of 8 strip s always runs on XCD s % 8, so
+// each XCD's L2 sees an eighth of E).  With the bf16 matrix cores a 128 x 128 x 64 tile is 0.25 us of MFMA work, so
+// everything else has to stay off the critical path:
+//   * the next block of E is fetched into registers while the current one is multiplied and filtered;
+//   * rows past B / N are clamped to the last row (no zero fill, no divergent loads): the epilogues mask them;
+//   * FILTER seeds the accumulators with -thr[row] (read from LDS with the operands), so the epilogue is one compare
+//     against zero and a branch per score: a threshold read per row inside the epilogue was an exposed LDS round trip
+//     each, 32 per tile, and dominated the kernel.  The keys are therefore scores shifted by the row's threshold: the
+//     finalize kernel only compares keys of one row with each other.  The shift's rounding (2^-22 relative) sits well
+//     inside the 5% slack of eps.
+constexpr int kWaveQueue = 128;  // queued candidates per wave and tile (6 B each: 36864 + 1024 + 3072 B of LDS = 4 workgroups per CU)
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int EPI>
+__global__ __launch_bounds__(kBlock, 4) void bf16_tile_kernel(const __bf16* __restrict__ Ub, int64_t B,
+                                                             const __bf16* __restrict__ Eb, int64_t N,
+                                                             const float* __restrict__ thr, TopkArgs ta, StripLists sl,
+                                                             int nvisit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  __bf16* sA = reinterpret_cast<__bf16*>(smem);  // [BM][BLD]
+  __bf16* sB = sA + BM * BLD;                    // [BN][BLD]
+  float* snthr = reinterpret_cast<float*>(sB + BN * BLD);  // FILTER only: -thr[row], then the rows' list counters
+  int* rowcnt = reinterpret_cast<int*>(snthr + BM);
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;
+  const int i32 = lane & 31, hh = lane >> 5;
+  const int stride = (EPI == EPI_TILEMAX && ta.col_stride > 1) ? ta.col_stride : 1;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.y) * BM;
+  const int strip = blockIdx.x, nstrip = gridDim.x;
+  if (strip >= nvisit) {  // idle strip (the count is padded to a multiple of 8): its lists are empty
+    if (EPI == EPI_FILTER && tid < BM && b0 + tid < B) sl.cnt[(b0 + tid) * sl.ns + strip] = 0;
+    return;
+  }
+  const int rows_here = (B - b0 < BM) ? static_cast<int>(B - b0) : BM;
+  const uint32_t n_cols = static_cast<uint32_t>(N);  // N < 2^32 (checked by the caller)
+  const uint32_t skip = ta.n_skip_low < N ? static_cast<uint32_t>(ta.n_skip_low) : n_cols;
+  const int erow = tid >> 3, eoff = (tid & 7) * 8;  // operand staging: 128 rows x 8 units of 8 k (16 B), 4 units per thread
+  u32x4 pf[4];  // the next block of E (a native vector type: an array of HIP's uint4 struct lands in scratch)
+
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = erow + 32 * q;
+    const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
+    const int64_t n0 = static_cast<int64_t>(strip) * stride * BN;
+    const int64_t rb = (n0 + r < N) ? n0 + r : N - 1;
+    *reinterpret_cast<u32x4*>(sA + r * BLD + eoff) = *reinterpret_cast<const u32x4*>(Ub + ra * 64 + eoff);
+    *reinterpret_cast<u32x4*>(sB + r * BLD + eoff) = *reinterpret_cast<const u32x4*>(Eb + rb * 64 + eoff);
+  }
+  if constexpr (EPI == EPI_FILTER) {
+    if (tid < BM) {
+      snthr[tid] = (tid < rows_here) ? -thr[b0 + tid] : -__builtin_inff();
+      rowcnt[tid] = 0;
+    }
+  }
+  __syncthreads();
+
+  for (int j = strip; j < nvisit; j += nstrip) {
+    const int64_t n0 = static_cast<int64_t>(j) * stride * BN;
+    const bool more = j + nstrip < nvisit;
+    {
+      const int64_t n1 = static_cast<int64_t>(more ? j + nstrip : j) * stride * BN;  // (the last block re-reads itself)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t rb = (n1 + erow + 32 * q < N) ? n1 + erow + 32 * q : N - 1;
+        pf[q] = *reinterpret_cast<const u32x4*>(Eb + rb * 64 + eoff);
+      }
+    }
+    // the epilogue's row / column offsets are loop invariant: made opaque here so that the compiler recomputes them per
+    // block instead of carrying 64+ registers of addresses (i.e. spills) across the strip loop
+    int lrow0 = wm * 64 + 4 * hh, lcol0 = wn * 64 + i32;
+    asm volatile("" : "+v"(lrow0), "+v"(lcol0));
+    f32x16 acc[2][2];
+
+    if constexpr (EPI == EPI_TILEMAX) {
+      // pass 1: maxima of the 64-column tiles.  The product is taken transposed (E block x U^T): a lane then holds 16
+      // COLUMNS of one user row per accumulator, so the tile maximum is 32 in-lane max3 operations + one exchange with
+      // lane ^ 32, instead of a 32-lane reduction per row (5 DPP steps for each of 32 rows: 1000 VALU operations per
+      // wave and tile, 4x the matrix-core time).  NaN sorts first (torch.topk): max3 drops NaNs, so they are tracked
+      // through the largest |bits| seen.
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {  // lane (r, h) supplies k = 16 ks + 8 h + j
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sA + (wm * 64 + m * 32 + i32) * BLD + ks * 16 + hh * 8));
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          b[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sB + (wn * 64 + n * 32 + i32) * BLD + ks * 16 + hh * 8));
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b[n], a[m], acc[m][n], 0, 0, 0);
+      }
+      // acc[m][n][r]: column n0 + wn 64 + n 32 + (r & 3) + 8 (r >> 2) + 4 hh, user row wm 64 + m 32 + i32
+      const int64_t c_lo = n0 + wn * 64, c_hi = c_lo + 64;
+      const bool all_cols = c_hi <= N && c_lo >= ta.n_skip_low;  // uniform; false only at the two ends of the catalogue
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        float best = -__builtin_inff();
+        uint32_t amax = 0u;
+        bool any = false;
+        if (all_cols) {
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              best = __builtin_fmaxf(__builtin_fmaxf(best, acc[m][n][r]), acc[m][n][r + 1]);
+              const uint32_t a0 = __float_as_uint(acc[m][n][r]) & 0x7FFFFFFFu, a1 = __float_as_uint(acc[m][n][r + 1]) & 0x7FFFFFFFu;
+              amax = a0 > amax ? a0 : amax;
+              amax = a1 > amax ? a1 : amax;
+            }
+          any = true;
+        } else {
+          uint32_t cbase = static_cast<uint32_t>(c_lo) + 4 * hh;
+          asm volatile("" : "+v"(cbase));  // (not hoisted out of the rare branch)
+#pragma unroll
+          for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const uint32_t col = cbase + n * 32 + (r & 3) + 8 * (r >> 2);
+              if (col < n_cols && col >= skip) {
+                best = __builtin_fmaxf(best, acc[m][n][r]);
+                const uint32_t a0 = __float_as_uint(acc[m][n][r]) & 0x7FFFFFFFu;
+                amax = a0 > amax ? a0 : amax;
+                any = true;
+              }
+            }
+        }
+        uint32_t key = !any ? 0u : (amax > 0x7F800000u ? 0xFFFFFFFFu : order_key(best));
+        const uint32_t other = __shfl_xor(key, 32, 64);
+        key = other > key ? other : key;
+        int lrow = wm * 64 + m * 32 + i32;
+        asm volatile("" : "+v"(lrow));  // (address recomputed per block: carried across the loop it spills)
+        if (hh == 0 && lrow < rows_here) (ta.tilemax + b0 * ta.NT + j * 2 + wn)[lrow * static_cast<int>(ta.NT)] = key;
+      }
+    } else {
+      // pass 2: every score that is not below the row's threshold -> the (row, strip) list
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // accumulator r holds row (r & 3) + 8 (r >> 2) + 4 hh of the 32 x 32 tile
+          const f32x4 init = *reinterpret_cast<const f32x4*>(snthr + lrow0 + m * 32 + 8 * g);
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            acc[m][n][4 * g + 0] = init.x;
+            acc[m][n][4 * g + 1] = init.y;
+            acc[m][n][4 * g + 2] = init.z;
+            acc[m][n][4 * g + 3] = init.w;
+          }
+        }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        bf16x8 a[2], b[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+          a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sA + (wm * 64 + m * 32 + i32) * BLD + ks * 16 + hh * 8));
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+          b[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sB + (wn * 64 + n * 32 + i32) * BLD + ks * 16 + hh * 8));
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+      }
+      // A passing score costs one queue push here (no waiting): the wave's queue is drained once per tile, one LDS
+      // atomic on the row's list counter and one store per entry, all entries in parallel.  (Taking the list slot inside
+      // the branch was an LDS round trip per taken branch, ~14 per wave and tile, and doubled the kernel's time.)
+      uint64_t* cand_wg = sl.cand + (b0 * sl.ns + strip) * sl.cap;  // + local row * (ns cap) + slot: 32-bit offsets
+      const int row_stride = sl.ns * sl.cap;
+      auto emit = [&](int lrow, uint32_t lcol, float v) {
+        const uint32_t col = static_cast<uint32_t>(n0) + lcol;
+        if (lrow < rows_here && col < n_cols && col >= skip) {
+          const uint64_t packed = (static_cast<uint64_t>(order_key(v)) << 32) | (0xFFFFFFFFu - col);
+          const int p = atomicAdd(&rowcnt[lrow], 1);
+          if (p < sl.cap) {
+            cand_wg[lrow * row_stride + p] = packed;
+          } else {
+            const int p2 = atomicAdd(&sl.ovf_cnt[b0 + lrow], 1);
+            if (p2 < kOvfCap) sl.ovf[(b0 + lrow) * kOvfCap + p2] = packed;
+          }
+        }
+      };
+      uint32_t* qv = reinterpret_cast<uint32_t*>(rowcnt + BM) + wv * kWaveQueue;                        // score bits
+      uint16_t* qc = reinterpret_cast<uint16_t*>(reinterpret_cast<uint32_t*>(rowcnt + BM) + 4 * kWaveQueue) + wv * kWaveQueue;  // row << 8 | col
+      int code0 = (lrow0 << 8) | lcol0;
+      asm volatile("" : "+v"(code0));
+      int qpos = 0;  // wave-uniform
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+          for (int n = 0; n < 2; ++n) {
+            const bool pass = !(acc[m][n][r] < 0.f);  // rare (a NaN passes too: emit() checks the row and the column)
+            const uint64_t mask = __ballot(pass);
+            if (mask) {
+              if (pass) {
+                const int slot = qpos + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)));
+                const int code = code0 + (((m * 32 + (r & 3) + 8 * (r >> 2)) << 8) | (n * 32));
+                if (slot < kWaveQueue) {
+                  qv[slot] = __float_as_uint(acc[m][n][r]);
+                  qc[slot] = static_cast<uint16_t>(code);
+                } else {  // queue full (runs of equal scores): take the slot here
+                  emit(code >> 8, static_cast<uint32_t>(code & 255), acc[m][n][r]);
+                }
+              }
+              qpos = __builtin_amdgcn_readfirstlane(qpos + __popcll(mask));
+            }
+          }
+      __builtin_amdgcn_wave_barrier();
+      const int nq = qpos < kWaveQueue ? qpos : kWaveQueue;
+      for (int i = lane; i < nq; i += 64) {
+        const int code = qc[i];
+        emit(code >> 8, static_cast<uint32_t>(code & 255), __uint_as_float(qv[i]));
+      }
+    }
+    if (more) {
+      __syncthreads();  // every wave is done with sB
+#pragma unroll
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(sB + (erow + 32 * q) * BLD + eoff) = pf[q];
+      __syncthreads();
+    }
+  }
+  if constexpr (EPI == EPI_FILTER) {
+    __syncthreads();
+    if (tid < rows_here) sl.cnt[(b0 + tid) * sl.ns + strip] = rowcnt[tid] < sl.cap ? rowcnt[tid] : sl.cap;
+  }
+}
+
+// finalize for the bf16 prefilter: gather the row's strip lists, cut by the k-th best bf16 key, exact f32 key of the
+// survivors (the oracle's fmaf chain), then the rank sort
+constexpr int kStripSlots = 1024;  // ns * cap <= kStripSlots
+__global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float* __restrict__ U, const float* __restrict__ E,
+                                                                     int64_t B, int64_t N, int64_t D, int k,
+                                                                     int64_t n_skip_low, StripLists sl,
+                                                                     const float* __restrict__ eps_row,
+                                                                     float* __restrict__ vals, int64_t* __restrict__ idx) {
+  __shared__ uint64_t lc[kStripSlots + kOvfCap];
+  __shared__ int seg_off[128 + 2];
+  __shared__ int overflow, n_keep;
+  __shared__ uint32_t kth_key;
+  __shared__ float su[64];
+  const int64_t row = blockIdx.x;
+  if (row >= B) return;
+  const int ns = sl.ns;  // <= 128
+  int mine = 0;
+  if (threadIdx.x < ns) mine = sl.cnt[row * ns + threadIdx.x];
+  if (threadIdx.x == ns) mine = sl.ovf_cnt[row];
+  if (threadIdx.x <= ns) seg_off[threadIdx.x + 1] = mine;  // counts first, offsets after the scan below
+  if (threadIdx.x < 64) su[threadIdx.x] = U[row * 64 + threadIdx.x];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int oc = seg_off[ns + 1];
+    int n = 0;
+    for (int g = 0; g < ns; ++g) {
+      const int c = seg_off[g + 1];
+      seg_off[g] = n;
+      n += c;
+    }
+    seg_off[ns] = n;
+    seg_off[ns + 1] = n + (oc < kOvfCap ? oc : kOvfCap);
+    overflow = (oc > kOvfCap);
+    n_keep = 0;
+    kth_key = 0u;
+  }
+  __syncthreads();
+  if (overflow) {
+    select_topk_row(DotKeys{U + row * D, E, D}, N, k, n_skip_low, vals + row * k, idx + row * k);
+    return;
+  }
+  for (int i = threadIdx.x; i < ns * sl.cap; i += kBlock) {
+    const int g = i / sl.cap, j = i % sl.cap;
+    if (j < seg_off[g + 1] - seg_off[g]) lc[seg_off[g] + j] = sl.cand[(row * ns + g) * sl.cap + j];
+  }
+  for (int j = threadIdx.x; j < seg_off[ns + 1] - seg_off[ns]; j += kBlock) lc[seg_off[ns] + j] = sl.ovf[row * kOvfCap + j];
+  __syncthreads();
+  const int n = seg_off[ns + 1];
+  // Stage 1: v_k = the k-th best bf16 score.  The k candidates at or above it have exact scores >= v_k - eps, so a
+  // candidate whose bf16 score is below v_k - 2 eps (exact score < v_k - eps) cannot be in the top k: only the others
+  // are re-scored exactly.  eps is the bound the filter pass used (the keys are shifted by the row's threshold, which
+  // cancels in the comparison).
+  const int kk = n < k ? n : k;
+  for (int i = threadIdx.x; i < n; i += kBlock) {
+    const uint64_t me = lc[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (lc[j] > me) ? 1 : 0;
+    if (rank == kk - 1) kth_key = static_cast<uint32_t>(me >> 32);
+  }
+  __syncthreads();
+  const float eps = eps_row[row];
+  const float vk = key_to_float(kth_key);
+  const float cut = vk - 2.f * eps;  // NaN / -inf when anything is not finite: then every candidate is re-scored
+  // Stage 2: exact f32 score of the survivors -- 16 independent float4 loads of the item row, then the oracle's chain
+  // acc = fma(u[d], e[d], acc), d = 0..63 from +0 (the order the f32 MFMA kernel runs); compacted in place
+  for (int base = 0; base < n; base += kBlock) {
+    const int i = base + threadIdx.x;
+    uint64_t out = 0;
+    bool keep = false;
+    if (i < n) {
+      const uint64_t me = lc[i];
+      const float sb = key_to_float(static_cast<uint32_t>(me >> 32));
+      keep = !(sb < cut);
+      if (keep) {
+        const uint32_t inv = static_cast<uint32_t>(me);
+        const float4* e4 = reinterpret_cast<const float4*>(E + static_cast<int64_t>(0xFFFFFFFFu - inv) * 64);
+        float4 ev[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) ev[c] = e4[c];
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+          acc = __builtin_fmaf(su[4 * c + 0], ev[c].x, acc);
+          acc = __builtin_fmaf(su[4 * c + 1], ev[c].y, acc);
+          acc = __builtin_fmaf(su[4 * c + 2], ev[c].z, acc);
+          acc = __builtin_fmaf(su[4 * c + 3], ev[c].w, acc);
+        }
+        out = (static_cast<uint64_t>(order_key(acc)) << 32) | inv;
+      }
+    }
+    __syncthreads();  // everyone has read its lc[i] of this batch: the compaction below may overwrite lower slots only
+    if (keep) lc[atomicAdd(&n_keep, 1)] = out;  // n_keep <= base + (threads done) <= i: never ahead of an unread slot
+    __syncthreads();
+  }
+  const int m = n_keep;
+  emit_ranked(lc, m, m < k ? m : k, k, vals + row * k, idx + row * k);
+}
+
 static size_t full_sort_lds() { return static_cast<size_t>(BM + BN) * LDK * sizeof(float); }
 
 template <bool VEC, int EPI>
@@ -695,7 +1145,7 @@ extern "C" int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const flo
 
 // Fused path layout inside the workspace (all regions 256-B aligned).
 struct FusedLayout {
-  int64_t NT, cap, stride, seg_width, off_tilemax, off_tau, off_tauf, off_cnt, off_cand, bytes;
+  int64_t NT, cap, stride, seg_width, off_tilemax, off_tau, off_tauf, off_u2, off_thr, off_eps, off_e2max, off_ub, off_eb, off_cnt, off_cand, bytes;
 };
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
 static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k) {
@@ -719,9 +1169,15 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k) {
   L.off_tilemax = 0;
   L.off_tau = align256(L.off_tilemax + B * L.NT * 4);
   L.off_tauf = align256(L.off_tau + B * 4);
-  L.off_cnt = align256(L.off_tauf + B * 4);
-  L.off_cand = align256(L.off_cnt + B * kSeg * 4);
-  L.bytes = align256(L.off_cand + B * L.cap * 8);
+  L.off_u2 = align256(L.off_tauf + B * 4);
+  L.off_thr = align256(L.off_u2 + B * 4);
+  L.off_eps = align256(L.off_thr + B * 4);
+  L.off_e2max = align256(L.off_eps + B * 4);
+  L.off_ub = align256(L.off_e2max + 256);        // bf16 copies of U and E (64-column inputs only)
+  L.off_eb = align256(L.off_ub + B * 128);
+  L.off_cnt = align256(L.off_eb + N * 128);
+  L.off_cand = align256(L.off_cnt + B * (128 + 1) * 4);  // f32 path: kSeg + 1 counters per row; bf16 path: <= 128 strips + 1
+  L.bytes = align256(L.off_cand + B * (L.cap + kOvfCap) * 8);
   return L;
 }
 // The fused two-pass path needs at least 2k column tiles per row (tau is the k-th tile maximum).
@@ -754,16 +1210,71 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
     ta.seg_width = static_cast<int>(L.seg_width);
     ta.n_skip_low = n_skip_low;
     ta.col_stride = static_cast<int>(L.stride);
-    if (hipMemsetAsync(ta.cnt, 0, static_cast<size_t>(B) * kSeg * 4, st) != hipSuccess) {
+    const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
+    static const bool bf16_path = [] { const char* e = getenv("MI_OOV_TOPK_BF16"); return !(e && e[0] == '0'); }();
+    int rc;
+    if (bf16_path && D == 64 && vec) {
+      // both GEMM passes on the bf16 matrix cores, exact f32 re-score of the survivors (see bf16_tile_kernel)
+      float* u2 = reinterpret_cast<float*>(ws + L.off_u2);
+      float* thr = reinterpret_cast<float*>(ws + L.off_thr);
+      float* eps = reinterpret_cast<float*>(ws + L.off_eps);
+      uint32_t* e2max = reinterpret_cast<uint32_t*>(ws + L.off_e2max);
+      __bf16* Ub = reinterpret_cast<__bf16*>(ws + L.off_ub);
+      __bf16* Eb = reinterpret_cast<__bf16*>(ws + L.off_eb);
+      const int64_t nblk = (N + BN - 1) / BN;
+      const int64_t rb = (B + BM - 1) / BM;
+      static const int64_t target = [] { const char* e = getenv("MI_OOV_STRIP_WGS"); return e ? atoll(e) : 1024LL; }();
+      auto strips = [&](int64_t nvisit) {  // ~target workgroups in all, at most 128 strips, a multiple of 8 when there are 8 blocks
+        int64_t n = target / rb;
+        if (n > 128) n = 128;
+        if (n > nvisit) n = nvisit;
+        if (n < 1) n = 1;
+        if (nvisit >= 8) n = (n + 7) / 8 * 8;
+        return n > 128 ? 128 : n;
+      };
+      const int64_t nvisit1 = (nblk + L.stride - 1) / L.stride;
+      const int64_t ns1 = strips(nvisit1), ns2 = strips(nblk);
+      StripLists sl{};
+      sl.ns = static_cast<int>(ns2);
+      {  // list capacity: 3x the expected share of ~1.3 k stride candidates per row + 8, within the finalize kernel's slots
+        int64_t cap = (3 * 13 * k * L.stride / 10 / ns2 + 8 + 7) / 8 * 8;
+        if (cap > kStripSlots / ns2) cap = kStripSlots / ns2;
+        sl.cap = static_cast<int>(cap);
+      }
+      sl.cnt = ta.cnt;                                  // [B, ns2]
+      sl.ovf_cnt = ta.cnt + B * 128;                    // [B]
+      sl.cand = ta.cand;                                // [B, ns2 * cap <= kStripSlots]
+      sl.ovf = ta.cand + B * kStripSlots;               // [B, kOvfCap]
+      const int64_t gu = grid_for(B, kBlock / 16), ge = grid_for(N, kBlock / 16);
+      hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(gu < kNormGrid ? gu : kNormGrid)), dim3(kBlock), 0, st, U, B, Ub, u2,
+                         static_cast<uint32_t*>(nullptr), e2max, sl.ovf_cnt);
+      hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(ge < kNormGrid ? ge : kNormGrid)), dim3(kBlock), 0, st, E, N, Eb,
+                         static_cast<float*>(nullptr), e2max, static_cast<uint32_t*>(nullptr), static_cast<int*>(nullptr));
+      if ((rc = check_launch())) return rc;
+      const size_t lds_ops = static_cast<size_t>(BM + BN) * BLD * sizeof(__bf16);
+      const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
+      hipLaunchKernelGGL(bf16_tile_kernel<EPI_TILEMAX>, dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
+                         Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
+      Bf16Bound bb{u2, e2max, thr, eps, getenv("MI_OOV_DEBUG_NOCAND") ? 1 : 0};
+      hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, L.NT,
+                         static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf), bb);
+      if ((rc = check_launch())) return rc;
+      hipLaunchKernelGGL(bf16_tile_kernel<EPI_FILTER>, dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
+                         Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
+      if ((rc = check_launch())) return rc;
+      hipLaunchKernelGGL(topk_finalize_exact_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, U, E, B, N, D,
+                         static_cast<int>(k), n_skip_low, sl, eps, vals, idx);
+      return check_launch();
+    }
+    if (hipMemsetAsync(ta.cnt, 0, static_cast<size_t>(B) * (kSeg + 1) * 4, st) != hipSuccess) {
       check_launch();
       return MI_OOV_ERR_LAUNCH;
     }
-    const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
-    int rc = vec ? launch_tiled<true, EPI_TILEMAX>(U, B, E, N, D, nullptr, nullptr, 0, st, ta)
-                 : launch_tiled<false, EPI_TILEMAX>(U, B, E, N, D, nullptr, nullptr, 0, st, ta);
+    rc = vec ? launch_tiled<true, EPI_TILEMAX>(U, B, E, N, D, nullptr, nullptr, 0, st, ta)
+             : launch_tiled<false, EPI_TILEMAX>(U, B, E, N, D, nullptr, nullptr, 0, st, ta);
     if (rc) return rc;
     hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, L.NT,
-                       static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf));
+                       static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf), Bf16Bound{});
     if ((rc = check_launch())) return rc;
     rc = vec ? launch_tiled<true, EPI_FILTER>(U, B, E, N, D, nullptr, nullptr, 0, st, ta)
              : launch_tiled<false, EPI_FILTER>(U, B, E, N, D, nullptr, nullptr, 0, st, ta);
