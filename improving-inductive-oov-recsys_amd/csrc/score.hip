@@ -487,10 +487,8 @@ struct Bf16Bound {
   const uint32_t* e2max;   // max squared row norm of E (float bits)
   float* thr;              // [B] out
   float* eps;              // [B] out
-  int dbg;                 // TIMING EXPERIMENT ONLY
 };
 __device__ __forceinline__ void bf16_threshold(const Bf16Bound& bb, int64_t row, float tauf) {
-  if (bb.dbg) { bb.thr[row] = __builtin_inff(); bb.eps[row] = 0.f; return; }
   // + what flushing subnormal bf16 operands to zero could cost: 2^-126 * sqrt(D) * (|u| + |e|), D <= 64
   const float nu = sqrtf(bb.u2[row]), ne = sqrtf(__uint_as_float(*bb.e2max));
   const float eps = 1.05f * 0x1p-8f * nu * ne + 0x1p-123f * (nu + ne) + 1e-30f;
@@ -526,6 +524,32 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
   int need_eq;
   radix_kth(U32Keys{tilemax + row * NT}, 0, NT, k, T, need_eq);
   if (threadIdx.x == 0) {
+    tau[row] = T;
+    tauf[row] = tau_as_float(T);
+    if (bb.thr) bf16_threshold(bb, row, tau_as_float(T));
+  }
+}
+
+// the same for NT <= 256, one wave per row (4 rows per workgroup): the tile maxima sit in registers and the k-th best
+// is the largest T with at least k keys >= T, found bit by bit (32 ballot steps; the workgroup-per-row kernel above
+// takes 12.5 us for 4096 rows of 98 keys, nearly all of it launch and barrier latency)
+__global__ __launch_bounds__(kBlock) void tile_kth_wave_kernel(const uint32_t* __restrict__ tilemax, int64_t B, int NT, int k,
+                                                               uint32_t* __restrict__ tau, float* __restrict__ tauf, Bf16Bound bb) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
+  if (row >= B) return;
+  uint32_t key[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) key[q] = (q * 64 + lane < NT) ? tilemax[row * NT + q * 64 + lane] : 0u;
+  uint32_t T = 0u;  // (fewer than k keys > 0: T stays 0 = "no bound", as the rank-counting kernel returns)
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t c = T | (1u << bit);
+    int have = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) have += __popcll(__ballot(key[q] >= c));
+    if (have >= k) T = c;
+  }
+  if (lane == 0) {
     tau[row] = T;
     tauf[row] = tau_as_float(T);
     if (bb.thr) bf16_threshold(bb, row, tau_as_float(T));
@@ -672,10 +696,10 @@ extern "C" int mi_oov_topk_hits(const int64_t* idx, int64_t S, int64_t k, const 
   return check_launch();
 }
 
-// ---- bf16 prefilter for the second pass of the fused top-k (D = 64) ------------------------------------------------------
-// The filter pass only has to decide which (row, column) pairs MAY belong to the top-k: the exact f32 score of the few
-// hundred survivors per row is recomputed by the finalize kernel anyway.  So the pass runs on the bf16 matrix cores
-// (v_mfma_f32_32x32x16_bf16: 16 x the f32 MFMA rate; operands converted to bf16 while they are staged) with a threshold
+// ---- bf16 prefilter: both GEMM passes of the fused top-k (D = 64) ---------------------------------------------------------
+// The two passes only have to decide which (row, column) pairs MAY belong to the top-k: the exact f32 score of the few
+// hundred survivors per row is recomputed by the finalize kernel anyway.  So they run on the bf16 matrix cores
+// (v_mfma_f32_32x32x16_bf16: 16 x the f32 MFMA rate; bf16 copies of U and E are made once per call) with a threshold
 // lowered by a bound on the bf16 error:
 //     |s_bf16 - s_f32| <= (2^-8 + 2^-17 + 2 D 2^-24) * sum_d |u_d e_d|  <=  1.02 * 2^-8 * |u| * |e|      (Cauchy-Schwarz)
 // (each operand rounds to 8 significant bits: relative 2^-9; f32 accumulation on both sides).  With eps_row =
@@ -757,8 +781,10 @@ constexpr int kWaveQueue = 128;  // queued candidates per wave and tile (6 B eac
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// (pass 1 runs ~3 workgroups per CU anyway -- 800 working workgroups -- and at 128 registers it spills: the reload's
+// s_waitcnt vmcnt(0) then also waits for the block prefetch)
 template <int EPI>
-__global__ __launch_bounds__(kBlock, 4) void bf16_tile_kernel(const __bf16* __restrict__ Ub, int64_t B,
+__global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_kernel(const __bf16* __restrict__ Ub, int64_t B,
                                                              const __bf16* __restrict__ Eb, int64_t N,
                                                              const float* __restrict__ thr, TopkArgs ta, StripLists sl,
                                                              int nvisit) {
@@ -795,7 +821,7 @@ __global__ __launch_bounds__(kBlock, 4) void bf16_tile_kernel(const __bf16* __re
   }
   if constexpr (EPI == EPI_FILTER) {
     if (tid < BM) {
-      snthr[tid] = (tid < rows_here) ? -thr[b0 + tid] : -__builtin_inff();
+      snthr[tid] = (tid < rows_here) ? 0.f - thr[b0 + tid] : -__builtin_inff();  // (0 - t: never -0)
       rowcnt[tid] = 0;
     }
   }
@@ -888,18 +914,16 @@ __global__ __launch_bounds__(kBlock, 4) void bf16_tile_kernel(const __bf16* __re
       }
     } else {
       // pass 2: every score that is not below the row's threshold -> the (row, strip) list
+      f32x16 seed[2];  // -thr of the 16 rows a lane holds per 32 x 32 tile: the C operand of the first MFMA
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {  // accumulator r holds row (r & 3) + 8 (r >> 2) + 4 hh of the 32 x 32 tile
-          const f32x4 init = *reinterpret_cast<const f32x4*>(snthr + lrow0 + m * 32 + 8 * g);
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            acc[m][n][4 * g + 0] = init.x;
-            acc[m][n][4 * g + 1] = init.y;
-            acc[m][n][4 * g + 2] = init.z;
-            acc[m][n][4 * g + 3] = init.w;
-          }
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(snthr + lrow0 + m * 32 + 8 * g);
+          seed[m][4 * g + 0] = t4.x;
+          seed[m][4 * g + 1] = t4.y;
+          seed[m][4 * g + 2] = t4.z;
+          seed[m][4 * g + 3] = t4.w;
         }
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
@@ -913,7 +937,8 @@ __global__ __launch_bounds__(kBlock, 4) void bf16_tile_kernel(const __bf16* __re
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < 2; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], ks == 0 ? seed[m] : acc[m][n], 0, 0, 0);
       }
       // A passing score costs one queue push here (no waiting): the wave's queue is drained once per tile, one LDS
       // atomic on the row's list counter and one store per entry, all entries in parallel.  (Taking the list slot inside
@@ -981,102 +1006,162 @@ __global__ __launch_bounds__(kBlock, 4) void bf16_tile_kernel(const __bf16* __re
   }
 }
 
-// finalize for the bf16 prefilter: gather the row's strip lists, cut by the k-th best bf16 key, exact f32 key of the
-// survivors (the oracle's fmaf chain), then the rank sort
+// finalize for the bf16 prefilter, one WAVE per row (4 rows per workgroup, no barriers on the common path): gather the
+// row's strip lists, cut by the k-th best bf16 key, exact f32 key of the survivors (the oracle's fmaf chain), rank sort.
+// (One 256-thread workgroup per row spent 48 us on 4096 rows: barriers between six short phases, and a rank-counting
+// pass over all ~200 candidates with 64-bit compares, 26 us of VALU work; the k-th key is found here by a 32-step
+// bitwise search instead, ~15 instructions per step.)
 constexpr int kStripSlots = 1024;  // ns * cap <= kStripSlots
+constexpr int kFinRows = kBlock / 64;
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+  int inc = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int t = __shfl_up(inc, off, 64);
+    if (lane >= off) inc += t;
+  }
+  return inc;
+}
+
 __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float* __restrict__ U, const float* __restrict__ E,
                                                                      int64_t B, int64_t N, int64_t D, int k,
                                                                      int64_t n_skip_low, StripLists sl,
                                                                      const float* __restrict__ eps_row,
                                                                      float* __restrict__ vals, int64_t* __restrict__ idx) {
-  __shared__ uint64_t lc[kStripSlots + kOvfCap];
-  __shared__ int seg_off[128 + 2];
-  __shared__ int overflow, n_keep;
-  __shared__ uint32_t kth_key;
-  __shared__ float su[64];
-  const int64_t row = blockIdx.x;
-  if (row >= B) return;
-  const int ns = sl.ns;  // <= 128
-  int mine = 0;
-  if (threadIdx.x < ns) mine = sl.cnt[row * ns + threadIdx.x];
-  if (threadIdx.x == ns) mine = sl.ovf_cnt[row];
-  if (threadIdx.x <= ns) seg_off[threadIdx.x + 1] = mine;  // counts first, offsets after the scan below
-  if (threadIdx.x < 64) su[threadIdx.x] = U[row * 64 + threadIdx.x];
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int oc = seg_off[ns + 1];
-    int n = 0;
-    for (int g = 0; g < ns; ++g) {
-      const int c = seg_off[g + 1];
-      seg_off[g] = n;
-      n += c;
-    }
-    seg_off[ns] = n;
-    seg_off[ns + 1] = n + (oc < kOvfCap ? oc : kOvfCap);
-    overflow = (oc > kOvfCap);
-    n_keep = 0;
-    kth_key = 0u;
-  }
-  __syncthreads();
-  if (overflow) {
-    select_topk_row(DotKeys{U + row * D, E, D}, N, k, n_skip_low, vals + row * k, idx + row * k);
-    return;
-  }
-  for (int i = threadIdx.x; i < ns * sl.cap; i += kBlock) {
-    const int g = i / sl.cap, j = i % sl.cap;
-    if (j < seg_off[g + 1] - seg_off[g]) lc[seg_off[g] + j] = sl.cand[(row * ns + g) * sl.cap + j];
-  }
-  for (int j = threadIdx.x; j < seg_off[ns + 1] - seg_off[ns]; j += kBlock) lc[seg_off[ns] + j] = sl.ovf[row * kOvfCap + j];
-  __syncthreads();
-  const int n = seg_off[ns + 1];
-  // Stage 1: v_k = the k-th best bf16 score.  The k candidates at or above it have exact scores >= v_k - eps, so a
-  // candidate whose bf16 score is below v_k - 2 eps (exact score < v_k - eps) cannot be in the top k: only the others
-  // are re-scored exactly.  eps is the bound the filter pass used (the keys are shifted by the row's threshold, which
-  // cancels in the comparison).
-  const int kk = n < k ? n : k;
-  for (int i = threadIdx.x; i < n; i += kBlock) {
-    const uint64_t me = lc[i];
-    int rank = 0;
-    for (int j = 0; j < n; ++j) rank += (lc[j] > me) ? 1 : 0;
-    if (rank == kk - 1) kth_key = static_cast<uint32_t>(me >> 32);
-  }
-  __syncthreads();
-  const float eps = eps_row[row];
-  const float vk = key_to_float(kth_key);
-  const float cut = vk - 2.f * eps;  // NaN / -inf when anything is not finite: then every candidate is re-scored
-  // Stage 2: exact f32 score of the survivors -- 16 independent float4 loads of the item row, then the oracle's chain
-  // acc = fma(u[d], e[d], acc), d = 0..63 from +0 (the order the f32 MFMA kernel runs); compacted in place
-  for (int base = 0; base < n; base += kBlock) {
-    const int i = base + threadIdx.x;
-    uint64_t out = 0;
-    bool keep = false;
-    if (i < n) {
-      const uint64_t me = lc[i];
-      const float sb = key_to_float(static_cast<uint32_t>(me >> 32));
-      keep = !(sb < cut);
-      if (keep) {
-        const uint32_t inv = static_cast<uint32_t>(me);
-        const float4* e4 = reinterpret_cast<const float4*>(E + static_cast<int64_t>(0xFFFFFFFFu - inv) * 64);
-        float4 ev[16];
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // kFinRows x (ns cap + kOvfCap) gathered entries
+  __shared__ int cnt_all[kFinRows][128], off_all[kFinRows][128];
+  __shared__ int ovf_row[kFinRows];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kFinRows + wv);  // wave-uniform
+  uint64_t* lc = reinterpret_cast<uint64_t*>(smem) + wv * (sl.ns * sl.cap + kOvfCap);
+  int* lcnt = cnt_all[wv];
+  int* loff = off_all[wv];
+  bool overflow = false;
+  if (row < B) {
+    const int ns = sl.ns, cap = sl.cap;  // ns <= 128, cap a power of two, ns * cap <= kStripSlots
+    const int cap_shift = __builtin_ctz(cap);
+    // the lists' lengths and their offsets in the gathered array
+    const int c0 = lane < ns ? sl.cnt[static_cast<int64_t>(row) * ns + lane] : 0;
+    const int c1 = lane + 64 < ns ? sl.cnt[static_cast<int64_t>(row) * ns + lane + 64] : 0;
+    const int oc_raw = sl.ovf_cnt[row];
+    const int i0 = wave_incl_scan(c0, lane), t0 = __shfl(i0, 63, 64);
+    const int i1 = wave_incl_scan(c1, lane), t1 = __shfl(i1, 63, 64);
+    lcnt[lane] = c0;
+    lcnt[lane + 64] = c1;
+    loff[lane] = i0 - c0;
+    loff[lane + 64] = t0 + i1 - c1;
+    overflow = oc_raw > kOvfCap;
+    const int oc = oc_raw < kOvfCap ? oc_raw : kOvfCap;
+    const int n = t0 + t1 + oc;
+    __builtin_amdgcn_wave_barrier();
+    if (!overflow) {
+      const uint64_t* lists = sl.cand + static_cast<int64_t>(row) * ns * cap;
+      for (int s0 = 0; s0 < ns * cap; s0 += 256) {  // 4 independent loads per lane and round
+        uint64_t v[4];
+        int dst[4];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) ev[c] = e4[c];
-        float acc = 0.f;
-#pragma unroll
-        for (int c = 0; c < 16; ++c) {
-          acc = __builtin_fmaf(su[4 * c + 0], ev[c].x, acc);
-          acc = __builtin_fmaf(su[4 * c + 1], ev[c].y, acc);
-          acc = __builtin_fmaf(su[4 * c + 2], ev[c].z, acc);
-          acc = __builtin_fmaf(su[4 * c + 3], ev[c].w, acc);
+        for (int q = 0; q < 4; ++q) {
+          const int slot = s0 + q * 64 + lane;
+          const int g = slot >> cap_shift, j = slot & (cap - 1);
+          dst[q] = -1;
+          if (slot < ns * cap && j < lcnt[g]) {
+            dst[q] = loff[g] + j;
+            v[q] = lists[slot];
+          }
         }
-        out = (static_cast<uint64_t>(order_key(acc)) << 32) | inv;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (dst[q] >= 0) lc[dst[q]] = v[q];
+      }
+      for (int j = lane; j < oc; j += 64) lc[t0 + t1 + j] = sl.ovf[static_cast<int64_t>(row) * kOvfCap + j];
+      __builtin_amdgcn_wave_barrier();
+      // Stage 1: v_k = the k-th best bf16 key: the largest T with at least kk keys >= T, bit by bit.  The k candidates
+      // at or above it have exact scores >= v_k - eps, so a candidate whose bf16 score is below v_k - 2 eps (exact
+      // score < v_k - eps) cannot be in the top k: only the others are re-scored exactly.  eps is the bound the filter
+      // pass used (the keys are shifted by the row's threshold, which cancels in the comparison).
+      const int kk = n < k ? n : k;
+      uint32_t mykey[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mykey[q] = (q * 64 + lane < n) ? static_cast<uint32_t>(lc[q * 64 + lane] >> 32) : 0u;
+      uint32_t T = 0u;
+      if (kk > 0) {
+        for (int bit = 31; bit >= 0; --bit) {
+          const uint32_t c = T | (1u << bit);
+          int have = 0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) have += __popcll(__ballot(mykey[q] >= c));  // (an absent slot's key 0 never counts: c > 0)
+          for (int b = 256; b < n; b += 64)  // lists longer than 256 entries (rare): from LDS
+            have += __popcll(__ballot(b + lane < n && static_cast<uint32_t>(lc[b + lane < n ? b + lane : 0] >> 32) >= c));
+          if (have >= kk) T = c;
+        }
+      }
+      const float eps = eps_row[row];
+      const float cut = key_to_float(T) - 2.f * eps;  // NaN / -inf when anything is not finite: then every candidate is re-scored
+      // Stage 2: exact f32 score of the survivors -- 16 independent float4 loads of the item row, then the oracle's chain
+      // acc = fma(u[d], e[d], acc), d = 0..63 from +0 (the order the f32 MFMA kernel runs); the user row comes in
+      // scalar registers
+      const float* u = U + static_cast<int64_t>(row) * 64;
+      int m = 0;
+      for (int base = 0; base < n; base += 64) {  // survivors to the front (a survivor's new slot is never above its old one)
+        const int i = base + lane;
+        const uint64_t me = i < n ? lc[i] : 0;
+        const bool keep = i < n && !(key_to_float(static_cast<uint32_t>(me >> 32)) < cut);
+        const uint64_t mask = __ballot(keep);
+        __builtin_amdgcn_wave_barrier();  // every lane holds its lc[i] before slots <= i are rewritten
+        if (keep)
+          lc[m + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)))] = me;
+        m += __popcll(mask);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int base = 0; base < m; base += 64) {  // usually one round: all the gathers of the row in flight together
+        const int i = base + lane;
+        if (i < m) {
+          const uint32_t inv = static_cast<uint32_t>(lc[i]);
+          const float4* e4 = reinterpret_cast<const float4*>(E + static_cast<int64_t>(0xFFFFFFFFu - inv) * 64);
+          float4 ev[16];
+#pragma unroll
+          for (int c = 0; c < 16; ++c) ev[c] = e4[c];
+          float acc = 0.f;
+#pragma unroll
+          for (int c = 0; c < 16; ++c) {
+            acc = __builtin_fmaf(u[4 * c + 0], ev[c].x, acc);
+            acc = __builtin_fmaf(u[4 * c + 1], ev[c].y, acc);
+            acc = __builtin_fmaf(u[4 * c + 2], ev[c].z, acc);
+            acc = __builtin_fmaf(u[4 * c + 3], ev[c].w, acc);
+          }
+          lc[i] = (static_cast<uint64_t>(order_key(acc)) << 32) | inv;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // rank sort of the m survivors; the best kk go out
+      const int kout = m < k ? m : k;
+      float* vals_row = vals + static_cast<int64_t>(row) * k;
+      int64_t* idx_row = idx + static_cast<int64_t>(row) * k;
+      for (int i = lane; i < m; i += 64) {
+        const uint64_t me = lc[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += (lc[j] > me) ? 1 : 0;
+        if (rank < kout) {
+          vals_row[rank] = key_to_float(static_cast<uint32_t>(me >> 32));
+          idx_row[rank] = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(me));
+        }
+      }
+      for (int t = kout + lane; t < k; t += 64) {  // fewer than k candidate columns exist
+        vals_row[t] = -__builtin_inff();
+        idx_row[t] = -1;
       }
     }
-    __syncthreads();  // everyone has read its lc[i] of this batch: the compaction below may overwrite lower slots only
-    if (keep) lc[atomicAdd(&n_keep, 1)] = out;  // n_keep <= base + (threads done) <= i: never ahead of an unread slot
+  }
+  // rows whose overflow list ran over: exact selection over the whole catalogue by the full workgroup (rare)
+  if (lane == 0) ovf_row[wv] = overflow ? 1 : 0;
+  __syncthreads();
+  for (int w = 0; w < kFinRows; ++w) {
+    if (!ovf_row[w]) continue;
+    const int64_t r = static_cast<int64_t>(blockIdx.x) * kFinRows + w;
+    select_topk_row(DotKeys{U + r * D, E, D}, N, k, n_skip_low, vals + r * k, idx + r * k);
     __syncthreads();
   }
-  const int m = n_keep;
-  emit_ranked(lc, m, m < k ? m : k, k, vals + row * k, idx + row * k);
 }
 
 static size_t full_sort_lds() { return static_cast<size_t>(BM + BN) * LDK * sizeof(float); }
@@ -1236,9 +1321,14 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
       const int64_t ns1 = strips(nvisit1), ns2 = strips(nblk);
       StripLists sl{};
       sl.ns = static_cast<int>(ns2);
-      {  // list capacity: 3x the expected share of ~1.3 k stride candidates per row + 8, within the finalize kernel's slots
-        int64_t cap = (3 * 13 * k * L.stride / 10 / ns2 + 8 + 7) / 8 * 8;
-        if (cap > kStripSlots / ns2) cap = kStripSlots / ns2;
+      {  // list capacity: a power of two >= `MI_OOV_LIST_SLACK` (2) x the expected share of ~1.3 k stride candidates per
+         // row, within the finalize kernel's slots: the rare longer list continues in the row's overflow list, and a
+         // smaller gathered array lets the finalize kernel keep more rows in flight
+        static const int64_t slack = [] { const char* e = getenv("MI_OOV_LIST_SLACK"); return e ? atoll(e) : 2LL; }();
+        const int64_t want = slack * 13 * k * L.stride / 10 / ns2 + 1;
+        int64_t cap = 8;
+        while (cap < want && cap * 2 * ns2 <= kStripSlots) cap *= 2;
+        while (cap > 1 && cap * ns2 > kStripSlots) cap /= 2;
         sl.cap = static_cast<int>(cap);
       }
       sl.cnt = ta.cnt;                                  // [B, ns2]
@@ -1255,14 +1345,20 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
       const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
       hipLaunchKernelGGL(bf16_tile_kernel<EPI_TILEMAX>, dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
                          Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
-      Bf16Bound bb{u2, e2max, thr, eps, getenv("MI_OOV_DEBUG_NOCAND") ? 1 : 0};
-      hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, L.NT,
-                         static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf), bb);
+      Bf16Bound bb{u2, e2max, thr, eps};
+      if (L.NT <= 256)
+        hipLaunchKernelGGL(tile_kth_wave_kernel, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
+                           static_cast<int>(L.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
+                           reinterpret_cast<float*>(ws + L.off_tauf), bb);
+      else
+        hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, L.NT,
+                           static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf), bb);
       if ((rc = check_launch())) return rc;
       hipLaunchKernelGGL(bf16_tile_kernel<EPI_FILTER>, dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
                          Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
       if ((rc = check_launch())) return rc;
-      hipLaunchKernelGGL(topk_finalize_exact_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, U, E, B, N, D,
+      hipLaunchKernelGGL(topk_finalize_exact_kernel, dim3(static_cast<unsigned>((B + kFinRows - 1) / kFinRows)), dim3(kBlock),
+                         static_cast<size_t>(kFinRows) * (sl.ns * sl.cap + kOvfCap) * 8, st, U, E, B, N, D,
                          static_cast<int>(k), n_skip_low, sl, eps, vals, idx);
       return check_launch();
     }

@@ -306,6 +306,38 @@ def test_fused_topk_vs_oracle(B, N, D, k, skip, oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
+@pytest.mark.parametrize("case", ["cluster_small", "cluster_big", "neg_nan", "many_strips", "skip_mid_tile"])
+def test_fused_topk_bf16_lists(case, oracle, ops, dev):
+    """The D = 64 fused path filters on bf16 matrix-core scores into per-(row, strip) lists and re-scores the
+    survivors exactly.  Shapes that stress the list plumbing: a cluster of dominant columns inside one strip (lists run
+    over into the row's overflow list), a cluster too big for both (exact fallback for every row), NaNs of either sign,
+    few rows (128 strips, 8-entry lists), a skip bound inside a tile.  Bit-exact against the oracle in all of them."""
+    rng = np.random.default_rng(sum(map(ord, case)))
+    B, N, k, skip = 96, 20000, 20, 1
+    U = rng.standard_normal((B, 64), dtype=np.float32)
+    E = rng.standard_normal((N, 64), dtype=np.float32)
+    if case == "cluster_small":
+        E[5000:5060] *= 4.0            # 60 adjacent columns carry every row's top scores (positive or negative)
+    elif case == "cluster_big":
+        E[5000:5600] *= 4.0
+    elif case == "neg_nan":
+        E[77] = np.float32(np.nan)
+        E[9000] = np.frombuffer(np.uint32(0xFFC00000).tobytes(), np.float32)[0]   # x86's default (negative) NaN
+        E[12000, 3] = np.inf
+        U[5] = 0.0
+        U[6, 0] = np.inf               # inf - inf / 0 * inf rows
+    elif case == "many_strips":
+        B, N, k = 7, 60000, 50
+        U = rng.standard_normal((B, 64), dtype=np.float32)
+        E = rng.standard_normal((N, 64), dtype=np.float32)
+    elif case == "skip_mid_tile":
+        skip, k = 333, 33
+    vals, idx = ops.score_topk(T(U, dev), T(E, dev), k, skip)
+    o_vals, o_idx = oracle.score_topk(U, E, k, skip)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    assert bits_equal(vals.cpu().numpy(), o_vals)
+
+
 def test_gather_splice_vs_oracle(oracle, ops, dev):
     rng = np.random.default_rng(11)
     for D in (64, 1, 50, 200):

@@ -18,5 +18,4 @@ for r in csv.DictReader(open(f)):
 PY
   rm -rf $out/pt_$tag
 }
-run base MI_OOV_STRIP_WGS=1024 &&
-run nocand MI_OOV_DEBUG_NOCAND=1
+run base MI_OOV_STRIP_WGS=1024
