@@ -1233,7 +1233,7 @@ struct FusedLayout {
   int64_t NT, cap, stride, seg_width, off_tilemax, off_tau, off_tauf, off_u2, off_thr, off_eps, off_e2max, off_ub, off_eb, off_cnt, off_cand, bytes;
 };
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
-static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k) {
+static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16) {
   FusedLayout L;
   // Pass 1 only needs a LOWER bound of the k-th best score, and the k-th best of any subset of the columns is
   // one: it visits every `stride`-th 128-column block (1/stride of the GEMM work).  The filter pass then lets
@@ -1242,8 +1242,10 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k) {
   // sampled blocks must still hold at least 2k tiles.  Results are unchanged: every true top-k entry has a
   // score >= tau and the finalize kernel ranks exactly.
   const int64_t nblk = (N + BN - 1) / BN;
-  static const int64_t max_stride = [] { const char* e = getenv("MI_OOV_TOPK_STRIDE"); return e ? atoll(e) : 8LL; }();
-  int64_t stride = max_stride;
+  // The bf16 path's passes are cheap next to its per-candidate work: stride 4-5 is its optimum (k = 20, 4096 x 50000:
+  // 8 -> 124 us, 4-5 -> 106 us, 3 -> 153 us); the f32 path pays a full-rate GEMM for pass 1 and keeps 8.
+  static const int64_t env_stride = [] { const char* e = getenv("MI_OOV_TOPK_STRIDE"); return e ? atoll(e) : 0LL; }();
+  int64_t stride = env_stride > 0 ? env_stride : (bf16 ? 4 : 8);
   if (stride > 256 / k) stride = 256 / k;  // ~k * stride candidates per row: a quarter of the 1024 slots
   if (stride > nblk / k) stride = nblk / k;  // sampled 64-column tiles: 2 * nblk / stride >= 2k
   if (stride < 1) stride = 1;
@@ -1270,7 +1272,10 @@ static bool use_fused_topk(int64_t N, int64_t k) { return k <= 256 && (N + 63) /
 
 extern "C" int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k) {
   if (B <= 0 || N <= 0 || k <= 0) return 0;
-  if (use_fused_topk(N, k)) return fused_layout(B, N, k).bytes;
+  if (use_fused_topk(N, k)) {  // the path is chosen per call (D, alignment): room for either
+    const int64_t a = fused_layout(B, N, k, true).bytes, b = fused_layout(B, N, k, false).bytes;
+    return a > b ? a : b;
+  }
   return topk_chunk_rows(B, N) * N * static_cast<int64_t>(sizeof(float));
 }
 
@@ -1282,7 +1287,10 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
   if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_OOV_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535) {
-    const FusedLayout L = fused_layout(B, N, k);
+    const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
+    static const bool bf16_path = [] { const char* e = getenv("MI_OOV_TOPK_BF16"); return !(e && e[0] == '0'); }();
+    const bool use_bf16 = bf16_path && D == 64 && vec;
+    const FusedLayout L = fused_layout(B, N, k, use_bf16);
     char* ws = static_cast<char*>(workspace);
     TopkArgs ta{};
     ta.tilemax = reinterpret_cast<uint32_t*>(ws + L.off_tilemax);
@@ -1295,10 +1303,8 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
     ta.seg_width = static_cast<int>(L.seg_width);
     ta.n_skip_low = n_skip_low;
     ta.col_stride = static_cast<int>(L.stride);
-    const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
-    static const bool bf16_path = [] { const char* e = getenv("MI_OOV_TOPK_BF16"); return !(e && e[0] == '0'); }();
     int rc;
-    if (bf16_path && D == 64 && vec) {
+    if (use_bf16) {
       // both GEMM passes on the bf16 matrix cores, exact f32 re-score of the survivors (see bf16_tile_kernel)
       float* u2 = reinterpret_cast<float*>(ws + L.off_u2);
       float* thr = reinterpret_cast<float*>(ws + L.off_thr);
@@ -1309,8 +1315,9 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
       const int64_t nblk = (N + BN - 1) / BN;
       const int64_t rb = (B + BM - 1) / BM;
       static const int64_t target = [] { const char* e = getenv("MI_OOV_STRIP_WGS"); return e ? atoll(e) : 1024LL; }();
-      auto strips = [&](int64_t nvisit) {  // ~target workgroups in all, at most 128 strips, a multiple of 8 when there are 8 blocks
-        int64_t n = target / rb;
+      static const int64_t target1 = [] { const char* e = getenv("MI_OOV_STRIP_WGS1"); return e ? atoll(e) : 768LL; }();  // pass 1: 3 workgroups per CU, one round
+      auto strips = [&](int64_t nvisit, int64_t tgt) {  // ~tgt workgroups in all, at most 128 strips, a multiple of 8 when there are 8 blocks
+        int64_t n = tgt / rb;
         if (n > 128) n = 128;
         if (n > nvisit) n = nvisit;
         if (n < 1) n = 1;
@@ -1318,7 +1325,7 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
         return n > 128 ? 128 : n;
       };
       const int64_t nvisit1 = (nblk + L.stride - 1) / L.stride;
-      const int64_t ns1 = strips(nvisit1), ns2 = strips(nblk);
+      const int64_t ns1 = strips(nvisit1, target1), ns2 = strips(nblk, target);
       StripLists sl{};
       sl.ns = static_cast<int>(ns2);
       {  // list capacity: a power of two >= `MI_OOV_LIST_SLACK` (2) x the expected share of ~1.3 k stride candidates per
