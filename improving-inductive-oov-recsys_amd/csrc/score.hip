@@ -965,29 +965,42 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
       int code0 = (lrow0 << 8) | lcol0;
       asm volatile("" : "+v"(code0));
       int qpos = 0;  // wave-uniform
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) {
-            const bool pass = !(acc[m][n][r] < 0.f);  // rare (a NaN passes too: emit() checks the row and the column)
-            const uint64_t mask = __ballot(pass);
-            if (mask) {
-              if (pass) {
-                const int slot = qpos + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
-                                                             __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)));
-                const int code = code0 + (((m * 32 + (r & 3) + 8 * (r >> 2)) << 8) | (n * 32));
-                if (slot < kWaveQueue) {
-                  qv[slot] = __float_as_uint(acc[m][n][r]);
-                  qc[slot] = static_cast<uint16_t>(code);
-                } else {  // queue full (runs of equal scores): take the slot here
-                  emit(code >> 8, static_cast<uint32_t>(code & 255), acc[m][n][r]);
-                }
-              }
-              qpos = __builtin_amdgcn_readfirstlane(qpos + __popcll(mask));
+      auto test_one = [&](int v) {  // v = m 32 + r 2 + n, a compile-time constant after unrolling
+        const int m = v >> 5, r = (v >> 1) & 15, n = v & 1;
+        const bool pass = !(acc[m][n][r] < 0.f);  // (a NaN passes too: emit() checks the row and the column)
+        const uint64_t mask = __ballot(pass);
+        if (mask) {
+          if (pass) {
+            const int slot = qpos + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)));
+            const int code = code0 + (((m * 32 + (r & 3) + 8 * (r >> 2)) << 8) | (n * 32));
+            if (slot < kWaveQueue) {
+              qv[slot] = __float_as_uint(acc[m][n][r]);
+              qc[slot] = static_cast<uint16_t>(code);
+            } else {  // queue full (runs of equal scores): take the slot here
+              emit(code >> 8, static_cast<uint32_t>(code & 255), acc[m][n][r]);
             }
           }
+          qpos = __builtin_amdgcn_readfirstlane(qpos + __popcll(mask));
+        }
+      };
+      // Three scores per wave-level branch: as signed integers the float images that FAIL (x < 0) are exactly those
+      // <= 0xFF800000 (-inf) -- negative numbers; NaNs of either sign and everything >= +0 lie above; -0 cannot occur,
+      // the seed is never -0 and a sum that cancels rounds to +0 -- so "some score passes" is one v_max3_i32 and one
+      // compare.  (About one wave-level test in eight finds a passing score; per-score branches were 3 instructions
+      // each on the path where none does.)
+      auto bits = [&](int v) { return static_cast<int>(__float_as_uint(acc[v >> 5][v & 1][(v >> 1) & 15])); };
+#pragma unroll
+      for (int v = 0; v < 64; v += 3) {
+        int mx = bits(v);
+        if (v + 1 < 64) mx = mx > bits(v + 1) ? mx : bits(v + 1);
+        if (v + 2 < 64) mx = mx > bits(v + 2) ? mx : bits(v + 2);
+        if (__ballot(mx > static_cast<int>(0xFF800000u))) {
+          test_one(v);
+          if (v + 1 < 64) test_one(v + 1);
+          if (v + 2 < 64) test_one(v + 2);
+        }
+      }
       __builtin_amdgcn_wave_barrier();
       const int nq = qpos < kWaveQueue ? qpos : kWaveQueue;
       for (int i = lane; i < nq; i += 64) {
