@@ -654,6 +654,94 @@ __global__ __launch_bounds__(kBlock) void segment_topk_kernel(const float* __res
   }
 }
 
+// The same, one WAVE per segment (4 segments per workgroup, no barriers): up to 2048 keys sit in registers (32 per
+// lane), the k-th best key T is the largest T with at least kk keys >= T (32 ballot steps), the winners -- every key
+// > T, then the first kk - n_gt positions with key == T -- are collected in position order and rank-sorted.  Same
+// outputs as segment_topk_kernel (which ranks 1506 candidates per user in 106 us for 4096 users: a radix select with
+// a dozen barriers per pass; this one is bound by reading the 12 B per candidate).  Longer segments stream the keys
+// from memory on every step (slow, rare).
+constexpr int kSegRegs = 32;
+__global__ __launch_bounds__(kBlock) void segment_topk_wave_kernel(const float* __restrict__ scores,
+                                                                   const int64_t* __restrict__ cols,
+                                                                   const int64_t* __restrict__ seg_ptr, int64_t S, int k,
+                                                                   int64_t col_lo, int64_t col_hi, float* __restrict__ vals,
+                                                                   int64_t* __restrict__ idx) {
+  __shared__ uint64_t win_all[kBlock / 64][256];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t seg = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + wv;
+  if (seg >= S) return;
+  uint64_t* win = win_all[wv];
+  const int64_t lo = seg_ptr[seg], n64 = seg_ptr[seg + 1] - lo;
+  float* vrow = vals + seg * k;
+  int64_t* irow = idx + seg * k;
+  const SegKeys keys{scores + lo, cols + lo, col_lo, col_hi};
+  const int n = n64 > 0x7FFFFFFF ? 0x7FFFFFFF : static_cast<int>(n64 < 0 ? 0 : n64);  // (positions are packed in 32 bits)
+  const int kk = n < k ? n : k;
+  const bool in_regs = n <= 64 * kSegRegs;
+  uint32_t reg[kSegRegs];
+  if (in_regs) {
+#pragma unroll
+    for (int q = 0; q < kSegRegs; ++q) reg[q] = (q * 64 + lane < n) ? keys(q * 64 + lane) : 0u;
+  }
+  // count of keys >= c (c > 0: absent slots never count)
+  auto count_ge = [&](uint32_t c) {
+    int have = 0;
+    if (in_regs) {
+#pragma unroll
+      for (int q = 0; q < kSegRegs; ++q)
+        if (q * 64 < n) have += __popcll(__ballot(reg[q] >= c));
+    } else {
+      for (int b = 0; b < n; b += 64) have += __popcll(__ballot(b + lane < n && keys(b + lane) >= c));
+    }
+    return have;
+  };
+  if (kk > 0) {
+    uint32_t T = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t c = T | (1u << bit);
+      if (count_ge(c) >= kk) T = c;
+    }
+    const int n_gt = (T == 0xFFFFFFFFu) ? 0 : count_ge(T + 1u);
+    const int need_eq = kk - n_gt;
+    int base_gt = 0, base_eq = 0;
+    auto place = [&](int i, uint32_t key) {  // all lanes call it, in position order
+      const bool gt = i < n && key > T, eq = i < n && key == T;
+      const uint64_t mg = __ballot(gt), me = __ballot(eq);
+      const uint64_t packed = (static_cast<uint64_t>(key) << 32) | (0xFFFFFFFFu - static_cast<uint32_t>(i));
+      const uint64_t below = (1ull << lane) - 1ull;
+      if (gt) win[base_gt + __popcll(mg & below)] = packed;
+      if (eq) {
+        const int p = base_eq + __popcll(me & below);
+        if (p < need_eq) win[n_gt + p] = packed;
+      }
+      base_gt += __popcll(mg);
+      base_eq += __popcll(me);
+    };
+    if (in_regs) {
+#pragma unroll
+      for (int q = 0; q < kSegRegs; ++q)
+        if (q * 64 < n) place(q * 64 + lane, reg[q]);
+    } else {
+      for (int b = 0; b < n; b += 64) place(b + lane, b + lane < n ? keys(b + lane) : 0u);
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < kk; i += 64) {  // rank sort of the winners; candidate position -> column, filtered ones dropped
+      const uint64_t mine = win[i];
+      int rank = 0;
+      for (int j = 0; j < kk; ++j) rank += (win[j] > mine) ? 1 : 0;
+      const int64_t pos = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(mine));
+      const int64_t col = cols[lo + pos];
+      const bool ok = col >= col_lo && col < col_hi;
+      vrow[rank] = ok ? key_to_float(static_cast<uint32_t>(mine >> 32)) : -__builtin_inff();
+      irow[rank] = ok ? col : -1;
+    }
+  }
+  for (int t = kk + lane; t < k; t += 64) {
+    vrow[t] = -__builtin_inff();
+    irow[t] = -1;
+  }
+}
+
 // rec.topk of the reference collector: out[s, j] = 1 when the j-th recommended column of segment s is one of its
 // positives, out[s, k] = number of positives (collector.py:161-166); positives are CSR (pos_ptr, pos_cols).
 __global__ __launch_bounds__(kBlock) void topk_hits_kernel(const int64_t* __restrict__ idx, int64_t S, int k,
@@ -681,8 +769,13 @@ extern "C" int mi_oov_segment_topk(const float* scores, const int64_t* cols, con
   if (S < 0 || k <= 0 || k > 256) return MI_OOV_ERR_SHAPE;
   if (S == 0) return MI_OOV_OK;
   if (!scores || !cols || !seg_ptr || !vals || !idx) return MI_OOV_ERR_NULL;
-  hipLaunchKernelGGL(segment_topk_kernel, dim3(static_cast<unsigned>(S)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                     scores, cols, seg_ptr, S, static_cast<int>(k), col_lo, col_hi, vals, idx);
+  static const bool wg_kernel = [] { const char* e = getenv("MI_OOV_SEGMENT_TOPK_WG"); return e && e[0] == '1'; }();
+  if (wg_kernel)
+    hipLaunchKernelGGL(segment_topk_kernel, dim3(static_cast<unsigned>(S)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       scores, cols, seg_ptr, S, static_cast<int>(k), col_lo, col_hi, vals, idx);
+  else
+    hipLaunchKernelGGL(segment_topk_wave_kernel, dim3(static_cast<unsigned>((S + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0,
+                       static_cast<hipStream_t>(stream), scores, cols, seg_ptr, S, static_cast<int>(k), col_lo, col_hi, vals, idx);
   return check_launch();
 }
 

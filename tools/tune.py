@@ -116,6 +116,12 @@ def main():
         "scatter_add_rows into 10M x 64 (gather backward)": (lambda i: ops.scatter_add_rows(ids[i], users[i % 8], N, out=gtab), B, 8 + 12 * D, 0),
         "segment_topk 4096 users x 1506 candidates k=20": (lambda i: ops.segment_topk(seg_scores, seg_cols, seg_ptr, 20), seg_scores.numel(), 12, 0),
     }
+    if args.only.startswith("score_topk sweep"):  # no cliffs over k, user-batch and catalogue sizes
+        for (b_, n_, k_) in ((4096, 50000, 1), (4096, 50000, 5), (4096, 50000, 50), (4096, 50000, 120), (4096, 50000, 256),
+                             (512, 50000, 20), (65536, 50000, 20), (4096, 500000, 20), (4096, 10000, 20)):
+            U_ = torch.randn(b_, D, device=dev)
+            E_ = torch.randn(n_, D, device=dev)
+            cases[f"score_topk sweep k={k_} B={b_} N={n_}"] = (lambda i, U_=U_, E_=E_, k_=k_: ops.score_topk(U_, E_, k_, 1), b_ * n_, 0, 2 * D)
     with torch.no_grad():
         for name, (fn, units, bpu, fpu) in cases.items():
             if args.only and args.only not in name:
