@@ -482,20 +482,28 @@ __device__ __forceinline__ float tau_as_float(uint32_t key) {
 // bf16 prefilter (see bf16_tile_kernel): eps[row] = 1.05 * 2^-8 * |u_row| * max|e| (+ the subnormal term),
 // thr[row] = tauf - 2 eps: tauf is the k-th best bf16 tile maximum, so the true k-th best score is >= tauf - eps, and a
 // column that reaches it has a bf16 score >= tauf - 2 eps.  -inf when the bound is not finite.
+constexpr int kNormGrid = 512;  // workgroups per matrix of the conversion kernel = partial maxima to reduce
 struct Bf16Bound {
   const float* u2;         // [B] squared row norms of U
-  const uint32_t* e2max;   // max squared row norm of E (float bits)
+  const uint32_t* e2part;  // [n_e2 <= kNormGrid] per-workgroup maxima of the squared row norms of E (float bits)
+  int n_e2;
   float* thr;              // [B] out
   float* eps;              // [B] out
 };
-__device__ __forceinline__ void bf16_threshold(const Bf16Bound& bb, int64_t row, float tauf) {
+// max_j |e_j|^2 as float bits: the callers pass the partial maxima they loaded (strided over the wave or the thread)
+__device__ __forceinline__ void bf16_threshold(const Bf16Bound& bb, int64_t row, float tauf, uint32_t e2) {
   // + what flushing subnormal bf16 operands to zero could cost: 2^-126 * sqrt(D) * (|u| + |e|), D <= 64
-  const float nu = sqrtf(bb.u2[row]), ne = sqrtf(__uint_as_float(*bb.e2max));
+  const float nu = sqrtf(bb.u2[row]), ne = sqrtf(__uint_as_float(e2));
   const float eps = 1.05f * 0x1p-8f * nu * ne + 0x1p-123f * (nu + ne) + 1e-30f;
   const float t = tauf - 2.f * eps;
   const bool ok = eps < __builtin_inff() && t == t;
   bb.thr[row] = ok ? t : -__builtin_inff();
   bb.eps[row] = ok ? eps : __builtin_inff();
+}
+__device__ __forceinline__ uint32_t e2_serial(const Bf16Bound& bb) {  // one thread (the workgroup-per-row kernel: rare shapes)
+  uint32_t e2 = 0u;
+  for (int i = 0; i < bb.n_e2; ++i) e2 = bb.e2part[i] > e2 ? bb.e2part[i] : e2;
+  return e2;
 }
 
 __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __restrict__ tilemax, int64_t B, int64_t NT,
@@ -515,7 +523,7 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
       if (ahead == k - 1) {
         tau[row] = me;
         tauf[row] = tau_as_float(me);
-        if (bb.thr) bf16_threshold(bb, row, tau_as_float(me));
+        if (bb.thr) bf16_threshold(bb, row, tau_as_float(me), e2_serial(bb));
       }
     }
     return;
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
   if (threadIdx.x == 0) {
     tau[row] = T;
     tauf[row] = tau_as_float(T);
-    if (bb.thr) bf16_threshold(bb, row, tau_as_float(T));
+    if (bb.thr) bf16_threshold(bb, row, tau_as_float(T), e2_serial(bb));
   }
 }
 
@@ -549,10 +557,19 @@ __global__ __launch_bounds__(kBlock) void tile_kth_wave_kernel(const uint32_t* _
     for (int q = 0; q < 4; ++q) have += __popcll(__ballot(key[q] >= c));
     if (have >= k) T = c;
   }
+  uint32_t e2 = 0u;
+  if (bb.thr) {  // max |e|^2: the norm kernel's per-workgroup maxima, reduced by the wave
+    for (int i = lane; i < bb.n_e2; i += 64) e2 = bb.e2part[i] > e2 ? bb.e2part[i] : e2;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const uint32_t o = __shfl_xor(e2, off, 64);
+      e2 = o > e2 ? o : e2;
+    }
+  }
   if (lane == 0) {
     tau[row] = T;
     tauf[row] = tau_as_float(T);
-    if (bb.thr) bf16_threshold(bb, row, tau_as_float(T));
+    if (bb.thr) bf16_threshold(bb, row, tau_as_float(T), e2);
   }
 }
 
@@ -805,44 +822,63 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int BLD = 72;  // bf16 elements per LDS row: 64 + 8 (144 B: staggers the banks, keeps 16-B alignment)
 
-// one pass over a matrix with 64-float rows: bf16 copy of every row + squared row norms (16 lanes per row); out[row] if
-// out, and the maximum over the rows into *maxbits (float bits, atomicMax on the unsigned image: valid for non-negative
-// floats, NaN images sort above +inf).  One global atomic per workgroup and at most 512 workgroups: atomics on one
-// address serialise at ~5 ns each (one per row took 140 us, one per 16 rows 26 us at N = 50000).
-constexpr int kNormGrid = 512;
-__global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __restrict__ M, int64_t rows,
-                                                              __bf16* __restrict__ Mb, float* __restrict__ out,
-                                                              uint32_t* __restrict__ maxbits, uint32_t* __restrict__ zero_this,
-                                                              int* __restrict__ zero_rows) {
+// bf16 copies of U and E (64-float rows) + squared row norms, one launch: workgroups [0, gu) take U (norms to u2[], the
+// rows' overflow counters zeroed), workgroups [gu, gu + ge) take E and leave the maximum squared norm of their rows in
+// e2part[workgroup] (float bits; unsigned order = float order for non-negative floats, NaN images sort above +inf; the
+// tau kernel reduces the <= 512 partials -- an atomicMax per row on one word took 140 us, one per workgroup 2.5 us, and
+// the word needed zeroing by an earlier launch).  16 lanes per row, 4 rows per thread and round (independent loads).
+// Separate launches for U and E were 5.2 + 9.3 us: a launch that moves 1 MB costs 5 us all the same.
+__global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __restrict__ U, int64_t B, __bf16* __restrict__ Ub,
+                                                              float* __restrict__ u2, int* __restrict__ zero_rows, int gu,
+                                                              const float* __restrict__ E, int64_t N, __bf16* __restrict__ Eb,
+                                                              uint32_t* __restrict__ e2part) {
   __shared__ uint32_t bmax;
+  const bool is_u = static_cast<int>(blockIdx.x) < gu;
+  const float* M = is_u ? U : E;
+  __bf16* Mb = is_u ? Ub : Eb;
+  const int64_t rows = is_u ? B : N;
+  const int blk = is_u ? blockIdx.x : blockIdx.x - gu, nblk = is_u ? gu : gridDim.x - gu;
   if (threadIdx.x == 0) bmax = 0u;
-  if (zero_this && blockIdx.x == 0 && threadIdx.x == 0) *zero_this = 0u;  // the NEXT launch's accumulator
   __syncthreads();
   const int l16 = threadIdx.x & 15;
   const int64_t per = kBlock / 16;
+  const int64_t step = static_cast<int64_t>(nblk) * per;
   uint32_t mine = 0u;
-  for (int64_t r = static_cast<int64_t>(blockIdx.x) * per + (threadIdx.x >> 4); r < rows; r += static_cast<int64_t>(gridDim.x) * per) {
-    const float4 v = *reinterpret_cast<const float4*>(M + r * 64 + l16 * 4);
-    uint2 pk;
-    pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v.x), static_cast<__bf16>(v.y)});
-    pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v.z), static_cast<__bf16>(v.w)});
-    *reinterpret_cast<uint2*>(Mb + r * 64 + l16 * 4) = pk;
-    float s = v.x * v.x;
-    s = __builtin_fmaf(v.y, v.y, s);
-    s = __builtin_fmaf(v.z, v.z, s);
-    s = __builtin_fmaf(v.w, v.w, s);
-    s = row16_sum(s);
-    if (l16 == 0) {
-      if (out) out[r] = s;
-      if (zero_rows) zero_rows[r] = 0;
-      const uint32_t bits = __float_as_uint(s);
-      mine = bits > mine ? bits : mine;
+  for (int64_t r0 = static_cast<int64_t>(blk) * per + (threadIdx.x >> 4); r0 < rows; r0 += 4 * step) {
+    float4 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t r = r0 + q * step;
+      v[q] = r < rows ? *reinterpret_cast<const float4*>(M + r * 64 + l16 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t r = r0 + q * step;
+      float s = v[q].x * v[q].x;
+      s = __builtin_fmaf(v[q].y, v[q].y, s);
+      s = __builtin_fmaf(v[q].z, v[q].z, s);
+      s = __builtin_fmaf(v[q].w, v[q].w, s);
+      s = row16_sum(s);  // (every lane takes part: no divergence around the cross-lane sum)
+      if (r < rows) {
+        uint2 pk;
+        pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v[q].x), static_cast<__bf16>(v[q].y)});
+        pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v[q].z), static_cast<__bf16>(v[q].w)});
+        *reinterpret_cast<uint2*>(Mb + r * 64 + l16 * 4) = pk;
+        if (l16 == 0) {
+          if (is_u) {
+            u2[r] = s;
+            zero_rows[r] = 0;
+          }
+          const uint32_t bits = __float_as_uint(s);
+          mine = bits > mine ? bits : mine;
+        }
+      }
     }
   }
-  if (maxbits) {
+  if (!is_u) {  // uniform per workgroup
     if (l16 == 0 && mine) atomicMax(&bmax, mine);
     __syncthreads();
-    if (threadIdx.x == 0 && bmax) atomicMax(maxbits, bmax);
+    if (threadIdx.x == 0) e2part[blk] = bmax;
   }
 }
 
@@ -1368,7 +1404,7 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16) {
   L.off_thr = align256(L.off_u2 + B * 4);
   L.off_eps = align256(L.off_thr + B * 4);
   L.off_e2max = align256(L.off_eps + B * 4);
-  L.off_ub = align256(L.off_e2max + 256);        // bf16 copies of U and E (64-column inputs only)
+  L.off_ub = align256(L.off_e2max + kNormGrid * 4);        // bf16 copies of U and E (64-column inputs only)
   L.off_eb = align256(L.off_ub + B * 128);
   L.off_cnt = align256(L.off_eb + N * 128);
   L.off_cand = align256(L.off_cnt + B * (128 + 1) * 4);  // f32 path: kSeg + 1 counters per row; bf16 path: <= 128 strips + 1
@@ -1450,17 +1486,17 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
       sl.ovf_cnt = ta.cnt + B * 128;                    // [B]
       sl.cand = ta.cand;                                // [B, ns2 * cap <= kStripSlots]
       sl.ovf = ta.cand + B * kStripSlots;               // [B, kOvfCap]
-      const int64_t gu = grid_for(B, kBlock / 16), ge = grid_for(N, kBlock / 16);
-      hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(gu < kNormGrid ? gu : kNormGrid)), dim3(kBlock), 0, st, U, B, Ub, u2,
-                         static_cast<uint32_t*>(nullptr), e2max, sl.ovf_cnt);
-      hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(ge < kNormGrid ? ge : kNormGrid)), dim3(kBlock), 0, st, E, N, Eb,
-                         static_cast<float*>(nullptr), e2max, static_cast<uint32_t*>(nullptr), static_cast<int*>(nullptr));
+      int64_t gu = grid_for(B, kBlock / 16), ge = grid_for(N, kBlock / 16);
+      if (gu > kNormGrid) gu = kNormGrid;
+      if (ge > kNormGrid) ge = kNormGrid;
+      hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(gu + ge)), dim3(kBlock), 0, st, U, B, Ub, u2, sl.ovf_cnt,
+                         static_cast<int>(gu), E, N, Eb, e2max);
       if ((rc = check_launch())) return rc;
       const size_t lds_ops = static_cast<size_t>(BM + BN) * BLD * sizeof(__bf16);
       const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
       hipLaunchKernelGGL(bf16_tile_kernel<EPI_TILEMAX>, dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
                          Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
-      Bf16Bound bb{u2, e2max, thr, eps};
+      Bf16Bound bb{u2, e2max, static_cast<int>(ge), thr, eps};
       if (L.NT <= 256)
         hipLaunchKernelGGL(tile_kth_wave_kernel, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
                            static_cast<int>(L.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),

@@ -59,7 +59,8 @@ def test_gpu_rec_topk_matches_reference(golden, oracle, dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("S,lens,k", [(5, (0, 40), 10), (64, (900, 1200), 20), (3, (5000, 30000), 256), (300, (1, 8), 17)])
+@pytest.mark.parametrize("S,lens,k", [(5, (0, 40), 10), (64, (900, 1200), 20), (3, (5000, 30000), 256), (300, (1, 8), 17),
+                                      (9, (2040, 2056), 50), (7, (1500, 2048), 256)])
 def test_gpu_segment_topk_vs_oracle(S, lens, k, oracle, dev):
     from mi_oov import ops
     rng = np.random.default_rng(S + k)
