@@ -31,6 +31,8 @@ _SIGNATURES = {
     "mi_oov_lsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_score_topk_excl_workspace": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_oov_score_topk_excl": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    "mi_oov_score_topk_masked_workspace": (_i64, [_i64, _i64, _i64, _i64]),
+    "mi_oov_score_topk_masked": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_segment_topk": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_topk_hits": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_slsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -337,6 +337,14 @@ struct DotKeys {  // same fmaf chain as the MFMA kernel: increasing d from +0, d
   }
 };
 
+struct MaskedDotKeys {  // DotKeys with a row of exclusion bits: an excluded column gets key 0 (no real key is 0)
+  DotKeys dot;
+  const uint64_t* mrow;
+  __device__ __forceinline__ uint32_t operator()(int64_t c) const {
+    return ((mrow[c >> 6] >> (c & 63)) & 1ull) ? 0u : dot(c);
+  }
+};
+
 __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot, int& total) {
   // exclusive prefix of v over the 256 threads of the block (shuffles + LDS)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -882,6 +890,18 @@ __global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __res
   }
 }
 
+// exclusion bitmap of a user batch from the CSR of excluded columns (histories): one workgroup per row; the words were
+// zeroed by a memset on the same stream.  Columns outside [0, N) are ignored, as the oracle does.
+__global__ __launch_bounds__(kBlock) void mask_build_kernel(const int64_t* __restrict__ excl_ptr, const int64_t* __restrict__ excl_cols,
+                                                            int64_t B, int64_t N, unsigned long long* __restrict__ mask, int64_t words) {
+  const int64_t row = blockIdx.x;
+  if (row >= B) return;
+  for (int64_t q = excl_ptr[row] + threadIdx.x; q < excl_ptr[row + 1]; q += kBlock) {
+    const int64_t c = excl_cols[q];
+    if (c >= 0 && c < N) atomicOr(&mask[row * words + (c >> 6)], 1ull << (c & 63));
+  }
+}
+
 // Candidate lists of the bf16 filter pass.  Strip s of a 128-row block is walked by exactly one workgroup, so the list
 // (row, s) has ONE writer: its counter lives in that workgroup's LDS and the entries go out as plain stores -- the
 // filter pass does no global atomics (one per candidate, ~0.85 M per launch, cost it 50 us).  Lists that run over
@@ -893,6 +913,8 @@ struct StripLists {
   int* ovf_cnt;    // [B] zeroed per launch
   uint64_t* ovf;   // [B, kOvfCap]
   int ns, cap;
+  const uint64_t* mask;  // [B, mask_words] bit c of a row = column c is excluded (the user's history); null: no exclusions
+  int64_t mask_words;
 };
 
 // A workgroup keeps its 128 user rows in LDS and walks a strip of column blocks (blocks s, s + ns, s + 2 ns, ...: a
@@ -914,7 +936,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // (pass 1 runs ~3 workgroups per CU anyway -- 800 working workgroups -- and at 128 registers it spills: the reload's
 // s_waitcnt vmcnt(0) then also waits for the block prefetch)
-template <int EPI>
+template <int EPI, bool MASKED>
 __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_kernel(const __bf16* __restrict__ Ub, int64_t B,
                                                              const __bf16* __restrict__ Eb, int64_t N,
                                                              const float* __restrict__ thr, TopkArgs ta, StripLists sl,
@@ -975,6 +997,15 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
     asm volatile("" : "+v"(lrow0), "+v"(lcol0));
     f32x16 acc[2][2];
 
+    uint64_t mw[2] = {0ull, 0ull};  // MASKED pass 1: the exclusion bits of this lane's two user rows for its 64-column tile
+    if constexpr (EPI == EPI_TILEMAX && MASKED) {
+      const int64_t tw = (n0 >> 6) + wn;  // the tile's word
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int lr = wm * 64 + m * 32 + i32;
+        if (lr < rows_here && tw < sl.mask_words) mw[m] = sl.mask[(b0 + lr) * sl.mask_words + tw];
+      }
+    }
     if constexpr (EPI == EPI_TILEMAX) {
       // pass 1: maxima of the 64-column tiles.  The product is taken transposed (E block x U^T): a lane then holds 16
       // COLUMNS of one user row per accumulator, so the tile maximum is 32 in-lane max3 operations + one exchange with
@@ -1010,15 +1041,26 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
         uint32_t amax = 0u;
         bool any = false;
         if (all_cols) {
+          const uint64_t wsh = mw[m] >> (4 * hh);  // bit n 32 + (r & 3) + 8 (r >> 2) = this lane's column (n, r)
 #pragma unroll
-          for (int n = 0; n < 2; ++n)
+          for (int n = 0; n < 2; ++n) {
+            const uint32_t wn32 = static_cast<uint32_t>(wsh >> (32 * n));
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-              best = __builtin_fmaxf(__builtin_fmaxf(best, acc[m][n][r]), acc[m][n][r + 1]);
-              const uint32_t a0 = __float_as_uint(acc[m][n][r]) & 0x7FFFFFFFu, a1 = __float_as_uint(acc[m][n][r + 1]) & 0x7FFFFFFFu;
+              float v0 = acc[m][n][r], v1 = acc[m][n][r + 1];
+              if constexpr (MASKED) {  // an excluded column counts as -inf: sign-extended bit, bit-field insert
+                const int b0_ = (r & 3) + 8 * (r >> 2), b1_ = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
+                const uint32_t e0 = static_cast<uint32_t>(static_cast<int>(wn32 << (31 - b0_)) >> 31);
+                const uint32_t e1 = static_cast<uint32_t>(static_cast<int>(wn32 << (31 - b1_)) >> 31);
+                v0 = __uint_as_float((__float_as_uint(v0) & ~e0) | (0xFF800000u & e0));
+                v1 = __uint_as_float((__float_as_uint(v1) & ~e1) | (0xFF800000u & e1));
+              }
+              best = __builtin_fmaxf(__builtin_fmaxf(best, v0), v1);
+              const uint32_t a0 = __float_as_uint(v0) & 0x7FFFFFFFu, a1 = __float_as_uint(v1) & 0x7FFFFFFFu;
               amax = a0 > amax ? a0 : amax;
               amax = a1 > amax ? a1 : amax;
             }
+          }
           any = true;
         } else {
           uint32_t cbase = static_cast<uint32_t>(c_lo) + 4 * hh;
@@ -1028,7 +1070,8 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const uint32_t col = cbase + n * 32 + (r & 3) + 8 * (r >> 2);
-              if (col < n_cols && col >= skip) {
+              const bool excluded = MASKED && ((mw[m] >> (col & 63u)) & 1ull);
+              if (col < n_cols && col >= skip && !excluded) {
                 best = __builtin_fmaxf(best, acc[m][n][r]);
                 const uint32_t a0 = __float_as_uint(acc[m][n][r]) & 0x7FFFFFFFu;
                 amax = a0 > amax ? a0 : amax;
@@ -1078,7 +1121,11 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
       const int row_stride = sl.ns * sl.cap;
       auto emit = [&](int lrow, uint32_t lcol, float v) {
         const uint32_t col = static_cast<uint32_t>(n0) + lcol;
-        if (lrow < rows_here && col < n_cols && col >= skip) {
+        bool allowed = lrow < rows_here && col < n_cols && col >= skip;
+        if constexpr (MASKED) {
+          if (allowed) allowed = !((sl.mask[(b0 + lrow) * sl.mask_words + (col >> 6)] >> (col & 63u)) & 1ull);
+        }
+        if (allowed) {
           const uint64_t packed = (static_cast<uint64_t>(order_key(v)) << 32) | (0xFFFFFFFFu - col);
           const int p = atomicAdd(&rowcnt[lrow], 1);
           if (p < sl.cap) {
@@ -1303,7 +1350,20 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
   for (int w = 0; w < kFinRows; ++w) {
     if (!ovf_row[w]) continue;
     const int64_t r = static_cast<int64_t>(blockIdx.x) * kFinRows + w;
-    select_topk_row(DotKeys{U + r * D, E, D}, N, k, n_skip_low, vals + r * k, idx + r * k);
+    if (sl.mask) {  // excluded columns rank below every real key and are blanked afterwards (never returned)
+      const uint64_t* mrow = sl.mask + r * sl.mask_words;
+      select_topk_row(MaskedDotKeys{DotKeys{U + r * D, E, D}, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
+      __syncthreads();
+      for (int t = threadIdx.x; t < k; t += kBlock) {
+        const int64_t c = idx[r * k + t];
+        if (c >= 0 && ((mrow[c >> 6] >> (c & 63)) & 1ull)) {
+          idx[r * k + t] = -1;
+          vals[r * k + t] = -__builtin_inff();
+        }
+      }
+    } else {
+      select_topk_row(DotKeys{U + r * D, E, D}, N, k, n_skip_low, vals + r * k, idx + r * k);
+    }
     __syncthreads();
   }
 }
@@ -1423,8 +1483,14 @@ extern "C" int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k) 
   return topk_chunk_rows(B, N) * N * static_cast<int64_t>(sizeof(float));
 }
 
-extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
-                                 int64_t n_skip_low, float* vals, int64_t* idx, void* workspace, void* stream) {
+// The bf16 fused path can take per-row exclusions (a bitmap built from the CSR); `mask` is then B x ceil(N / 64) words.
+static bool masked_topk_supported(int64_t B, int64_t N, int64_t D, int64_t k) {
+  return B > 0 && N > 0 && N < (1LL << 32) && D == 64 && k > 0 && use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535;
+}
+
+static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k, int64_t n_skip_low,
+                           const int64_t* excl_ptr, const int64_t* excl_cols, unsigned long long* mask, float* vals,
+                           int64_t* idx, void* workspace, void* stream) {
   if (B < 0 || N <= 0 || D <= 0 || k <= 0 || n_skip_low < 0 || N >= (1LL << 32)) return MI_OOV_ERR_SHAPE;
   if (B == 0) return MI_OOV_OK;
   if (!U || !E || !vals || !idx || !workspace) return MI_OOV_ERR_NULL;
@@ -1433,7 +1499,8 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
   if (use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535) {
     const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
     static const bool bf16_path = [] { const char* e = getenv("MI_OOV_TOPK_BF16"); return !(e && e[0] == '0'); }();
-    const bool use_bf16 = bf16_path && D == 64 && vec;
+    const bool use_bf16 = (bf16_path || mask) && D == 64 && vec;
+    if (mask && !use_bf16) return MI_OOV_ERR_ALIGN;  // (the masked entry point checked the shape; only alignment is left)
     const FusedLayout L = fused_layout(B, N, k, use_bf16);
     char* ws = static_cast<char*>(workspace);
     TopkArgs ta{};
@@ -1486,6 +1553,15 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
       sl.ovf_cnt = ta.cnt + B * 128;                    // [B]
       sl.cand = ta.cand;                                // [B, ns2 * cap <= kStripSlots]
       sl.ovf = ta.cand + B * kStripSlots;               // [B, kOvfCap]
+      if (mask) {
+        sl.mask = reinterpret_cast<const uint64_t*>(mask);
+        sl.mask_words = (N + 63) / 64;
+        if (hipMemsetAsync(mask, 0, static_cast<size_t>(B) * sl.mask_words * 8, st) != hipSuccess) {
+          check_launch();
+          return MI_OOV_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(mask_build_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, excl_ptr, excl_cols, B, N, mask, sl.mask_words);
+      }
       int64_t gu = grid_for(B, kBlock / 16), ge = grid_for(N, kBlock / 16);
       if (gu > kNormGrid) gu = kNormGrid;
       if (ge > kNormGrid) ge = kNormGrid;
@@ -1494,8 +1570,12 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
       if ((rc = check_launch())) return rc;
       const size_t lds_ops = static_cast<size_t>(BM + BN) * BLD * sizeof(__bf16);
       const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
-      hipLaunchKernelGGL(bf16_tile_kernel<EPI_TILEMAX>, dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
-                         Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
+      if (mask)
+        hipLaunchKernelGGL((bf16_tile_kernel<EPI_TILEMAX, true>), dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
+                           Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
+      else
+        hipLaunchKernelGGL((bf16_tile_kernel<EPI_TILEMAX, false>), dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
+                           Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
       Bf16Bound bb{u2, e2max, static_cast<int>(ge), thr, eps};
       if (L.NT <= 256)
         hipLaunchKernelGGL(tile_kth_wave_kernel, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
@@ -1505,8 +1585,12 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
         hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, L.NT,
                            static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf), bb);
       if ((rc = check_launch())) return rc;
-      hipLaunchKernelGGL(bf16_tile_kernel<EPI_FILTER>, dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
-                         Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
+      if (mask)
+        hipLaunchKernelGGL((bf16_tile_kernel<EPI_FILTER, true>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
+                           Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
+      else
+        hipLaunchKernelGGL((bf16_tile_kernel<EPI_FILTER, false>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
+                           Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
       if ((rc = check_launch())) return rc;
       hipLaunchKernelGGL(topk_finalize_exact_kernel, dim3(static_cast<unsigned>((B + kFinRows - 1) / kFinRows)), dim3(kBlock),
                          static_cast<size_t>(kFinRows) * (sl.ns * sl.cap + kOvfCap) * 8, st, U, E, B, N, D,
@@ -1544,6 +1628,30 @@ extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int6
     if (int rc = check_launch()) return rc;
   }
   return MI_OOV_OK;
+}
+
+extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                                 int64_t n_skip_low, float* vals, int64_t* idx, void* workspace, void* stream) {
+  return score_topk_impl(U, B, E, N, D, k, n_skip_low, nullptr, nullptr, nullptr, vals, idx, workspace, stream);
+}
+
+// Exclusions of any length on the fused path: the histories become a bitmap (B x ceil(N / 64) words) that pass 1 applies
+// to the tile maxima (so tau is the k-th best ALLOWED tile maximum and the candidate count does not grow with the
+// histories), pass 2 applies when it emits a candidate, and the exact fallback applies to its keys.
+extern "C" int64_t mi_oov_score_topk_masked_workspace(int64_t B, int64_t N, int64_t D, int64_t k) {
+  if (!masked_topk_supported(B, N, D, k)) return 0;
+  return align256(mi_oov_score_topk_workspace(B, N, k)) + align256(B * ((N + 63) / 64) * 8);
+}
+
+extern "C" int mi_oov_score_topk_masked(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                                        int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols, float* vals,
+                                        int64_t* idx, void* workspace, void* stream) {
+  if (B == 0 && N > 0 && D > 0 && k > 0) return MI_OOV_OK;
+  if (!masked_topk_supported(B, N, D, k) || n_skip_low < 0) return MI_OOV_ERR_SHAPE;
+  if (!U || !E || !excl_ptr || !excl_cols || !vals || !idx || !workspace) return MI_OOV_ERR_NULL;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_OOV_ERR_ALIGN;
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + align256(mi_oov_score_topk_workspace(B, N, k)));
+  return score_topk_impl(U, B, E, N, D, k, n_skip_low, excl_ptr, excl_cols, mask, vals, idx, workspace, stream);
 }
 
 // ---- full-sort evaluation with per-user exclusions (history masks) ---------------------------------------------

@@ -641,11 +641,17 @@ def topk_hits(idx, pos_ptr, pos_cols):
     return out
 
 
+_MASKED_TOPK_MAX_BYTES = 4 << 30  # workspace bound for the bitmap path (B x N / 8 bytes of mask + the fused lists)
+_USE_MASKED_TOPK = True           # tests flip this to cover the k + h_max path on shapes the masked kernel takes
+
+
 def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
     """top-k of U @ E.T per user with scores[:, :n_skip_low] and the user's excluded columns (history) treated as
     -inf (InductiveEvaluator.eval_batch, R/inductive/evaluator.py:92-95), without materialising the scores.
-    excl_ptr i64[B+1], excl_cols i64[nnz] ascending within a row.  Users are processed in groups such that
-    k + (longest history of the group) <= 256; users with longer histories go through the materialising path."""
+    excl_ptr i64[B+1], excl_cols i64[nnz] ascending within a row.  64-column tables take the masked fused kernel
+    (`mi_oov_score_topk_masked`: any history length, no host synchronisation).  Other shapes: users are processed
+    in groups such that k + (longest history of the group) <= 256 (`mi_oov_score_topk_excl`); users with longer
+    histories go through the materialising path."""
     U, E = _f32(U, "U"), _f32(E, "E")
     excl_ptr, excl_cols = _ids(excl_ptr, "excl_ptr"), _ids(excl_cols, "excl_cols")
     B, N = U.shape[0], E.shape[0]
@@ -653,11 +659,20 @@ def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
     idx = torch.empty((B, k), dtype=torch.int64, device=U.device)
     if B == 0:
         return vals, idx
-    lens = excl_ptr[1:] - excl_ptr[:-1]
-    longest = int(lens.max()) if h_max is None else int(h_max)
     if excl_cols.numel() == 0:
         excl_cols = torch.zeros((1,), dtype=torch.int64, device=U.device)
     lib = C.lib()
+    # histories of any length, one call, no host sync: exclusion bitmap applied inside the fused kernel (D = 64)
+    need = int(lib.mi_oov_score_topk_masked_workspace(B, N, U.shape[1], k))
+    if _USE_MASKED_TOPK and 0 < need <= _MASKED_TOPK_MAX_BYTES and U.data_ptr() % 16 == 0 and E.data_ptr() % 16 == 0:
+        ws = torch.empty((need,), dtype=torch.uint8, device=U.device)
+        with C.on_device(U):
+            rc = lib.mi_oov_score_topk_masked(C.ptr(U), B, C.ptr(E), N, U.shape[1], k, int(n_skip_low), C.ptr(excl_ptr),
+                                              C.ptr(excl_cols), C.ptr(vals), C.ptr(idx), C.ptr(ws), C.stream_of(U))
+        C.check(rc, "mi_oov_score_topk_masked")
+        return vals, idx
+    lens = excl_ptr[1:] - excl_ptr[:-1]
+    longest = int(lens.max()) if h_max is None else int(h_max)
     if k + longest <= 256:
         ws = torch.empty((max(int(lib.mi_oov_score_topk_excl_workspace(B, N, k, longest)), 16),), dtype=torch.uint8, device=U.device)
         with C.on_device(U):

@@ -273,6 +273,18 @@ int mi_oov_score_topk_excl(const float* U, int64_t B, const float* E, int64_t N,
                            int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols, int64_t h_max,
                            float* vals, int64_t* idx, void* workspace, void* stream);
 
+/* The same result with exclusion lists of ANY length, still without a [B,N] matrix: the CSR becomes a bitmap of
+ * B x ceil(N/64) words inside the workspace; the first pass of the fused kernel leaves excluded columns out of its tile
+ * maxima (so its bound is the k-th best ALLOWED one and the candidate count does not grow with the histories), the
+ * second pass drops them when it emits a candidate.  D = 64 rows, 16-byte aligned, k <= 256, N >= 128 k (the fused bf16
+ * path); the workspace query returns 0 for shapes it does not take (use mi_oov_score_topk_excl or materialise).
+ * excl_cols need not be sorted; entries outside [0, N) are ignored.
+ *   workspace: mi_oov_score_topk_masked_workspace(B, N, D, k) bytes, 16-byte aligned.                            */
+int64_t mi_oov_score_topk_masked_workspace(int64_t B, int64_t N, int64_t D, int64_t k);
+int mi_oov_score_topk_masked(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                             int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols,
+                             float* vals, int64_t* idx, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

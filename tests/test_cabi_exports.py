@@ -61,6 +61,13 @@ def test_argument_validation_of_the_widened_entry_points(lib):
     assert lib.mi_oov_score_topk(None, 4, None, 0, 64, 10, 0, None, None, None, None) == -2  # empty catalogue
     assert lib.mi_oov_score_topk(None, 4, None, 100, 64, 10, 0, None, None, None, None) == -1
     assert lib.mi_oov_score_topk_workspace(4096, 50_000, 20) > 0
+    ws = lib.mi_oov_score_topk_masked_workspace(4096, 50_000, 64, 20)                        # lists + 4096 x 782 mask words
+    assert ws >= lib.mi_oov_score_topk_workspace(4096, 50_000, 20) + 4096 * 782 * 8
+    assert lib.mi_oov_score_topk_masked_workspace(4096, 50_000, 32, 20) == 0                 # D != 64: not taken
+    assert lib.mi_oov_score_topk_masked_workspace(4096, 1000, 64, 20) == 0                   # catalogue < 128 k
+    assert lib.mi_oov_score_topk_masked(None, 4, None, 50_000, 32, 20, 0, None, None, None, None, None, None) == -2
+    assert lib.mi_oov_score_topk_masked(None, 4, None, 50_000, 64, 20, 0, None, None, None, None, None, None) == -1
+    assert lib.mi_oov_score_topk_masked(None, 0, None, 50_000, 64, 20, 0, None, None, None, None, None, None) == 0
     assert lib.mi_oov_linear_act(None, 4, 16, None, None, 8, 7, None, None) in (-2, -3)       # unknown activation
     assert lib.mi_oov_last_hip_error() == 0                                                  # nothing touched the GPU
 

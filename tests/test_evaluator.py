@@ -110,11 +110,14 @@ def test_gpu_collector_dedups_and_slices(dev):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("masked", [True, False])
 @pytest.mark.parametrize("B,N,k,hmax", [(70, 3000, 10, 40), (9, 1300, 5, 0), (130, 4159, 20, 200), (40, 2500, 10, 600)])
-def test_gpu_full_sort_topk_with_history_vs_oracle(B, N, k, hmax, oracle, dev):
-    """Full-sort evaluation: column 0 and every user's history masked (evaluator.py:92-95) inside the fused top-k;
+def test_gpu_full_sort_topk_with_history_vs_oracle(B, N, k, hmax, masked, oracle, dev, monkeypatch):
+    """Full-sort evaluation: column 0 and every user's history masked (evaluator.py:92-95) inside the fused top-k.
+    masked: the exclusion bitmap inside the kernel (any history length); otherwise top-(k + longest history), where
     histories longer than 256 - k fall back to materialised scores for those users."""
     from mi_oov import ops
+    monkeypatch.setattr(ops, "_USE_MASKED_TOPK", masked)
     rng = np.random.default_rng(B + N)
     U = rng.standard_normal((B, 64), dtype=np.float32)
     E = rng.standard_normal((N, 64), dtype=np.float32)
@@ -137,6 +140,44 @@ def test_gpu_full_sort_topk_with_history_vs_oracle(B, N, k, hmax, oracle, dev):
     assert np.array_equal(v.cpu().numpy(), ov)
     for b in range(B):  # nothing excluded is ever recommended
         assert not np.intersect1d(i[b], cols[ptr[b]:ptr[b + 1]]).size and 0 not in i[b]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["heavy", "nearly_all", "unsorted_dups", "wide"])
+def test_gpu_masked_topk_edge_cases(case, oracle, dev):
+    """mi_oov_score_topk_masked: histories far beyond 256 entries that hold every top item; rows with fewer than k
+    allowed columns (missing entries are (-inf, -1)); unsorted lists with duplicates and out-of-range columns; a batch
+    that spans several row blocks and a catalogue that is not a multiple of 64."""
+    from mi_oov import ops
+    rng = np.random.default_rng(len(case))
+    B, N, k = 48, 6000, 20
+    if case == "wide":
+        B, N, k = 300, 20011, 50
+    U = rng.standard_normal((B, 64), dtype=np.float32)
+    E = rng.standard_normal((N, 64), dtype=np.float32)
+    _, best = oracle.score_topk(U, E, 700, 1)
+    lists = []
+    for b in range(B):
+        if case == "heavy":          # the 700 best columns of the user are its history
+            c = best[b]
+        elif case == "nearly_all":   # only k - 3 + (b % 7) columns stay allowed
+            keep = rng.choice(np.arange(1, N), size=k - 3 + (b % 7), replace=False)
+            c = np.setdiff1d(np.arange(0, N), keep)
+        elif case == "unsorted_dups":
+            c = np.concatenate((best[b][:40], best[b][:17], [-5, N, N + 99, 2 ** 40]))
+            rng.shuffle(c)
+        else:
+            c = best[b][: int(rng.integers(0, 500))]
+        lists.append(np.asarray(c, np.int64))
+    ptr = np.concatenate(([0], np.cumsum([len(c) for c in lists]))).astype(np.int64)
+    cols = np.concatenate(lists + [np.zeros(0, np.int64)])
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    from mi_oov import _cabi
+    assert _cabi.lib().mi_oov_score_topk_masked_workspace(B, N, 64, k) > 0   # the shape is one the masked kernel takes
+    v, i = ops.score_topk_excl(T(U), T(E), k, T(ptr), T(cols), n_skip_low=1)
+    ov, oi = oracle.score_topk_excl(U, E, k, ptr, cols, 1)
+    assert np.array_equal(i.cpu().numpy(), oi)
+    assert np.array_equal(v.cpu().numpy(), ov)
 
 
 def test_oracle_full_sort_rec_topk_matches_reference(golden, oracle):

@@ -116,6 +116,18 @@ def main():
         "scatter_add_rows into 10M x 64 (gather backward)": (lambda i: ops.scatter_add_rows(ids[i], users[i % 8], N, out=gtab), B, 8 + 12 * D, 0),
         "segment_topk 4096 users x 1506 candidates k=20": (lambda i: ops.segment_topk(seg_scores, seg_cols, seg_ptr, 20), seg_scores.numel(), 12, 0),
     }
+    if args.only.startswith("score_topk_excl"):  # full-sort evaluation: histories masked (bitmap in the kernel vs top-(k + h_max))
+        gh = torch.Generator(device=dev).manual_seed(5)
+        for hmean, hmax in ((60, 120), (100, 230), (100, 1500)):
+            lens = torch.randint(0, 2 * hmean, (Bs,), generator=gh, device=dev)
+            lens[0] = hmax
+            ptr = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(lens, 0)))
+            colsx = torch.randint(1, Ns, (int(ptr[-1]),), generator=gh, device=dev)
+            for masked in (True, False):
+                def run(i, ptr=ptr, colsx=colsx, masked=masked):
+                    ops._USE_MASKED_TOPK = masked
+                    return ops.score_topk_excl(U, E, 20, ptr, colsx, 1)
+                cases[f"score_topk_excl k=20 B=4096 N=50000 hist~{hmean} max {hmax} {'masked' if masked else 'k+h_max'}"] = (run, Bs * Ns, 0, 2 * D)
     if args.only.startswith("score_topk sweep"):  # no cliffs over k, user-batch and catalogue sizes
         for (b_, n_, k_) in ((4096, 50000, 1), (4096, 50000, 5), (4096, 50000, 50), (4096, 50000, 120), (4096, 50000, 256),
                              (512, 50000, 20), (65536, 50000, 20), (4096, 500000, 20), (4096, 10000, 20)):
