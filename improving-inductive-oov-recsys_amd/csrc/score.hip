@@ -546,23 +546,26 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
   }
 }
 
-// the same for NT <= 256, one wave per row (4 rows per workgroup): the tile maxima sit in registers and the k-th best
-// is the largest T with at least k keys >= T, found bit by bit (32 ballot steps; the workgroup-per-row kernel above
-// takes 12.5 us for 4096 rows of 98 keys, nearly all of it launch and barrier latency)
+// the same for NT <= 1024, one wave per row (4 rows per workgroup): the tile maxima sit in registers (up to 16 per lane)
+// and the k-th best is the largest T with at least k keys >= T, found bit by bit (32 ballot steps).  The
+// workgroup-per-row kernel above ranks by counting, NT^2 compares per row: 12.5 us for 4096 rows of 98 keys, nearly all
+// of it launch and barrier latency, and 85 us at 262 keys.
+constexpr int kKthRegs = 16;
 __global__ __launch_bounds__(kBlock) void tile_kth_wave_kernel(const uint32_t* __restrict__ tilemax, int64_t B, int NT, int k,
                                                                uint32_t* __restrict__ tau, float* __restrict__ tauf, Bf16Bound bb) {
   const int lane = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= B) return;
-  uint32_t key[4];
+  uint32_t key[kKthRegs];
 #pragma unroll
-  for (int q = 0; q < 4; ++q) key[q] = (q * 64 + lane < NT) ? tilemax[row * NT + q * 64 + lane] : 0u;
+  for (int q = 0; q < kKthRegs; ++q) key[q] = (q * 64 + lane < NT) ? tilemax[row * NT + q * 64 + lane] : 0u;
   uint32_t T = 0u;  // (fewer than k keys > 0: T stays 0 = "no bound", as the rank-counting kernel returns)
   for (int bit = 31; bit >= 0; --bit) {
     const uint32_t c = T | (1u << bit);
     int have = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) have += __popcll(__ballot(key[q] >= c));
+    for (int q = 0; q < kKthRegs; ++q)
+      if (q * 64 < NT) have += __popcll(__ballot(key[q] >= c));  // (uniform skip of the unused registers)
     if (have >= k) T = c;
   }
   uint32_t e2 = 0u;
@@ -1449,7 +1452,7 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16) {
   // The bf16 path's passes are cheap next to its per-candidate work: stride 4-5 is its optimum (k = 20, 4096 x 50000:
   // 8 -> 124 us, 4-5 -> 106 us, 3 -> 153 us); the f32 path pays a full-rate GEMM for pass 1 and keeps 8.
   static const int64_t env_stride = [] { const char* e = getenv("MI_OOV_TOPK_STRIDE"); return e ? atoll(e) : 0LL; }();
-  int64_t stride = env_stride > 0 ? env_stride : (bf16 ? 4 : 8);
+  int64_t stride = env_stride > 0 ? env_stride : (bf16 ? (k <= 32 ? 4 : 2) : 8);  // (k = 50: 2 -> 130 us, 3 -> 135 us, 4 -> 151 us)
   if (stride > 256 / k) stride = 256 / k;  // ~k * stride candidates per row: a quarter of the 1024 slots
   if (stride > nblk / k) stride = nblk / k;  // sampled 64-column tiles: 2 * nblk / stride >= 2k
   if (stride < 1) stride = 1;
@@ -1577,7 +1580,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
         hipLaunchKernelGGL((bf16_tile_kernel<EPI_TILEMAX, false>), dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
                            Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
       Bf16Bound bb{u2, e2max, static_cast<int>(ge), thr, eps};
-      if (L.NT <= 256)
+      if (L.NT <= 64 * kKthRegs)
         hipLaunchKernelGGL(tile_kth_wave_kernel, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
                            static_cast<int>(L.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
                            reinterpret_cast<float*>(ws + L.off_tauf), bb);

@@ -591,18 +591,28 @@ def hash_net_forward(net, x):
     return x
 
 
+_TOPK_WORKSPACE_MAX_BYTES = 2 << 30
+
+
 def score_topk(U, E, k, n_skip_low=0):
     """Per-row top-k of U @ E.T without returning the [B,N] matrix.  Returns (vals, idx)."""
     U, E = _f32(U, "U"), _f32(E, "E")
     B, N, D = U.shape[0], E.shape[0], U.shape[1]
     vals = torch.empty((B, k), dtype=torch.float32, device=U.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=U.device)
-    nbytes = C.lib().mi_oov_score_topk_workspace(B, N, k)
-    ws = torch.empty((max(1, nbytes // 4),), dtype=torch.float32, device=U.device)
+    lib = C.lib()
+    # the fused path's workspace grows with B x N (tile maxima, candidate lists): a 10 M-row catalogue is ~165 KB per
+    # user, so big batches go through in chunks of users (multiples of the 128-row tile)
+    rows = B
+    while rows > 128 and lib.mi_oov_score_topk_workspace(rows, N, k) > _TOPK_WORKSPACE_MAX_BYTES:
+        rows = max(128, (rows // 2 + 127) // 128 * 128)
+    ws = torch.empty((max(16, int(lib.mi_oov_score_topk_workspace(min(rows, B), N, k))),), dtype=torch.uint8, device=U.device)
     with C.on_device(U):
-        rc = C.lib().mi_oov_score_topk(C.ptr(U), B, C.ptr(E), N, D, k, n_skip_low, C.ptr(vals), C.ptr(idx),
-                                       C.ptr(ws), C.stream_of(U))
-    C.check(rc, "mi_oov_score_topk")
+        for b0 in range(0, max(B, 1), max(rows, 1)):
+            nb = min(rows, B - b0)
+            rc = lib.mi_oov_score_topk(C.ptr(U[b0:b0 + nb]), nb, C.ptr(E), N, D, k, n_skip_low, C.ptr(vals[b0:b0 + nb]),
+                                       C.ptr(idx[b0:b0 + nb]), C.ptr(ws), C.stream_of(U))
+            C.check(rc, "mi_oov_score_topk")
     return vals, idx
 
 

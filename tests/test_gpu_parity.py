@@ -338,6 +338,18 @@ def test_fused_topk_bf16_lists(case, oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
+def test_score_topk_user_chunks(oracle, ops, dev, monkeypatch):
+    """ops.score_topk bounds its workspace by going through big user batches in chunks (multiples of 128 rows)."""
+    rng = np.random.default_rng(77)
+    U = rng.standard_normal((700, 64), dtype=np.float32)
+    E = rng.standard_normal((9000, 64), dtype=np.float32)
+    monkeypatch.setattr(ops, "_TOPK_WORKSPACE_MAX_BYTES", 3 << 20)   # 700 rows need ~9 MB: three chunks
+    vals, idx = ops.score_topk(T(U, dev), T(E, dev), 12, 1)
+    o_vals, o_idx = oracle.score_topk(U, E, 12, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    assert bits_equal(vals.cpu().numpy(), o_vals)
+
+
 def test_gather_splice_vs_oracle(oracle, ops, dev):
     rng = np.random.default_rng(11)
     for D in (64, 1, 50, 200):
