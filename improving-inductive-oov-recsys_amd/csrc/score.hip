@@ -337,8 +337,28 @@ struct DotKeys {  // same fmaf chain as the MFMA kernel: increasing d from +0, d
   }
 };
 
-struct MaskedDotKeys {  // DotKeys with a row of exclusion bits: an excluded column gets key 0 (no real key is 0)
-  DotKeys dot;
+struct Dot64Keys {  // DotKeys for 64-float rows, 16-byte aligned: 16 independent float4 loads, then the same chain
+  const float* u;
+  const float* E;
+  __device__ __forceinline__ uint32_t operator()(int64_t c) const {
+    const float4* e4 = reinterpret_cast<const float4*>(E + c * 64);
+    float4 ev[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) ev[q] = e4[q];
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      acc = __builtin_fmaf(u[4 * q + 0], ev[q].x, acc);
+      acc = __builtin_fmaf(u[4 * q + 1], ev[q].y, acc);
+      acc = __builtin_fmaf(u[4 * q + 2], ev[q].z, acc);
+      acc = __builtin_fmaf(u[4 * q + 3], ev[q].w, acc);
+    }
+    return order_key(acc);
+  }
+};
+
+struct MaskedDot64Keys {  // ... with a row of exclusion bits: an excluded column gets key 0 (no real key is 0)
+  Dot64Keys dot;
   const uint64_t* mrow;
   __device__ __forceinline__ uint32_t operator()(int64_t c) const {
     return ((mrow[c >> 6] >> (c & 63)) & 1ull) ? 0u : dot(c);
@@ -1133,7 +1153,9 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
           const int p = atomicAdd(&rowcnt[lrow], 1);
           if (p < sl.cap) {
             cand_wg[lrow * row_stride + p] = packed;
-          } else {
+          } else if (__atomic_load_n(&sl.ovf_cnt[b0 + lrow], __ATOMIC_RELAXED) <= kOvfCap) {
+            // (a row that has already run over is lost to the exact fallback: no point in counting on -- a row of equal
+            // scores would otherwise do N atomics on one word; a stale low read only costs an extra atomic)
             const int p2 = atomicAdd(&sl.ovf_cnt[b0 + lrow], 1);
             if (p2 < kOvfCap) sl.ovf[(b0 + lrow) * kOvfCap + p2] = packed;
           }
@@ -1355,7 +1377,7 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
     const int64_t r = static_cast<int64_t>(blockIdx.x) * kFinRows + w;
     if (sl.mask) {  // excluded columns rank below every real key and are blanked afterwards (never returned)
       const uint64_t* mrow = sl.mask + r * sl.mask_words;
-      select_topk_row(MaskedDotKeys{DotKeys{U + r * D, E, D}, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
+      select_topk_row(MaskedDot64Keys{Dot64Keys{U + r * 64, E}, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
       __syncthreads();
       for (int t = threadIdx.x; t < k; t += kBlock) {
         const int64_t c = idx[r * k + t];
@@ -1365,7 +1387,7 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
         }
       }
     } else {
-      select_topk_row(DotKeys{U + r * D, E, D}, N, k, n_skip_low, vals + r * k, idx + r * k);
+      select_topk_row(Dot64Keys{U + r * 64, E}, N, k, n_skip_low, vals + r * k, idx + r * k);
     }
     __syncthreads();
   }

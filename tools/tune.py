@@ -128,6 +128,9 @@ def main():
                     ops._USE_MASKED_TOPK = masked
                     return ops.score_topk_excl(U, E, 20, ptr, colsx, 1)
                 cases[f"score_topk_excl k=20 B=4096 N=50000 hist~{hmean} max {hmax} {'masked' if masked else 'k+h_max'}"] = (run, Bs * Ns, 0, 2 * D)
+    if args.only.startswith("score_topk degenerate"):  # every row ties everywhere: all rows take the exact fallback
+        Uz = torch.zeros(512, D, device=dev)
+        cases["score_topk degenerate (512 zero user rows, N=50000, k=20: exact fallback for every row)"] = (lambda i: ops.score_topk(Uz, E, 20, 1), 512 * Ns, 0, 2 * D)
     if args.only.startswith("score_topk sweep"):  # no cliffs over k, user-batch and catalogue sizes
         for (b_, n_, k_) in ((4096, 50000, 1), (4096, 50000, 5), (4096, 50000, 50), (4096, 50000, 120), (4096, 50000, 256),
                              (512, 50000, 20), (65536, 50000, 20), (4096, 500000, 20), (4096, 10000, 20)):
