@@ -337,21 +337,24 @@ struct DotKeys {  // same fmaf chain as the MFMA kernel: increasing d from +0, d
   }
 };
 
-struct Dot64Keys {  // DotKeys for 64-float rows, 16-byte aligned: 16 independent float4 loads, then the same chain
-  const float* u;
+struct Dot64Keys {  // DotKeys for 64-float rows, 16-byte aligned: float4 loads, four in flight, then the same chain
+  const float* u;   // (all 16 in flight cost the finalize kernel 135 instead of 81 registers: 13 -> 19 us on the common path)
   const float* E;
   __device__ __forceinline__ uint32_t operator()(int64_t c) const {
     const float4* e4 = reinterpret_cast<const float4*>(E + c * 64);
-    float4 ev[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) ev[q] = e4[q];
     float acc = 0.f;
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+      float4 ev[4];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      acc = __builtin_fmaf(u[4 * q + 0], ev[q].x, acc);
-      acc = __builtin_fmaf(u[4 * q + 1], ev[q].y, acc);
-      acc = __builtin_fmaf(u[4 * q + 2], ev[q].z, acc);
-      acc = __builtin_fmaf(u[4 * q + 3], ev[q].w, acc);
+      for (int q = 0; q < 4; ++q) ev[q] = e4[4 * g + q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        acc = __builtin_fmaf(u[16 * g + 4 * q + 0], ev[q].x, acc);
+        acc = __builtin_fmaf(u[16 * g + 4 * q + 1], ev[q].y, acc);
+        acc = __builtin_fmaf(u[16 * g + 4 * q + 2], ev[q].z, acc);
+        acc = __builtin_fmaf(u[16 * g + 4 * q + 3], ev[q].w, acc);
+      }
     }
     return order_key(acc);
   }
@@ -571,21 +574,22 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
 // workgroup-per-row kernel above ranks by counting, NT^2 compares per row: 12.5 us for 4096 rows of 98 keys, nearly all
 // of it launch and barrier latency, and 85 us at 262 keys.
 constexpr int kKthRegs = 16;
+template <int REGS>  // 64 REGS >= NT (4 for the common shapes: the unused slots of 16 doubled the kernel's time)
 __global__ __launch_bounds__(kBlock) void tile_kth_wave_kernel(const uint32_t* __restrict__ tilemax, int64_t B, int NT, int k,
                                                                uint32_t* __restrict__ tau, float* __restrict__ tauf, Bf16Bound bb) {
   const int lane = threadIdx.x & 63;
   const int64_t row = static_cast<int64_t>(blockIdx.x) * (kBlock / 64) + (threadIdx.x >> 6);
   if (row >= B) return;
-  uint32_t key[kKthRegs];
+  uint32_t key[REGS];
 #pragma unroll
-  for (int q = 0; q < kKthRegs; ++q) key[q] = (q * 64 + lane < NT) ? tilemax[row * NT + q * 64 + lane] : 0u;
+  for (int q = 0; q < REGS; ++q) key[q] = (q * 64 + lane < NT) ? tilemax[row * NT + q * 64 + lane] : 0u;
   uint32_t T = 0u;  // (fewer than k keys > 0: T stays 0 = "no bound", as the rank-counting kernel returns)
   for (int bit = 31; bit >= 0; --bit) {
     const uint32_t c = T | (1u << bit);
     int have = 0;
 #pragma unroll
-    for (int q = 0; q < kKthRegs; ++q)
-      if (q * 64 < NT) have += __popcll(__ballot(key[q] >= c));  // (uniform skip of the unused registers)
+    for (int q = 0; q < REGS; ++q)
+      if (REGS <= 4 || q * 64 < NT) have += __popcll(__ballot(key[q] >= c));  // (16 registers: uniform skip of the unused ones)
     if (have >= k) T = c;
   }
   uint32_t e2 = 0u;
@@ -1602,8 +1606,12 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
         hipLaunchKernelGGL((bf16_tile_kernel<EPI_TILEMAX, false>), dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
                            Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
       Bf16Bound bb{u2, e2max, static_cast<int>(ge), thr, eps};
-      if (L.NT <= 64 * kKthRegs)
-        hipLaunchKernelGGL(tile_kth_wave_kernel, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
+      if (L.NT <= 256)
+        hipLaunchKernelGGL(tile_kth_wave_kernel<4>, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
+                           static_cast<int>(L.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
+                           reinterpret_cast<float*>(ws + L.off_tauf), bb);
+      else if (L.NT <= 64 * kKthRegs)
+        hipLaunchKernelGGL(tile_kth_wave_kernel<kKthRegs>, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
                            static_cast<int>(L.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
                            reinterpret_cast<float*>(ws + L.off_tauf), bb);
       else
