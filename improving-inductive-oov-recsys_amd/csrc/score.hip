@@ -747,7 +747,51 @@ __global__ __launch_bounds__(kBlock) void segment_topk_wave_kernel(const float* 
     }
     return have;
   };
-  if (kk > 0) {
+  // Short cut for kk <= 64 with the keys in registers: the kk-th best of the 64 per-lane maxima is a lower bound T0 of
+  // the kk-th best key (one ballot per step instead of one per register), the keys >= T0 -- kk of them at least, a few
+  // dozen typically -- are compacted in position order and rank-sorted; the best kk of that order are the winners.  More
+  // than 256 such keys (heavy ties): the general search below.
+  bool done = false;
+  if (kk > 0 && kk <= 64 && in_regs) {
+    uint32_t lmax = 0u;
+#pragma unroll
+    for (int q = 0; q < kSegRegs; ++q) lmax = reg[q] > lmax ? reg[q] : lmax;
+    uint32_t T0 = 0u;
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t c = T0 | (1u << bit);
+      if (__popcll(__ballot(lmax >= c)) >= kk) T0 = c;
+    }
+    int m = 0;
+#pragma unroll
+    for (int q = 0; q < kSegRegs; ++q)
+      if (q * 64 < n) m += __popcll(__ballot(q * 64 + lane < n && reg[q] >= T0));
+    if (m <= 256) {
+      int base = 0;
+#pragma unroll
+      for (int q = 0; q < kSegRegs; ++q)
+        if (q * 64 < n) {
+          const bool in = q * 64 + lane < n && reg[q] >= T0;
+          const uint64_t mk = __ballot(in);
+          if (in) win[base + __popcll(mk & ((1ull << lane) - 1ull))] = (static_cast<uint64_t>(reg[q]) << 32) | (0xFFFFFFFFu - static_cast<uint32_t>(q * 64 + lane));
+          base += __popcll(mk);
+        }
+      __builtin_amdgcn_wave_barrier();
+      for (int i = lane; i < m; i += 64) {
+        const uint64_t mine = win[i];
+        int rank = 0;
+        for (int j = 0; j < m; ++j) rank += (win[j] > mine) ? 1 : 0;
+        if (rank < kk) {
+          const int64_t pos = static_cast<int64_t>(0xFFFFFFFFu - static_cast<uint32_t>(mine));
+          const int64_t col = cols[lo + pos];
+          const bool ok = col >= col_lo && col < col_hi;
+          vrow[rank] = ok ? key_to_float(static_cast<uint32_t>(mine >> 32)) : -__builtin_inff();
+          irow[rank] = ok ? col : -1;
+        }
+      }
+      done = true;
+    }
+  }
+  if (kk > 0 && !done) {
     uint32_t T = 0u;
     for (int bit = 31; bit >= 0; --bit) {
       const uint32_t c = T | (1u << bit);
