@@ -338,6 +338,20 @@ def test_fused_topk_bf16_lists(case, oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
+@pytest.mark.parametrize("su,se", [(1e-20, 1e-20), (1e-3, 1e3), (1e3, 1e2), (1e15, 1e15), (1e-30, 1.0)])
+def test_fused_topk_bf16_bound_over_magnitudes(su, se, oracle, ops, dev):
+    """The bf16 prefilter's error bound scales with the operands' norms (and carries a term for subnormal operands the
+    matrix cores may flush): the top-k stays bit-exact from subnormal products to squared norms that overflow f32
+    (there the bound is infinite and the rows take the exact path)."""
+    rng = np.random.default_rng(5)
+    U = (rng.standard_normal((40, 64)) * su).astype(np.float32)
+    E = (rng.standard_normal((5000, 64)) * se).astype(np.float32)
+    vals, idx = ops.score_topk(T(U, dev), T(E, dev), 10, 1)
+    o_vals, o_idx = oracle.score_topk(U, E, 10, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    assert bits_equal(vals.cpu().numpy(), o_vals)
+
+
 def test_score_topk_user_chunks(oracle, ops, dev, monkeypatch):
     """ops.score_topk bounds its workspace by going through big user batches in chunks (multiples of 128 rows)."""
     rng = np.random.default_rng(77)
