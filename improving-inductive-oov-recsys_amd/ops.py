@@ -179,8 +179,8 @@ class _LshTrainLookup(torch.autograd.Function):
         rows = _gather_rows_forward(ids, table)  # NaN rows where ids >= n_vocab: never selected
         out = torch.where(oov[:, None], emb, rows)
         # rows that are not lsh rows must not reach the lsh backward with a 0/0: give them a one-plane code
-        first = torch.zeros((1, bits.shape[1]), dtype=bits.dtype, device=bits.device)
-        first[0, 0] = 1
+        first = (torch.arange(bits.shape[1], device=bits.device) == 0).to(bits.dtype)[None]  # (device ops only: the
+        # step stays capturable in a HIP graph; `first[0, 0] = 1` is a host -> device copy)
         safe = torch.where(oov[:, None], bits, first)  # (no boolean-mask assignment: that would sync)
         ctx.save_for_backward(ids, oov, safe)
         ctx.n_vocab = n_vocab
