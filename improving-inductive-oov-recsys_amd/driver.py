@@ -88,8 +88,12 @@ def _read_atomic(path):
 
 
 def _remap(values):
-    """token -> id with 0 reserved for padding (RecBole's [PAD]); ids follow sorted token order."""
-    vocab = {t: i + 1 for i, t in enumerate(sorted(set(values)))}
+    """token -> id with 0 reserved for padding (RecBole's [PAD]); ids follow the order of first appearance, as
+    `pandas.factorize` numbers them in R/data/dataset/dataset.py:1219-1241 (`_remap`)."""
+    vocab = {}
+    for t in values:
+        if t not in vocab:
+            vocab[t] = len(vocab) + 1
     return vocab
 
 
@@ -117,7 +121,7 @@ class AtomicDataset:
         self.split = None
         if benchmark_filename:
             parts = [p for p in benchmark_filename]
-            users_raw, items_raw, split = [], [], []
+            users_raw, items_raw, split, is_new = [], [], [], []
             per_part = []
             for k, part in enumerate(parts):
                 inames, _, icols = _read_atomic(os.path.join(root, f"{name}.{part}.inter"))
@@ -126,15 +130,13 @@ class AtomicDataset:
                 users_raw += u
                 items_raw += i
                 split += [k] * len(u)
+                if "is_new" in inames:  # `is_new:token`, -1 old / 1 new (R/data/dataset/dataset.py:174-190)
+                    is_new += [v == "1" for v in icols[inames.index("is_new")]]
+                else:
+                    is_new += [False] * len(u)
+            self.is_new = np.array(is_new, dtype=bool)
             self.uvocab = _remap_in_order(*(u for u, _ in per_part))
             self.ivocab = _remap_in_order(*(i for _, i in per_part))
-            for path, field, vocab in ((os.path.join(root, f"{name}.user"), user_field, self.uvocab),
-                                       (os.path.join(root, f"{name}.item"), item_field, self.ivocab)):
-                if os.path.exists(path):  # entities that only occur in the feature files come last
-                    names, _, raw = _read_atomic(path)
-                    for t in raw[names.index(field)]:
-                        if t not in vocab:
-                            vocab[t] = len(vocab) + 1
             self.split = np.array(split, dtype=np.int64)
             self.n_train_users = len(set(per_part[0][0])) + 1
             self.n_train_items = len(set(per_part[0][1])) + 1
@@ -142,14 +144,26 @@ class AtomicDataset:
             inames, _, icols = _read_atomic(os.path.join(root, f"{name}.inter"))
             users_raw, items_raw = icols[inames.index(user_field)], icols[inames.index(item_field)]
             self.uvocab, self.ivocab = _remap(users_raw), _remap(items_raw)
+            self.is_new = None
+        for path, field, vocab in ((os.path.join(root, f"{name}.user"), user_field, self.uvocab),
+                                   (os.path.join(root, f"{name}.item"), item_field, self.ivocab)):
+            if os.path.exists(path):  # entities that only occur in the feature files come last (dataset.py:1162-1192:
+                names, _, raw = _read_atomic(path)  # the id field is remapped over inter_feat first, then the feature file)
+                for t in raw[names.index(field)]:
+                    if t not in vocab:
+                        vocab[t] = len(vocab) + 1
         self.user_num, self.item_num = len(self.uvocab) + 1, len(self.ivocab) + 1
         self.inter_user = np.array([self.uvocab[u] for u in users_raw], dtype=np.int64)
         self.inter_item = np.array([self.ivocab[i] for i in items_raw], dtype=np.int64)
+        self.field2token_id, self.field2type = {}, {}
         self.user_feat = self._features(os.path.join(root, f"{name}.user"), user_field, self.uvocab, self.user_num)
         self.item_feat = self._features(os.path.join(root, f"{name}.item"), item_field, self.ivocab, self.item_num)
 
-    @staticmethod
-    def _features(path, id_field, vocab, n):
+    def _features(self, path, id_field, vocab, n):
+        """Feature file -> columns indexed by the remapped entity id (row 0 = padding).  Token fields are numbered by
+        first appearance in file order, sequences flattened (dataset.py:1198-1241); a missing float is the mean of the
+        present ones, a missing token is [PAD] (dataset.py:655-680 `_fill_nan`); entities the file does not list keep
+        the same fill values (dataset.py `_user_item_feat_preparation`: reindex, then `_fill_nan`)."""
         cols = {id_field: torch.arange(n)}
         if not os.path.exists(path):
             return FeatureTable(cols)
@@ -159,12 +173,16 @@ class AtomicDataset:
             if name == id_field:
                 continue
             if typ == "float":
-                t = torch.zeros(n)
-                t[rows] = torch.tensor([float(v) if v else 0.0 for v in vals])
+                present = [float(v) for v in vals if v != ""]
+                fill = float(np.mean(np.array(present, dtype=np.float64))) if present else 0.0
+                t = torch.full((n,), fill, dtype=torch.float32)
+                t[0] = 0.0
+                t[rows] = torch.tensor([float(v) if v != "" else fill for v in vals], dtype=torch.float32)
             elif typ == "token":
-                tv = _remap(vals)
+                tv = _remap([v for v in vals if v != ""])
                 t = torch.zeros(n, dtype=torch.int64)
-                t[rows] = torch.tensor([tv[v] for v in vals])
+                t[rows] = torch.tensor([tv.get(v, 0) for v in vals])
+                self.field2token_id[name] = tv
             elif typ in ("token_seq", "float_seq"):
                 seqs = [v.split(" ") if v else [] for v in vals]
                 width = max(1, max(len(s) for s in seqs))
@@ -173,6 +191,7 @@ class AtomicDataset:
                     t = torch.zeros((n, width), dtype=torch.int64)
                     for r, s in zip(rows, seqs):
                         t[r, :len(s)] = torch.tensor([tv[x] for x in s], dtype=torch.int64)
+                    self.field2token_id[name] = tv
                 else:
                     t = torch.zeros((n, width))
                     for r, s in zip(rows, seqs):
@@ -180,7 +199,45 @@ class AtomicDataset:
             else:
                 continue
             cols[name] = t
+            self.field2type[name] = typ
         return FeatureTable(cols)
+
+    def remap_features(self, orig):
+        """Bring the feature columns of an inductive dataset onto the numbering of its transductive twin `orig` (the
+        dataset the model was trained on), as InductiveDataset.remap_features does before evaluation
+        (R/data/dataset/inductive_dataset.py:73-168): every token id becomes the id the same token has in `orig`, a
+        token `orig` never saw becomes 0 ([PAD]); token sequences are cut to `orig`'s width; the value a float column
+        was mean-filled with becomes `orig`'s fill value.  After it, rows 1..orig.n-1 of every column equal `orig`'s
+        (the check S/perform_hashing.py:112-138 prints), so the plugin hashes old entities exactly as in training.
+        Returns {field: [tokens orig never saw]}."""
+        missing = {}
+        for feat, ofeat in ((self.user_feat, orig.user_feat), (self.item_feat, orig.item_feat)):
+            for name in feat.columns[1:]:
+                if name not in ofeat.columns:
+                    continue
+                col, ocol = feat[name], ofeat[name]
+                typ = self.field2type.get(name)
+                if typ in ("token", "token_seq"):
+                    mine, theirs = self.field2token_id[name], orig.field2token_id[name]
+                    lut = torch.zeros(len(mine) + 1, dtype=torch.int64)
+                    for tok, i in mine.items():
+                        lut[i] = theirs.get(tok, 0)
+                    missing[name] = [tok for tok in mine if tok not in theirs]
+                    col = lut[col]
+                    if col.ndim > 1 and col.shape[1] != ocol.shape[1]:
+                        col = col[:, :ocol.shape[1]]
+                    self.field2token_id[name] = dict(theirs, **{tok: 0 for tok in missing[name]})
+                elif typ == "float":
+                    k = ocol.shape[0]
+                    old = col[1:k]
+                    diff = ocol[1:] != old
+                    if bool(diff.any()):
+                        if not (bool((old[diff] == old[diff][0]).all()) and bool((ocol[1:][diff] == ocol[1:][diff][0]).all())):
+                            raise AssertionError(f"float feature {name}: old rows differ by more than the fill value")
+                        col = col.clone()
+                        col[1:k][diff] = ocol[1:][diff][0]
+                feat._cols[name] = col
+        return missing
 
     def get_user_feature(self):
         return self.user_feat
@@ -280,6 +337,11 @@ def run(args):
     if isinstance(bench_files, str):
         bench_files = [p.strip(" '\"[]") for p in bench_files.split(",") if p.strip(" '\"[]")]
     ds = AtomicDataset(cfg["dataset"], cfg["data_path"], ukey, ikey, benchmark_filename=bench_files)
+    if cfg["orig_dataset"]:  # the transductive twin the checkpoint was trained on (S/perform_hashing.py:101-109:
+        orig = AtomicDataset(cfg["orig_dataset"], cfg["data_path"], ukey, ikey)  # `ind_dataset.set_orig_dataset`)
+        missing = ds.remap_features(orig)
+        print("feature tokens the transductive dataset never saw (-> [PAD]):",
+              {k: len(v) for k, v in missing.items() if v})
     if ds.split is not None:  # pre-split inductive dataset: vocabulary = what the train part contains
         n_users, n_items = ds.n_train_users, ds.n_train_items
         is_test = ds.split == ds.split.max()

@@ -154,3 +154,68 @@ def test_checkpoint_round_trip(tmp_path, monkeypatch, dev):
     assert res2["overall"].keys() == res1["overall"].keys() and all(0 <= v <= 1 for v in res2["overall"].values())
     assert abs(res2["old_users"]["recall@10"] - res1["old_users"]["recall@10"]) < 0.05  # different negative samples
 
+
+
+def test_inductive_dataset_pair_matches_reference():
+    """The on-disk step either side of the path: a transductive dataset and its `X_ind` twin
+    (`benchmark_filename = [train, empty, test_filt]`, `is_new` column) loaded by driver.AtomicDataset, and
+    `remap_features` onto the transductive numbering, against what the REAL reference's Dataset / InductiveDataset
+    produce for the same files (tests/golden/make_golden_ind.py; R/data/dataset/inductive_dataset.py:73-190)."""
+    import numpy as np
+    from mi_oov import driver
+    here = os.path.dirname(os.path.abspath(__file__))
+    z = np.load(os.path.join(here, "golden", "ind_dataset.npz"))
+    root = os.path.join(here, "golden", "ind_dataset")
+    tr = driver.AtomicDataset("ml-100k_tr", root)
+    ind = driver.AtomicDataset("ml-100k_ind", root, benchmark_filename=["train", "empty", "test_filt"])
+    assert [tr.user_num, tr.item_num] == z["tr__nums"].tolist()
+    assert [ind.user_num, ind.item_num] == z["ind__nums"].tolist()
+    assert (ind.n_train_users, ind.n_train_items) == (tr.user_num, tr.item_num)   # train-first numbering
+    for side, feat in (("user", tr.user_feat), ("item", tr.item_feat)):
+        for col in feat.columns:
+            assert np.array_equal(feat[col].numpy(), z[f"tr__{side}__{col}"]), (side, col)
+    for side, feat in (("user", ind.user_feat), ("item", ind.item_feat)):       # before the remap: the twin's own numbering
+        for col in feat.columns:
+            assert np.array_equal(feat[col].numpy(), z[f"ind_raw__{side}__{col}"]), (side, col)
+    missing = ind.remap_features(tr)
+    assert "homemaker" in missing["occupation"] and not missing["gender"]
+    for side, feat, tfeat in (("user", ind.user_feat, tr.user_feat), ("item", ind.item_feat, tr.item_feat)):
+        for col in feat.columns:
+            got = feat[col].numpy()
+            assert np.array_equal(got, z[f"ind__{side}__{col}"]), (side, col)
+            k = tfeat[col].shape[0]
+            assert np.array_equal(got[1:k], tfeat[col].numpy()[1:])               # S/perform_hashing.py:112-138
+    for k, part in enumerate(("train", "empty", "test_filt")):
+        sel = ind.split == k
+        assert np.array_equal(ind.inter_user[sel], z[f"ind__inter__{part}__user"])
+        assert np.array_equal(ind.inter_item[sel], z[f"ind__inter__{part}__item"])
+    new_tok = z["ind__is_new_tokens"].tolist().index("1")
+    assert np.array_equal(ind.is_new[ind.split == 2], z["ind__inter__test_filt__is_new"] == new_tok)
+    # every row flagged new touches an out-of-vocabulary user or item; the flagged-old ones do not
+    t = ind.split == 2
+    oov = (ind.inter_user[t] >= ind.n_train_users) | (ind.inter_item[t] >= ind.n_train_items)
+    assert np.array_equal(oov, ind.is_new[t])
+
+
+@pytest.mark.gpu
+def test_train_transductive_then_evaluate_inductive_twin(tmp_path, monkeypatch, dev):
+    """The paper driver's two stages on the golden dataset pair (S/run_recbole.py:202-266 -> S/perform_hashing.py:85-170):
+    train BPR + lsh on the transductive dataset, save; load the checkpoint against the `_ind` twin with its features
+    remapped onto the transductive numbering (`--orig_dataset`) and evaluate the old / new slices."""
+    from mi_oov import driver
+    monkeypatch.chdir(tmp_path)
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ind_dataset")
+    ck = str(tmp_path / "tr.pth")
+    common = ["x", f"--data_path={root}", "--model=BPR", "--embedding_size=64", "--user_oov_buckets=8", "--item_oov_buckets=8",
+              "--inductive_embedder=lsh", "--add_oov_buckets", "--train_oov", "--train_batch_size=1024"]
+    _, m1 = driver.run(driver.custom_parse_args(common + ["--dataset=ml-100k_tr", "--oov_fraction=0", "--epochs=3",
+                                                          f"--save_checkpoint={ck}"]))
+    res, m2 = driver.run(driver.custom_parse_args(common + ["--dataset=ml-100k_ind", "--benchmark_filename=train,empty,test_filt",
+                                                            "--orig_dataset=ml-100k_tr", "--eval_only", f"--load_checkpoint={ck}"]))
+    assert m2.user_embedding.weight.shape == m1.user_embedding.weight.shape    # the twin's train part = the transductive vocabulary
+    assert torch.equal(m1.item_embedding.weight, m2.item_embedding.weight)
+    # the plugin hashes the old entities of the twin exactly as it did in training: same feature rows
+    k = m1.inductive_embedder.item_feature_mat.shape[0]
+    assert torch.equal(m1.inductive_embedder.item_feature_mat[1:], m2.inductive_embedder.item_feature_mat[1:k])
+    assert {"overall", "old_users", "new_users", "new_items"} <= set(res)
+    assert all(0 <= v <= 1 for v in res["overall"].values())
