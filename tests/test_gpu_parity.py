@@ -352,6 +352,18 @@ def test_fused_topk_bf16_bound_over_magnitudes(su, se, oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
+def test_fused_topk_large_catalogue(oracle, ops, dev):
+    """3 M items: 11 719 sampled tile maxima per row (the radix tau kernel), 128 strips of 183 blocks, column
+    indices far beyond 2^16; a few user rows keep the oracle to a couple of seconds."""
+    rng = np.random.default_rng(12)
+    U = rng.standard_normal((6, 64), dtype=np.float32)
+    E = rng.standard_normal((3_000_000, 64), dtype=np.float32)
+    vals, idx = ops.score_topk(T(U, dev), T(E, dev), 10, 1)
+    o_vals, o_idx = oracle.score_topk(U, E, 10, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    assert bits_equal(vals.cpu().numpy(), o_vals)
+
+
 def test_score_topk_user_chunks(oracle, ops, dev, monkeypatch):
     """ops.score_topk bounds its workspace by going through big user batches in chunks (multiples of 128 rows)."""
     rng = np.random.default_rng(77)
