@@ -1523,6 +1523,15 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16) {
   // 8 -> 124 us, 4-5 -> 106 us, 3 -> 153 us); the f32 path pays a full-rate GEMM for pass 1 and keeps 8.
   static const int64_t env_stride = [] { const char* e = getenv("MI_OOV_TOPK_STRIDE"); return e ? atoll(e) : 0LL; }();
   int64_t stride = env_stride > 0 ? env_stride : (bf16 ? (k <= 32 ? 4 : 2) : 8);  // (k = 50: 2 -> 130 us, 3 -> 135 us, 4 -> 151 us)
+  if (bf16 && env_stride <= 0 && k < 20) {
+    // small k over a big catalogue (the knn search: k = 2, 10 M rows): ~80 candidates per row allow a wider stride, as
+    // long as ~200 sampled tiles remain -- the k-th best of a few dozen tile maxima is a poor bound (k = 5, stride 16
+    // at 50 000 items left 50 tiles and sent rows to the exact fallback)
+    int64_t wide = 80 / k;
+    if (wide > 16) wide = 16;
+    if (wide > nblk / 96) wide = nblk / 96;
+    if (wide > stride) stride = wide;
+  }
   if (stride > 256 / k) stride = 256 / k;  // ~k * stride candidates per row: a quarter of the 1024 slots
   if (stride > nblk / k) stride = nblk / k;  // sampled 64-column tiles: 2 * nblk / stride >= 2k
   if (stride < 1) stride = 1;

@@ -134,7 +134,7 @@ def main():
     if args.only.startswith("score_topk sweep"):  # no cliffs over k, user-batch and catalogue sizes
         for (b_, n_, k_) in ((4096, 50000, 1), (4096, 50000, 5), (4096, 50000, 50), (4096, 50000, 120), (4096, 50000, 256),
                              (512, 50000, 20), (65536, 50000, 20), (4096, 500000, 20), (4096, 10000, 20),
-                             (4096, 10_000_000, 2)):  # the last one: the knn search of BASELINE's 10 M-row table
+                             (4096, 500000, 5), (4096, 10_000_000, 2)):  # the last one: the knn search of BASELINE's 10 M-row table
             U_ = torch.randn(b_, D, device=dev)
             E_ = torch.randn(n_, D, device=dev)
             cases[f"score_topk sweep k={k_} B={b_} N={n_}"] = (lambda i, U_=U_, E_=E_, k_=k_: ops.score_topk(U_, E_, k_, 1), b_ * n_, 0, 2 * D)
