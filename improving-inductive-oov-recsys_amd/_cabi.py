@@ -33,6 +33,9 @@ _SIGNATURES = {
     "mi_oov_score_topk_excl": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_score_topk_masked_workspace": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_oov_score_topk_masked": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mi_oov_topk_catalogue_bytes": (_i64, [_i64, _i64]),
+    "mi_oov_topk_catalogue_prepare": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_score_topk_prepared": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_segment_topk": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_topk_hits": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_slsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -1570,9 +1570,16 @@ static bool masked_topk_supported(int64_t B, int64_t N, int64_t D, int64_t k) {
   return B > 0 && N > 0 && N < (1LL << 32) && D == 64 && k > 0 && use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535;
 }
 
+// `catalogue`: bf16 copy of E + partial norm maxima made by mi_oov_topk_catalogue_prepare (null: made per call).
+static int64_t catalogue_e2_offset(int64_t N) { return align256(N * 128); }
+static int64_t catalogue_parts(int64_t N) {
+  const int64_t ge = grid_for(N, kBlock / 16);
+  return ge > kNormGrid ? kNormGrid : ge;
+}
+
 static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k, int64_t n_skip_low,
-                           const int64_t* excl_ptr, const int64_t* excl_cols, unsigned long long* mask, float* vals,
-                           int64_t* idx, void* workspace, void* stream) {
+                           const int64_t* excl_ptr, const int64_t* excl_cols, unsigned long long* mask,
+                           const void* catalogue, float* vals, int64_t* idx, void* workspace, void* stream) {
   if (B < 0 || N <= 0 || D <= 0 || k <= 0 || n_skip_low < 0 || N >= (1LL << 32)) return MI_OOV_ERR_SHAPE;
   if (B == 0) return MI_OOV_OK;
   if (!U || !E || !vals || !idx || !workspace) return MI_OOV_ERR_NULL;
@@ -1581,8 +1588,8 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
   if (use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535) {
     const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
     static const bool bf16_path = [] { const char* e = getenv("MI_OOV_TOPK_BF16"); return !(e && e[0] == '0'); }();
-    const bool use_bf16 = (bf16_path || mask) && D == 64 && vec;
-    if (mask && !use_bf16) return MI_OOV_ERR_ALIGN;  // (the masked entry point checked the shape; only alignment is left)
+    const bool use_bf16 = (bf16_path || mask || catalogue) && D == 64 && vec;
+    if ((mask || catalogue) && !use_bf16) return MI_OOV_ERR_ALIGN;  // (the entry points checked the shape; only alignment is left)
     const FusedLayout L = fused_layout(B, N, k, use_bf16);
     char* ws = static_cast<char*>(workspace);
     TopkArgs ta{};
@@ -1605,6 +1612,10 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       uint32_t* e2max = reinterpret_cast<uint32_t*>(ws + L.off_e2max);
       __bf16* Ub = reinterpret_cast<__bf16*>(ws + L.off_ub);
       __bf16* Eb = reinterpret_cast<__bf16*>(ws + L.off_eb);
+      if (catalogue) {  // prepared once for a catalogue that many user batches are scored against
+        Eb = const_cast<__bf16*>(static_cast<const __bf16*>(catalogue));
+        e2max = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(static_cast<const char*>(catalogue) + catalogue_e2_offset(N)));
+      }
       const int64_t nblk = (N + BN - 1) / BN;
       const int64_t rb = (B + BM - 1) / BM;
       static const int64_t target = [] { const char* e = getenv("MI_OOV_STRIP_WGS"); return e ? atoll(e) : 1024LL; }();
@@ -1644,11 +1655,11 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
         }
         hipLaunchKernelGGL(mask_build_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, excl_ptr, excl_cols, B, N, mask, sl.mask_words);
       }
-      int64_t gu = grid_for(B, kBlock / 16), ge = grid_for(N, kBlock / 16);
+      int64_t gu = grid_for(B, kBlock / 16);
+      const int64_t ge = catalogue_parts(N);
       if (gu > kNormGrid) gu = kNormGrid;
-      if (ge > kNormGrid) ge = kNormGrid;
-      hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(gu + ge)), dim3(kBlock), 0, st, U, B, Ub, u2, sl.ovf_cnt,
-                         static_cast<int>(gu), E, N, Eb, e2max);
+      hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
+                         sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max);
       if ((rc = check_launch())) return rc;
       const size_t lds_ops = static_cast<size_t>(BM + BN) * BLD * sizeof(__bf16);
       const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
@@ -1718,7 +1729,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
 
 extern "C" int mi_oov_score_topk(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
                                  int64_t n_skip_low, float* vals, int64_t* idx, void* workspace, void* stream) {
-  return score_topk_impl(U, B, E, N, D, k, n_skip_low, nullptr, nullptr, nullptr, vals, idx, workspace, stream);
+  return score_topk_impl(U, B, E, N, D, k, n_skip_low, nullptr, nullptr, nullptr, nullptr, vals, idx, workspace, stream);
 }
 
 // Exclusions of any length on the fused path: the histories become a bitmap (B x ceil(N / 64) words) that pass 1 applies
@@ -1737,7 +1748,43 @@ extern "C" int mi_oov_score_topk_masked(const float* U, int64_t B, const float* 
   if (!U || !E || !excl_ptr || !excl_cols || !vals || !idx || !workspace) return MI_OOV_ERR_NULL;
   if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_OOV_ERR_ALIGN;
   unsigned long long* mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + align256(mi_oov_score_topk_workspace(B, N, k)));
-  return score_topk_impl(U, B, E, N, D, k, n_skip_low, excl_ptr, excl_cols, mask, vals, idx, workspace, stream);
+  return score_topk_impl(U, B, E, N, D, k, n_skip_low, excl_ptr, excl_cols, mask, nullptr, vals, idx, workspace, stream);
+}
+
+// A catalogue that many user batches are scored against (the knn search's feature table, the item table of an evaluation
+// run) is converted once: the counterpart of the reference building its ScaNN searcher at construction
+// (knn_embedder.py:84-93).  The buffer holds the bf16 copy of E and the per-workgroup maxima of its squared row norms.
+extern "C" int64_t mi_oov_topk_catalogue_bytes(int64_t N, int64_t D) {
+  if (N <= 0 || N >= (1LL << 32) || D != 64) return 0;
+  return catalogue_e2_offset(N) + align256(kNormGrid * 4);
+}
+
+extern "C" int mi_oov_topk_catalogue_prepare(const float* E, int64_t N, int64_t D, void* catalogue, void* stream) {
+  if (N <= 0 || N >= (1LL << 32) || D != 64) return MI_OOV_ERR_SHAPE;
+  if (!E || !catalogue) return MI_OOV_ERR_NULL;
+  if (!aligned16(E) || (reinterpret_cast<uintptr_t>(catalogue) & 15u) != 0) return MI_OOV_ERR_ALIGN;
+  __bf16* Eb = static_cast<__bf16*>(catalogue);
+  uint32_t* e2part = reinterpret_cast<uint32_t*>(static_cast<char*>(catalogue) + catalogue_e2_offset(N));
+  hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(catalogue_parts(N))), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                     static_cast<const float*>(nullptr), 0, static_cast<__bf16*>(nullptr), static_cast<float*>(nullptr),
+                     static_cast<int*>(nullptr), 0, E, N, Eb, e2part);
+  return check_launch();
+}
+
+// mi_oov_score_topk (excl_ptr == NULL) or mi_oov_score_topk_masked (excl_ptr != NULL) against a prepared catalogue of
+// the same E; workspace as for the respective call.  Shapes the bf16 path does not take are an error here (a caller
+// that prepared a catalogue has a 64-column, aligned E).
+extern "C" int mi_oov_score_topk_prepared(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                                          int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols,
+                                          const void* catalogue, float* vals, int64_t* idx, void* workspace, void* stream) {
+  if (B == 0 && N > 0 && D > 0 && k > 0) return MI_OOV_OK;
+  if (!masked_topk_supported(B, N, D, k) || n_skip_low < 0) return MI_OOV_ERR_SHAPE;
+  if (!U || !E || !catalogue || !vals || !idx || !workspace || (excl_ptr && !excl_cols)) return MI_OOV_ERR_NULL;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0 || (reinterpret_cast<uintptr_t>(catalogue) & 15u) != 0 || !aligned16(U) || !aligned16(E))
+    return MI_OOV_ERR_ALIGN;
+  unsigned long long* mask = nullptr;
+  if (excl_ptr) mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + align256(mi_oov_score_topk_workspace(B, N, k)));
+  return score_topk_impl(U, B, E, N, D, k, n_skip_low, excl_ptr, excl_cols, mask, catalogue, vals, idx, workspace, stream);
 }
 
 // ---- full-sort evaluation with per-user exclusions (history masks) ---------------------------------------------

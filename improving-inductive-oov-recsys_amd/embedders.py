@@ -475,7 +475,14 @@ class KNNInductiveEmbedder(_FeatureEmbedder):
 
     def _hash_node(self, nodes, n_original, feature_mat):
         q = ops.gather_rows(nodes, feature_mat)
-        return ops.score_topk(q, feature_mat[:n_original], self.n_neighbors)[1]
+        # the searched table is fixed for the embedder's lifetime: its fused-search form is made once, where the
+        # reference builds its ScaNN searcher (knn_embedder.py:84-93); None for widths the fused path does not take
+        cache = self.__dict__.setdefault("_catalogues", {})
+        key = (feature_mat.data_ptr(), n_original)
+        cat = cache.get(key)
+        if key not in cache or (cat is not None and not cat.fresh()):
+            cat = cache[key] = ops.TopkCatalogue.of(feature_mat[:n_original])
+        return ops.score_topk(q, cat if cat is not None else feature_mat[:n_original], self.n_neighbors)[1]
 
     def _hash_users(self, users):
         return self._hash_node(users, self.n_original_users, self.user_feature_mat)

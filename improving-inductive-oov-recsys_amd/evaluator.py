@@ -103,7 +103,12 @@ class FullSortCollector(RankingCollector):
         if positive_u.numel() > 1 and bool((positive_u[1:] < positive_u[:-1]).any()):
             o = torch.sort(positive_u, stable=True).indices
             positive_u, positive_i = positive_u[o], positive_i[o]
-        _, idx = ops.score_topk_excl(U, E, self.topk[-1], _csr_ptr(hu, n_users), hi, n_skip_low=n_skip_low)
+        # the item table is the same for every user batch of an evaluation run: prepared once per table version
+        cat = getattr(self, "_catalogue", None)
+        if cat is None or not cat.fresh(E):
+            cat = self._catalogue = ops.TopkCatalogue.of(E)
+        _, idx = ops.score_topk_excl(U, cat if cat is not None else E, self.topk[-1], _csr_ptr(hu, n_users), hi,
+                                     n_skip_low=n_skip_low)
         rec = ops.topk_hits(idx, _csr_ptr(positive_u, n_users), positive_i)
         self.blocks.append(rec)
         return rec

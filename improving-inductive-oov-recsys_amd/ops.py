@@ -594,13 +594,67 @@ def hash_net_forward(net, x):
 _TOPK_WORKSPACE_MAX_BYTES = 2 << 30
 
 
+class TopkCatalogue:
+    """A catalogue E prepared once for many `score_topk` / `score_topk_excl` calls (`mi_oov_topk_catalogue_prepare`): the
+    counterpart of the reference building its ScaNN searcher at construction (knn_embedder.py:84-93).  Holds a reference
+    to E and is valid while E is not written to (`fresh()` checks torch's version counter); `TopkCatalogue.of(E)` returns
+    None for shapes the fused bf16 path does not take (callers then pass the plain tensor)."""
+
+    def __init__(self, E):
+        E = _f32(E, "E")
+        nbytes = int(C.lib().mi_oov_topk_catalogue_bytes(E.shape[0], E.shape[1]))
+        if nbytes <= 0 or E.data_ptr() % 16:
+            raise ValueError("TopkCatalogue needs a 16-byte aligned [N, 64] float32 table")
+        self.E = E
+        self.version = E._version
+        self.buf = torch.empty((nbytes,), dtype=torch.uint8, device=E.device)
+        with C.on_device(E):
+            rc = C.lib().mi_oov_topk_catalogue_prepare(C.ptr(E), E.shape[0], E.shape[1], C.ptr(self.buf), C.stream_of(E))
+        C.check(rc, "mi_oov_topk_catalogue_prepare")
+
+    @staticmethod
+    def of(E):
+        ok = torch.is_tensor(E) and E.is_cuda and E.dtype == torch.float32 and E.dim() == 2 and E.is_contiguous() \
+            and E.shape[1] == 64 and E.shape[0] > 0 and E.data_ptr() % 16 == 0
+        return TopkCatalogue(E) if ok else None
+
+    def fresh(self, E=None):
+        same = E is None or (E.data_ptr() == self.E.data_ptr() and E.shape == self.E.shape)
+        return same and self.E._version == self.version
+
+
+def _prepared_call(U, cat, k, n_skip_low, excl_ptr, excl_cols, vals, idx):
+    """One mi_oov_score_topk_prepared launch; returns False when the shape is not one the fused bf16 path takes."""
+    lib = C.lib()
+    B, N, D = U.shape[0], cat.E.shape[0], U.shape[1]
+    need = int(lib.mi_oov_score_topk_masked_workspace(B, N, D, k)) if excl_ptr is not None else \
+        (int(lib.mi_oov_score_topk_workspace(B, N, k)) if int(lib.mi_oov_score_topk_masked_workspace(B, N, D, k)) > 0 else 0)
+    if need <= 0 or U.data_ptr() % 16:
+        return False
+    ws = torch.empty((need,), dtype=torch.uint8, device=U.device)
+    with C.on_device(U):
+        rc = lib.mi_oov_score_topk_prepared(C.ptr(U), B, C.ptr(cat.E), N, D, k, int(n_skip_low), C.ptr(excl_ptr), C.ptr(excl_cols),
+                                            C.ptr(cat.buf), C.ptr(vals), C.ptr(idx), C.ptr(ws), C.stream_of(U))
+    C.check(rc, "mi_oov_score_topk_prepared")
+    return True
+
+
 def score_topk(U, E, k, n_skip_low=0):
-    """Per-row top-k of U @ E.T without returning the [B,N] matrix.  Returns (vals, idx)."""
+    """Per-row top-k of U @ E.T without returning the [B,N] matrix.  Returns (vals, idx).  E: the table, or a
+    `TopkCatalogue` of it."""
+    cat = E if isinstance(E, TopkCatalogue) else None
+    if cat is not None:
+        if not cat.fresh():
+            raise ValueError("the catalogue's table was modified after TopkCatalogue was built")
+        E = cat.E
     U, E = _f32(U, "U"), _f32(E, "E")
     B, N, D = U.shape[0], E.shape[0], U.shape[1]
     vals = torch.empty((B, k), dtype=torch.float32, device=U.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=U.device)
     lib = C.lib()
+    if cat is not None and B > 0 and lib.mi_oov_score_topk_workspace(B, N, k) <= _TOPK_WORKSPACE_MAX_BYTES \
+            and _prepared_call(U, cat, k, n_skip_low, None, None, vals, idx):
+        return vals, idx
     # the fused path's workspace grows with B x N (tile maxima, candidate lists): a 10 M-row catalogue is ~165 KB per
     # user, so big batches go through in chunks of users (multiples of the 128-row tile)
     rows = B
@@ -610,6 +664,8 @@ def score_topk(U, E, k, n_skip_low=0):
     with C.on_device(U):
         for b0 in range(0, max(B, 1), max(rows, 1)):
             nb = min(rows, B - b0)
+            if cat is not None and nb > 0 and _prepared_call(U[b0:b0 + nb], cat, k, n_skip_low, None, None, vals[b0:b0 + nb], idx[b0:b0 + nb]):
+                continue
             rc = lib.mi_oov_score_topk(C.ptr(U[b0:b0 + nb]), nb, C.ptr(E), N, D, k, n_skip_low, C.ptr(vals[b0:b0 + nb]),
                                        C.ptr(idx[b0:b0 + nb]), C.ptr(ws), C.stream_of(U))
             C.check(rc, "mi_oov_score_topk")
@@ -662,6 +718,11 @@ def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
     (`mi_oov_score_topk_masked`: any history length, no host synchronisation).  Other shapes: users are processed
     in groups such that k + (longest history of the group) <= 256 (`mi_oov_score_topk_excl`); users with longer
     histories go through the materialising path."""
+    cat = E if isinstance(E, TopkCatalogue) else None
+    if cat is not None:
+        if not cat.fresh():
+            raise ValueError("the catalogue's table was modified after TopkCatalogue was built")
+        E = cat.E
     U, E = _f32(U, "U"), _f32(E, "E")
     excl_ptr, excl_cols = _ids(excl_ptr, "excl_ptr"), _ids(excl_cols, "excl_cols")
     B, N = U.shape[0], E.shape[0]
@@ -675,6 +736,8 @@ def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
     # histories of any length, one call, no host sync: exclusion bitmap applied inside the fused kernel (D = 64)
     need = int(lib.mi_oov_score_topk_masked_workspace(B, N, U.shape[1], k))
     if _USE_MASKED_TOPK and 0 < need <= _MASKED_TOPK_MAX_BYTES and U.data_ptr() % 16 == 0 and E.data_ptr() % 16 == 0:
+        if cat is not None and _prepared_call(U, cat, k, n_skip_low, excl_ptr, excl_cols, vals, idx):
+            return vals, idx
         ws = torch.empty((need,), dtype=torch.uint8, device=U.device)
         with C.on_device(U):
             rc = lib.mi_oov_score_topk_masked(C.ptr(U), B, C.ptr(E), N, U.shape[1], k, int(n_skip_low), C.ptr(excl_ptr),

@@ -285,6 +285,19 @@ int mi_oov_score_topk_masked(const float* U, int64_t B, const float* E, int64_t 
                              int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols,
                              float* vals, int64_t* idx, void* workspace, void* stream);
 
+/* A catalogue E that many user batches are scored against (the knn search's feature table -- the reference builds a ScaNN
+ * searcher over it at construction, knn_embedder.py:84-93 -- or the item table of an evaluation run) can be prepared once:
+ * the buffer receives what the fused bf16 path otherwise derives from E on every call.  D = 64, E 16-byte aligned;
+ * mi_oov_topk_catalogue_bytes returns 0 for other shapes.  The catalogue is valid for exactly the E it was made from.
+ * mi_oov_score_topk_prepared = mi_oov_score_topk (excl_ptr NULL; workspace mi_oov_score_topk_workspace) or
+ * mi_oov_score_topk_masked (excl_ptr given; workspace mi_oov_score_topk_masked_workspace) with the per-call pass over E
+ * left out; results are identical.                                                                                */
+int64_t mi_oov_topk_catalogue_bytes(int64_t N, int64_t D);
+int mi_oov_topk_catalogue_prepare(const float* E, int64_t N, int64_t D, void* catalogue, void* stream);
+int mi_oov_score_topk_prepared(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                               int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols,
+                               const void* catalogue, float* vals, int64_t* idx, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

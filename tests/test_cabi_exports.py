@@ -68,6 +68,12 @@ def test_argument_validation_of_the_widened_entry_points(lib):
     assert lib.mi_oov_score_topk_masked(None, 4, None, 50_000, 32, 20, 0, None, None, None, None, None, None) == -2
     assert lib.mi_oov_score_topk_masked(None, 4, None, 50_000, 64, 20, 0, None, None, None, None, None, None) == -1
     assert lib.mi_oov_score_topk_masked(None, 0, None, 50_000, 64, 20, 0, None, None, None, None, None, None) == 0
+    assert lib.mi_oov_topk_catalogue_bytes(50_000, 64) >= 50_000 * 128 + 512 * 4            # bf16 rows + partial norm maxima
+    assert lib.mi_oov_topk_catalogue_bytes(50_000, 32) == 0
+    assert lib.mi_oov_topk_catalogue_prepare(None, 50_000, 32, None, None) == -2
+    assert lib.mi_oov_topk_catalogue_prepare(None, 50_000, 64, None, None) == -1
+    assert lib.mi_oov_score_topk_prepared(None, 4, None, 50_000, 64, 20, 0, None, None, None, None, None, None, None) == -1
+    assert lib.mi_oov_score_topk_prepared(None, 4, None, 1000, 64, 20, 0, None, None, None, None, None, None, None) == -2
     assert lib.mi_oov_linear_act(None, 4, 16, None, None, 8, 7, None, None) in (-2, -3)       # unknown activation
     assert lib.mi_oov_last_hip_error() == 0                                                  # nothing touched the GPU
 

@@ -364,6 +364,30 @@ def test_fused_topk_large_catalogue(oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
+def test_topk_prepared_catalogue(oracle, ops, dev):
+    """A catalogue prepared once (mi_oov_topk_catalogue_prepare) gives the same top-k as the per-call path, with and
+    without exclusions; writing to the table invalidates it."""
+    rng = np.random.default_rng(31)
+    U = rng.standard_normal((150, 64), dtype=np.float32)
+    E = rng.standard_normal((7000, 64), dtype=np.float32)
+    Eg = T(E, dev)
+    cat = ops.TopkCatalogue(Eg)
+    vals, idx = ops.score_topk(T(U, dev), cat, 15, 1)
+    o_vals, o_idx = oracle.score_topk(U, E, 15, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx) and bits_equal(vals.cpu().numpy(), o_vals)
+    lens = rng.integers(0, 400, 150)
+    ptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    cols = rng.integers(1, 7000, int(ptr[-1])).astype(np.int64)
+    v2, i2 = ops.score_topk_excl(T(U, dev), cat, 15, T(ptr, dev), T(cols, dev), n_skip_low=1)
+    ov, oi = oracle.score_topk_excl(U, E, 15, ptr, cols, 1)
+    assert np.array_equal(i2.cpu().numpy(), oi) and np.array_equal(v2.cpu().numpy(), ov)
+    assert ops.TopkCatalogue.of(Eg[:, :32].contiguous()) is None          # a width the fused path does not take
+    Eg[5] += 1.0
+    assert not cat.fresh()
+    with pytest.raises(ValueError):
+        ops.score_topk(T(U, dev), cat, 15, 1)
+
+
 def test_score_topk_user_chunks(oracle, ops, dev, monkeypatch):
     """ops.score_topk bounds its workspace by going through big user batches in chunks (multiples of 128 rows)."""
     rng = np.random.default_rng(77)

@@ -128,6 +128,13 @@ def main():
                     ops._USE_MASKED_TOPK = masked
                     return ops.score_topk_excl(U, E, 20, ptr, colsx, 1)
                 cases[f"score_topk_excl k=20 B=4096 N=50000 hist~{hmean} max {hmax} {'masked' if masked else 'k+h_max'}"] = (run, Bs * Ns, 0, 2 * D)
+    if args.only.startswith("score_topk prepared"):  # catalogue converted once (knn search table, evaluation item table)
+        catE = ops.TopkCatalogue(E)
+        cases["score_topk prepared k=20 B=4096 N=50000"] = (lambda i: ops.score_topk(U, catE, 20, 1), Bs * Ns, 0, 2 * D)
+        Ebig = torch.randn(10_000_000, D, device=dev)
+        catB = ops.TopkCatalogue(Ebig)
+        cases["score_topk prepared k=2 B=4096 N=10000000"] = (lambda i: ops.score_topk(U, catB, 2, 1), Bs * 10_000_000, 0, 2 * D)
+        cases["score_topk unprepared k=2 B=4096 N=10000000"] = (lambda i: ops.score_topk(U, Ebig, 2, 1), Bs * 10_000_000, 0, 2 * D)
     if args.only.startswith("score_topk degenerate"):  # every row ties everywhere: all rows take the exact fallback
         Uz = torch.zeros(512, D, device=dev)
         cases["score_topk degenerate (512 zero user rows, N=50000, k=20: exact fallback for every row)"] = (lambda i: ops.score_topk(Uz, E, 20, 1), 512 * Ns, 0, 2 * D)
