@@ -1237,7 +1237,8 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
       // <= 0xFF800000 (-inf) -- negative numbers; NaNs of either sign and everything >= +0 lie above; -0 cannot occur,
       // the seed is never -0 and a sum that cancels rounds to +0 -- so "some score passes" is one v_max3_i32 and one
       // compare.  (About one wave-level test in eight finds a passing score; per-score branches were 3 instructions
-      // each on the path where none does.)
+      // each on the path where none does.  A coarser first test -- one per 32 scores -- for catalogues so big that
+      // hardly any tile holds a candidate changed nothing: 10 M rows, k = 2: 6.42 vs 6.40 ms.)
       auto bits = [&](int v) { return static_cast<int>(__float_as_uint(acc[v >> 5][v & 1][(v >> 1) & 15])); };
 #pragma unroll
       for (int v = 0; v < 64; v += 3) {
