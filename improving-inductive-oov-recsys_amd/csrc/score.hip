@@ -994,7 +994,9 @@ struct StripLists {
 // everything else has to stay off the critical path:
 //   * the next block of E is fetched into registers while the current one is multiplied and filtered (measured by
 //     knocking phases out of the FILTER kernel, 56 us: no re-staging and no barriers 54 us, no MFMAs 41 us, no
-//     epilogue 31 us -- the per-score compare-and-branch, ~3 instructions x 64 scores per lane, is what is left);
+//     epilogue 31 us -- the per-score compare-and-branch, ~3 instructions x 64 scores per lane, is what is left).
+//     512-thread workgroups (8 waves of 64 x 32: half the accumulators, 74 registers, 6 waves per SIMD) were slower:
+//     110 vs 101 us at 50 000 items, 7.4 vs 6.3 ms at 10 M -- more waves do not help, operand reads per MFMA do (1.5 vs 1);
 //   * rows past B / N are clamped to the last row (no zero fill, no divergent loads): the epilogues mask them;
 //   * FILTER seeds the accumulators with -thr[row] (read from LDS with the operands), so the epilogue is one compare
 //     against zero and a branch per score: a threshold read per row inside the epilogue was an exposed LDS round trip
