@@ -6,27 +6,33 @@
 
 Workload (BASELINE.json north_star / SURVEY.md section 8d "Config S-lsh"): item features
 f32[N=10M, F=64] row-normalised, planes f32[8,64], OOV bucket table f32[8,64], batch B=65536
-random ids, user rows f32[B,64].  One STEP = one pass of the hot path over one batch = ONE launch of
-    mi_oov_lsh_embed_score  (gather feat[id] -> 8 sign projections -> masked mean of bucket rows ->
-                             dot with the user row -> score[b]; what BPR.predict returns for OOV
-                             items behind LSHInductiveEmbedder.embed_item_ids, embedding never
-                             materialised: 16 + 4F + 4D + 4 = 532 algorithmic bytes per lookup)
-`--unfused` runs the same step as the two launches the plugin boundary implies (mi_oov_lsh_embed
-writing [B,64] rows, then mi_oov_rowdot).  Every step uses a fresh id batch (no cache reuse across
-steps); all inputs are resident in HBM before the timed region.  value = lookups (each embedded
-and scored) per second, whole job.
+random ids, user rows f32[B,64].  One STEP = one pass of the hot path over one batch:
+    gather feat[id] -> 8 sign projections -> masked mean of bucket rows -> dot with the user row -> score[b]
+(what BPR.predict returns for OOV items behind LSHInductiveEmbedder.embed_item_ids, embedding never
+materialised: 16 + 4F + 4D + 4 = 532 algorithmic bytes per lookup by SURVEY 8d's formula, 524 of which this
+path moves -- it is handed user ROWS, not user ids).
 
-N > 1: one process per GPU; the 2.56 GB table is REPLICATED (it fits 288 GB HBM 100x over), ranks
-process independent batches and there is no data-path collective -> weak
-scaling.  `--sharded` instead row-shards the table and exchanges ids/rows with RCCL all-to-all.
+The K timed steps are K distinct id batches queued to mi_oov_lsh_embed_score_multi (csrc/lsh64p.hip): ONE
+persistent launch per `--batches-per-launch` steps, whose waves walk the tiles of all queued batches with the ids
+/ rows of the next tiles already requested (what a serving loop with K batches in its queue calls).
+`--per-batch` launches every step separately (mi_oov_lsh_embed_score, K launches in one HIP graph: the round-1
+headline); `--unfused` runs the two launches the plugin boundary implies (mi_oov_lsh_embed writing [B,64] rows,
+then mi_oov_rowdot).  Every step has its own id batch, the user rows come from a ring of >= 1 GiB (4x the
+256 MiB Infinity Cache) and the clock ramp runs on batches of its own, so nothing the timed region reads has been
+touched recently; all inputs are resident in HBM before the timed region.  value = lookups (each embedded and
+scored) per second, whole job.
 
-The JSON line also carries `roofline` (dominant kernel = the fused lsh kernel, HBM-bound,
-algorithmic bytes 8+4F+4D = 520 B per lookup, timed with HIP events on its own stream inside the
-timed region) and, at N=1, `cpu_baseline` (the reference's torch-CPU op sequence on the host).
+N > 1: `python bench.py --gpus N` starts the N ranks itself (one process per GPU, RCCL) when no launcher did.
+Default N > 1 table mode is `--table sharded` (feature table row-sharded, ids out / codes back
+by RCCL all-to-all); the replicated-table figure (no data-path collective) is reported beside it as `replicated`.
+
+The JSON line also carries `roofline` (dominant kernel, HBM-bound, timed with HIP events on its own stream inside
+the timed region) and, at N=1, `cpu_baseline` (the reference's torch-CPU op sequence on the host).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -36,47 +42,81 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
+INFINITY_CACHE = 256 << 20
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    # defaults: 20000 timed steps = 0.17 s on the GPU, so that the two barrier + synchronize fences around the timed
-    # region (~0.9 ms together) stay below 1 % of it; 22000 distinct id batches = 11.5 GB of the 288 GB
+    # defaults: 20000 timed steps = 0.11 s on the GPU, so that the two barrier + synchronize fences around the timed
+    # region stay below 1 % of it; 22000 distinct id batches = 11.5 GB of the 288 GB
     ap.add_argument("--steps", type=int, default=20000)
     ap.add_argument("--warmup", type=int, default=2000)
+    ap.add_argument("--batches-per-launch", type=int, default=1000,
+                    help="steps queued to one persistent launch (the whole run when --steps is smaller)")
     ap.add_argument("--ramp-seconds", type=float, default=1.0,
                     help="untimed pre-warm-up that lets the GPU leave its idle clock (sclk idles at ~500 MHz and "
-                         "needs tens of ms of load to ramp; 200 x 11 us steps alone are over before it does)")
+                         "needs tens of ms of load to ramp); runs on id batches and user rows of its own")
     ap.add_argument("--items", type=int, default=10_000_000)
     ap.add_argument("--feat", type=int, default=64)
     ap.add_argument("--dim", type=int, default=64)
     ap.add_argument("--hashes", type=int, default=8)
     ap.add_argument("--batch", type=int, default=65536)
-    ap.add_argument("--sharded", action="store_true", help="row-shard the table + RCCL all-to-all exchange")
-    ap.add_argument("--unfused", action="store_true", help="two launches (lsh_embed + rowdot) instead of the fused kernel")
+    ap.add_argument("--ring-mib", type=int, default=1024, help="size of the ring of user-row buffers")
+    ap.add_argument("--table", choices=["sharded", "replicated"], default="sharded",
+                    help="N > 1: row-shard the feature table + RCCL all-to-all (default), or replicate it per GPU")
+    ap.add_argument("--sharded", action="store_true", help="same as --table sharded (kept for round-1 command lines)")
+    ap.add_argument("--per-batch", action="store_true", help="one launch per step (K launches in one HIP graph)")
+    ap.add_argument("--unfused", action="store_true", help="two launches per step (lsh_embed + rowdot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="launch every step from Python instead of replaying one HIP graph of the K launches")
-    ap.add_argument("--in-flight", type=int, default=4,
-                    help="N=1 only: after the timed region, also measure the same K steps with this many batches "
-                         "allowed to overlap (one graph chain per stream) and report it as `pipelined` (0 = skip)")
+    ap.add_argument("--no-graph", action="store_true", help="with --per-batch: launch every step from Python")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     return ap.parse_args()
 
 
-def make_inputs(args, dev, rank, n_rows, row_offset=0):
-    """Deterministic synthetic tables, generated on the device in chunks."""
+def spawn_ranks(args):
+    """`python bench.py --gpus N` from a bare shell: start the N ranks as CHILD processes -- before this process has
+    made a single GPU call -- with the rendezvous environment torch.distributed.run would have set, wait for them, and
+    exit with the first failure.  Rank 0 prints the JSON line to our stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    if rc:  # a rank that died leaves the others in a collective: end them
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def make_inputs(args, dev, n_rows, row_offset=0):
+    """Deterministic synthetic tables, generated on the device in chunks (row r gets the same values whichever rank
+    and shard holds it)."""
     g = torch.Generator(device=dev)
     feat = torch.empty((n_rows, args.feat), dtype=torch.float32, device=dev)
     chunk = 1 << 20
-    for lo in range(0, n_rows, chunk):
-        hi = min(n_rows, lo + chunk)
-        g.manual_seed(1_000_003 * ((row_offset + lo) // chunk) + 0)
-        x = torch.randn((hi - lo, args.feat), generator=g, device=dev)
+    lo = 0
+    while lo < n_rows:
+        glo = row_offset + lo
+        c0 = glo // chunk
+        hi = min(n_rows, lo + (c0 + 1) * chunk - glo)
+        g.manual_seed(1_000_003 * c0)
+        x = torch.randn((chunk, args.feat), generator=g, device=dev)
+        x = x[glo - c0 * chunk: glo - c0 * chunk + (hi - lo)]
         feat[lo:hi] = torch.nn.functional.normalize(x, dim=-1)
+        lo = hi
     g.manual_seed(1)
     planes = torch.randn((args.hashes, args.feat), generator=g, device=dev)
     g.manual_seed(2)
@@ -123,66 +163,39 @@ def cpu_baseline(args, feat, planes, buckets, seconds):
                       f"sequence (oracle/ref_torch.py), {t_total:.1f} s, torch.set_num_threads({cores})"}
 
 
-def pipelined(args, step, per_lookup):
-    """The same K steps with `--in-flight` batches allowed to overlap: one HIP-graph chain per stream, replayed
-    together.  NOT the headline (`value` times the K steps serialised, as the contract's single-stream HIP-event
-    timing implies); it shows what the same kernel delivers to a serving loop that keeps several batches in
-    flight: the launch -> ids -> rows -> store chain of one batch hides under the row traffic of the others."""
-    C, K, B = min(args.in_flight, args.steps), args.steps, args.batch
-    if C < 2:
-        return None
-    with torch.no_grad():
-        streams = [torch.cuda.Stream() for _ in range(C)]
-        graphs = []
-        for c, s in enumerate(streams):
-            gr = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gr, stream=s):
-                for k in range(c, K, C):
-                    step(args.warmup + k)
-            graphs.append(gr)
-        times = []
-        for _ in range(5):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for gr, s in zip(graphs, streams):
-                with torch.cuda.stream(s):
-                    gr.replay()
-            torch.cuda.synchronize()
-            times.append(time.perf_counter() - t0)
-    dt = sorted(times)[len(times) // 2]
-    return {"batches_in_flight": C, "value": K * B / dt, "unit": "lookups/s", "us_per_step": dt / K * 1e6,
-            "achieved": K * B * per_lookup / dt / 1e9, "achieved_unit": "GB/s (algorithmic)", "timing": "host clock around "
-            "one concurrent replay of the C graph chains (median of 5), K steps in total"}
-
-
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
-    (profiles/*_bench_summary.json, written by tools/summarize_profile.py from separate --pmc
-    FETCH_SIZE / --pmc WRITE_SIZE runs of this same command).  FETCH_SIZE/WRITE_SIZE are in KiB; on
-    gfx950 FETCH_SIZE reports half of the bytes of 16-B-per-lane reads (MI355X_MICROARCH.md, HBM
-    section), hence the factor 2.  None when no profile is committed for this kernel."""
+def pmc_traffic(kernel, args):
+    """HBM bytes per BATCH of the dominant kernel from the committed rocprofv3 PMC passes (profiles/*_bench_summary.json,
+    written by tools/summarize_profile.py from separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this command).
+    FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the bytes of 16-B-per-lane reads
+    (MI355X_MICROARCH.md, HBM section), hence the factor 2.  Only a profile of the SAME kernel on the SAME shape is
+    used (the newest one); returns (bytes_per_batch, source file) or (None, None)."""
     import glob
-    best = None
+    shape = {"items": args.items, "feat": args.feat, "dim": args.dim, "hashes": args.hashes, "batch": args.batch}
+    best = (None, None)
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*_bench_summary.json"))):
         try:
             d = json.load(open(f))
         except (OSError, ValueError):
             continue
+        if d.get("shape") != shape:
+            continue
         for k, v in d.get("pmc_per_launch", {}).items():
-            if k.startswith(kernel_prefix.rstrip(">")) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-                best = (2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0
+            if k.startswith(kernel.split("<")[0]) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+                per_launch = (2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0
+                best = (per_launch / max(1, int(v.get("batches_per_launch", 1))), os.path.relpath(f, ROOT))
     return best
 
 
 def main():
     args = parse()
+    if args.sharded:
+        args.table = "sharded"
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
+    args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
     dev_index = 0 if args.single_device else local_rank
@@ -198,44 +211,12 @@ def main():
     ctl_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")  # where control tensors live
 
     import mi_oov  # noqa: F401
-    from mi_oov import ops, sharded
+    from mi_oov import ops
 
     B, D, F, H, N = args.batch, args.dim, args.feat, args.hashes, args.items
-    if args.sharded and world > 1:
-        lo, hi, per = sharded.shard_bounds(N, world, rank)
-        feat, planes, buckets = make_inputs(args, dev, rank, hi - lo, lo)
-        table = sharded.ShardedLSHTable(feat, N)
-        embed = lambda ids: table.embed(ids, planes, buckets)  # noqa: E731
-    else:
-        feat, planes, buckets = make_inputs(args, dev, rank, N)
-        embed = lambda ids: ops.lsh_embed(ids, feat, planes, buckets)  # noqa: E731
-
-    total = args.warmup + args.steps
-    g = torch.Generator(device=dev)
-    g.manual_seed(3 + 1000 * rank)
-    all_ids = torch.randint(0, N, (total, B), generator=g, device=dev)
-    g.manual_seed(4 + 1000 * rank)
-    n_user_bufs = 8
-    users = torch.randn((n_user_bufs, B, D), generator=g, device=dev)
-
-    fused = not args.unfused and not (args.sharded and world > 1)
-    # The K timed launches are captured once into a HIP graph (stream capture sees the C-ABI launches, which
-    # go to torch's current stream) and the timed region is ONE replay: the host contributes nothing per
-    # step.  Launched from Python, a step costs ~8.6 us of host time against ~9.5 us on the GPU, so any
-    # host jitter shows up in the number (tools/stability.py).  Same kernels, same K distinct id batches.
-    use_graph = fused and not args.no_graph
-    scores = torch.empty((n_user_bufs, B), dtype=torch.float32, device=dev)
-
-    def step(i, ev=None):
-        ids = all_ids[i]
-        if fused:
-            return ops.lsh_embed_score(ids, feat, planes, buckets, users[i % n_user_bufs], score_out=scores[i % n_user_bufs])
-        if ev:
-            ev[0].record()
-        e = embed(ids)
-        if ev:
-            ev[1].record()
-        return ops.rowdot(users[i % n_user_bufs], e)
+    K, W = args.steps, args.warmup
+    mode = "unfused" if args.unfused else ("per_batch" if args.per_batch else "multi")
+    bpl = max(1, min(args.batches_per_launch, K)) if mode == "multi" else 1
 
     def fence():
         torch.cuda.synchronize()
@@ -243,79 +224,141 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    with torch.no_grad():
-        graph = None
-        if use_graph:
-            for i in range(3):  # first-use initialisation outside the capture
-                step(i % total)
-            torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                for k in range(args.steps):
-                    step(args.warmup + k)
-        # Clock ramp, before the W warm-up steps: keep launching until the time of a burst (256 steps, or one
-        # replay of the graph) has settled (two consecutive bursts within 2 %) and at least --ramp-seconds
-        # have passed; give up after 5 x that.  Untimed; uses the same id batches as the run.
-        t_ramp = time.perf_counter()
-        i, prev = 0, None
-        while True:
-            t_b = time.perf_counter()
-            if graph is not None:
-                graph.replay()
-            else:
-                for _ in range(256):
-                    step(i % total)
-                    i += 1
-            torch.cuda.synchronize()
-            now = time.perf_counter()
-            burst = now - t_b
-            settled = prev is not None and abs(burst - prev) <= 0.02 * burst
-            prev = burst
-            if (settled and now - t_ramp >= args.ramp_seconds) or now - t_ramp >= 5 * args.ramp_seconds:
-                break
-        for i in range(args.warmup):
-            step(i)
-        # HIP events on the launch stream (torch's current stream is the one handed to the C ABI).
-        # Fused: the timed region holds nothing but K launches of the dominant kernel, so one event
-        # pair around the region gives its average launch duration (inter-launch gaps included).
-        # Unfused: one pair around every lsh_embed launch.
-        region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        events = None if fused else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                                     for _ in range(args.steps)]
-        fence()
-        t0 = time.perf_counter()
-        region[0].record()
-        if graph is not None:
-            graph.replay()  # the K captured steps
-        else:
-            for k in range(args.steps):
-                step(args.warmup + k, events[k] if events else None)
-        region[1].record()
-        fence()
-        t1 = time.perf_counter()
+    def reduce_max(x):
+        t = torch.tensor([x], dtype=torch.float64, device=ctl_dev)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
-    elapsed = torch.tensor([t1 - t0], dtype=torch.float64, device=ctl_dev)
-    if fused:
-        kern_ms = region[0].elapsed_time(region[1]) / max(1, args.steps)
-    else:
-        kern_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
-    kern = torch.tensor([kern_ms], dtype=torch.float64, device=ctl_dev)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-        dist.all_reduce(kern, op=dist.ReduceOp.MAX)
-    elapsed_s, kern_ms = float(elapsed.item()), float(kern.item())
+    # ---- inputs ---------------------------------------------------------------------------------------------------
+    n_ramp = 64  # id batches (and as many user buffers) that only the clock ramp touches
+    total = n_ramp + W + K
+    g = torch.Generator(device=dev)
+    g.manual_seed(3 + 1000 * rank)
+    all_ids = torch.randint(0, N, (total, B), generator=g, device=dev)
+    g.manual_seed(4 + 1000 * rank)
+    ring = max(2, -(-(args.ring_mib << 20) // (B * D * 4)))
+    users = torch.randn((ring, B, D), generator=g, device=dev)
+    ramp_users = torch.randn((n_ramp, B, D), generator=g, device=dev)
+    scores = torch.empty((ring, B), dtype=torch.float32, device=dev)
+    # batch i (0 <= i < total): ramp batches first, then the W warm-up steps, then the K timed steps
+    user_of = lambda i: ramp_users[i] if i < n_ramp else users[(i - n_ramp) % ring]  # noqa: E731
+
+    def time_region(run_steps):
+        """ramp -> W warm-up steps -> fence -> K timed steps -> fence.  `run_steps(i0, n)` enqueues steps [i0, i0+n)
+        on the current stream and returns the number of launches of the dominant kernel it made."""
+        with torch.no_grad():
+            t_ramp = time.perf_counter()
+            prev, j = None, 0
+            while True:  # clock ramp on the ramp batches only; settled = two consecutive bursts within 2 %
+                t_b = time.perf_counter()
+                run_steps(0, n_ramp)
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                burst = now - t_b
+                settled = prev is not None and abs(burst - prev) <= 0.02 * burst
+                prev = burst
+                j += 1
+                if (settled and now - t_ramp >= args.ramp_seconds) or now - t_ramp >= 5 * args.ramp_seconds:
+                    break
+            if W:
+                run_steps(n_ramp, W)
+            region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            fence()
+            t0 = time.perf_counter()
+            region[0].record()
+            launches = run_steps(n_ramp + W, K)
+            region[1].record()
+            fence()
+            t1 = time.perf_counter()
+        return reduce_max(t1 - t0), reduce_max(region[0].elapsed_time(region[1])), launches
+
+    def replicated_runner(feat, planes, buckets):
+        """Local table, no collective: the N = 1 path, and the `replicated` figure at N > 1."""
+        if mode == "multi":
+            scorer = ops.LshMultiScorer(feat, planes, buckets)
+            q = ops.LshBatchQueue([all_ids[i] for i in range(total)], [user_of(i) for i in range(total)],
+                                  [scores[i % ring] for i in range(total)])
+
+            def run_steps(i0, n):
+                launches = 0
+                for k0 in range(i0, i0 + n, bpl):
+                    scorer.run(q, k0, min(bpl, i0 + n - k0))
+                    launches += 1
+                return launches
+            return run_steps, "lsh64_multi_kernel<8>", "mi_oov_lsh_embed_score_multi"
+        if mode == "per_batch":
+            scorer = ops.LshScorer(feat, planes, buckets)
+            graphs = {}
+
+            def run_steps(i0, n):
+                if args.no_graph:
+                    for i in range(i0, i0 + n):
+                        scorer(all_ids[i], user_of(i), score_out=scores[i % ring])
+                    return n
+                if (i0, n) not in graphs:  # the n launches captured once, replayed as one graph
+                    scorer(all_ids[i0], user_of(i0), score_out=scores[i0 % ring])
+                    torch.cuda.synchronize()
+                    gr = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gr):
+                        for i in range(i0, i0 + n):
+                            scorer(all_ids[i], user_of(i), score_out=scores[i % ring])
+                    graphs[(i0, n)] = gr
+                graphs[(i0, n)].replay()
+                return n
+            for span in ((0, n_ramp), (n_ramp, W), (n_ramp + W, K)):  # capture outside the timed region
+                if span[1] and not args.no_graph:
+                    run_steps(*span)
+            torch.cuda.synchronize()
+            return run_steps, "lsh64_kernel<8, true, false, false, false>", "mi_oov_lsh_embed_score"
+
+        def run_steps(i0, n):
+            for i in range(i0, i0 + n):
+                e = ops.lsh_embed(all_ids[i], feat, planes, buckets)
+                ops.rowdot(user_of(i), e)
+            return n
+        return run_steps, "lsh64_kernel<8, false, true, false, false>", "mi_oov_lsh_embed + mi_oov_rowdot"
+
+    per_lookup = (16 + 4 * F + 4 * D + 4) if mode != "unfused" else (8 + 4 * F + 4 * D)
+    moved = per_lookup - 8 if mode != "unfused" else per_lookup
+    sharded_line = None
+    if world > 1 and args.table == "sharded":
+        try:
+            from mi_oov import sharded
+            sharded_line = sharded.bench_sharded(args, dev, rank, world, all_ids, user_of, scores, ring, n_ramp,
+                                                 make_inputs, time_region, ctl_dev)
+        except Exception as e:  # noqa: BLE001 -- the replicated line is still worth printing
+            sharded_line = {"error": f"{type(e).__name__}: {e}"}
+            try:
+                fence()
+            except Exception:  # noqa: BLE001
+                pass
+
+    feat, planes, buckets = make_inputs(args, dev, N)
+    run_steps, kernel, entry = replicated_runner(feat, planes, buckets)
+    elapsed_s, region_ms, launches = time_region(run_steps)
 
     if rank == 0:
-        per_lookup = (16 + 4 * F + 4 * D + 4) if fused else (8 + 4 * F + 4 * D)
-        achieved = (B * per_lookup / (kern_ms * 1e-3)) / 1e9 if kern_ms > 0 else 0.0
+        launch_us = region_ms * 1e3 / max(1, launches)
+        lookups_per_launch = B * K / max(1, launches)
+        achieved = lookups_per_launch * per_lookup / (launch_us * 1e-6) / 1e9 if launch_us > 0 else 0.0
+        rep_value = world * B * K / elapsed_s
+        traffic_batch, traffic_src = pmc_traffic(kernel, args)
+        roofline = {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "bytes_per_lookup": per_lookup,
+                    "bytes_moved_per_lookup": moved, "frac_moved": achieved / HBM_PEAK_GBS * moved / per_lookup,
+                    "lookups_per_launch": lookups_per_launch, "batches_per_launch": K / max(1, launches),
+                    "launches": launches, "avg_launch_us": launch_us, "us_per_batch": region_ms * 1e3 / K,
+                    "traffic": None if traffic_batch is None else traffic_batch * K / max(1, launches),
+                    "traffic_source": traffic_src}
         out = {
             "metric": "OOV embed lookups+scores/sec",
-            "value": world * B * args.steps / elapsed_s,
+            "value": rep_value,
             "unit": "lookups/s",
             "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed_s / args.steps,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": 1e3 * elapsed_s / K,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -324,25 +367,31 @@ def main():
             "config": {"workload": "synthetic lsh hash-gather-aggregate + pairwise score "
                                    f"({N}-item x {F}-feature table, {H} hashes/buckets, {D}-d, batch {B} per GPU)",
                        "items": N, "feat": F, "dim": D, "hashes": H, "batch_per_gpu": B,
-                       "table": "row-sharded + all-to-all" if (args.sharded and world > 1) else "replicated per GPU",
-                       "launches_per_step": "lsh_embed_score" if fused else "lsh_embed + rowdot",
-                       "launch_mode": "one HIP graph of the K launches, replayed once" if use_graph else "one launch per step from the host"},
-            "roofline": {"bound": "hbm", "kernel": "lsh64_kernel<8, true, false, false, false>" if fused else "lsh64_kernel<8, false, true, false, false>",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "bytes_per_lookup": per_lookup, "lookups_per_launch": B, "avg_launch_us": kern_ms * 1e3,
-                         "traffic": None},
+                       "table": "replicated per GPU", "entry_point": entry,
+                       "launch_mode": {"multi": f"persistent launch, {bpl} queued batches per launch",
+                                       "per_batch": "one launch per step" + ("" if args.no_graph else ", one HIP graph of the K launches"),
+                                       "unfused": "two launches per step from the host"}[mode],
+                       "user_row_ring_bytes": ring * B * D * 4, "ranks": world,
+                       "backend": None if world == 1 else ("rccl" if args.dist_backend == "nccl" else args.dist_backend)},
+            "roofline": roofline,
         }
-        out["roofline"]["traffic"] = pmc_traffic(out["roofline"]["kernel"])
-        if world == 1 and use_graph and args.in_flight > 1:
-            try:  # an extra, never allowed to cost the headline line
-                pl = pipelined(args, step, per_lookup)
-            except Exception as e:  # noqa: BLE001
-                pl = {"error": f"{type(e).__name__}: {e}"}
-            if pl is not None:
-                out["pipelined"] = pl
+        if sharded_line is not None and "error" not in sharded_line:
+            # N > 1 headline = the row-sharded table north_star specifies; the replicated figure stays beside it
+            out["replicated"] = {"value": rep_value, "ms_per_step": out["ms_per_step"], "roofline": roofline,
+                                 "table": "replicated per GPU, no data-path collective"}
+            out["value"] = sharded_line["value"]
+            out["ms_per_step"] = sharded_line["ms_per_step"]
+            out["config"]["table"] = sharded_line["table"]
+            out["config"]["entry_point"] = sharded_line["entry_point"]
+            out["config"]["launch_mode"] = sharded_line["launch_mode"]
+            out["roofline"] = sharded_line["roofline"]
+            out["sharded"] = sharded_line.get("detail")
+        elif sharded_line is not None:
+            out["sharded"] = sharded_line
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, feat, planes, buckets, args.cpu_seconds)
+                out["vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             except Exception as e:  # noqa: BLE001 -- the GPU line is still worth printing
                 out["cpu_baseline"] = {"value": None, "unit": "lookups/s", "cores": host_cores(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}

@@ -1,0 +1,345 @@
+// lsh, hot shape F = D = 64, H <= 8, fused with the pairwise score: K batches in ONE persistent launch.
+//
+// What it replaces: K back-to-back launches of lsh64_kernel<H, SCORE> (lsh64.hip), i.e. K times the reference's
+// per-batch op sequence LSHInductiveEmbedder.embed_item_ids (lsh_embedder.py:161-179) + BPR.predict
+// (bpr.py:145-149).  A serialised launch of 65536 lookups spends ~2 of its 8.5 us in a head nothing overlaps
+// (launch ramp, ids hop, first gathered row) and a tail; the row traffic itself moves at ~5.2 TB/s
+// (DESIGN.md section 5).  Here the waves stay resident and walk the tiles of ALL batches (tile t of the launch =
+// 16 consecutive lookups of batch t / tiles_per_batch), software-pipelined three deep per wave:
+//     ids of tile i+2   requested   (one 8-byte load per lane, handed round with row_newbcast)
+//     rows of tile i+1  requested   (4 gathered feature rows + 4 sequential rows of the other side per lane)
+//     tile i            reduced, scored, stored
+// in that ISSUE ORDER: vmcnt retires in order, so a wait for the ids of tile i+2 must not have the rows of tile
+// i+1 queued in front of it.  The arithmetic per lookup is lsh64_embed_row (lsh64_tile.hpp), the same additions in
+// the same order as the per-batch kernel: results are bit-identical (tests/test_gpu_parity.py).
+//
+// Measured on MI355X (tools/multi_bench.cpp: N = 10 M x 64, B = 65536, H = 8, 512 distinct id batches, 1 GiB ring of
+// user rows, so nothing is re-read out of the 256 MiB Infinity Cache; gpurun_out/r02_multi_ab*.log), per batch:
+//   K single launches (lsh64_kernel)                                   9.05 us = 3.85 TB/s of 532 B/lookup
+//   this kernel, weights in VGPRs, 3 waves/SIMD x 4-wave workgroups     6.11 us
+//   + aggregate from the 2^H-row table in LDS (12 waves / CU)           5.86 us
+//   + 2 waves/SIMD, one 8-wave workgroup per CU                         5.73 us  (1-wave-per-SIMD: 6.13)
+//   + non-temporal loads for the sequential rows of the other side      5.45 us = 6.40 TB/s = 0.80 of the 8 TB/s peak
+//     (read once, 16.7 MB per batch: kept out of the caches they leave L2 / Infinity Cache to the gathers; the
+//     same hint on the gathered rows costs 0.15 us)
+//   K = 20 batches per launch 5.6 us, K = 4: 6.5 us (the launch's head and tail are paid once per launch).
+//
+// Scheduling is static (wave g of G takes tiles g, g+G, ...): uniform work per tile, no counter to contend for, and
+// the sequential rows of the other side are then swept by all waves as one moving front (DRAM page locality).
+// Every wave's loop is bounded by the tile count, so the grid always drains.
+#include "common.hpp"
+#include "lsh64_tile.hpp"
+
+namespace mi_oov {
+
+// Developer knobs (tools/multi_bench.sh builds the variants): MI_PW = waves per SIMD the register allocation is
+// bounded for; MI_PWPB = waves per workgroup; MI_PTABLE = 1: the aggregate comes from a per-workgroup table in LDS.
+#ifndef MI_PW
+#define MI_PW 2
+#endif
+#ifndef MI_PWPB
+#define MI_PWPB 8
+#endif
+#ifndef MI_PTABLE
+#define MI_PTABLE 1
+#endif
+constexpr int kPWpb = MI_PWPB, kPBlk = 64 * kPWpb;
+constexpr bool kPTable = MI_PTABLE != 0;
+
+typedef const int64_t __attribute__((address_space(1))) * gptr_i64;
+typedef const float __attribute__((address_space(1))) * gptr_cf32;
+typedef float __attribute__((address_space(1))) * gptr_f32;
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(1))) * gptr_cv4;
+// 16-byte load through a pointer KNOWN to be global: a pointer read from a table in memory is generic to the
+// compiler, and a flat_load counts against lgkmcnt as well as vmcnt, which would serialise the pipeline below
+template <bool NT = false>
+__device__ __forceinline__ float4 gload4(const void* p) {
+  const v4f v = NT ? __builtin_nontemporal_load((gptr_cv4)p) : *(gptr_cv4)p;
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+#ifndef MI_PNT_X
+#define MI_PNT_X 0
+#endif
+#ifndef MI_PNT_U
+#define MI_PNT_U 1
+#endif
+
+struct TilePos {
+  unsigned batch, local;  // wave-uniform
+};
+
+template <int R>
+__device__ __forceinline__ int64_t bcast_id(int64_t v) {  // lane R of every 16-lane row -> the whole row
+  const int lo = __builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x150 + R, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, static_cast<int>(v >> 32), 0x150 + R, 0xF, 0xF, true);
+  return (static_cast<int64_t>(hi) << 32) | static_cast<uint32_t>(lo);
+}
+
+__device__ __forceinline__ void round_ids(int64_t idv, int64_t (&id)[4]) {
+  id[0] = bcast_id<0>(idv);
+  id[1] = bcast_id<1>(idv);
+  id[2] = bcast_id<2>(idv);
+  id[3] = bcast_id<3>(idv);
+}
+
+template <int H>
+__global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_multi_kernel(const int64_t* const* __restrict__ ids_tab,
+                                                                   const float* const* __restrict__ other_tab,
+                                                                   float* const* __restrict__ score_tab, unsigned K,
+                                                                   unsigned B, const float* __restrict__ feat, int64_t N,
+                                                                   const float* __restrict__ planes,
+                                                                   const float* __restrict__ buckets) {
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+  const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned tpb = (B + 15) / 16, nfull = B / 16;
+  const unsigned G = gridDim.x * kPWpb;
+
+  auto advance = [&](TilePos p) {
+    p.local += G;
+    while (p.local >= tpb) {
+      p.local -= tpb;
+      ++p.batch;
+    }
+    return p;
+  };
+  // stage A: the ids of a tile.  Lane (grp, l16) asks for the id of row (l16 & 3) * 4 + grp, i.e. lane r of a row
+  // holds the id of round r (16 distinct addresses = one 128-B line per instruction).
+  auto load_ids = [&](TilePos p) -> int64_t {
+    gptr_i64 idp = (gptr_i64)ids_tab[p.batch];
+    unsigned row = p.local * 16u + (l16 & 3) * 4u + grp;
+    row = row < B ? row : B - 1;  // tail tiles recompute the last row
+    return idp[row];
+  };
+  // stage B: the 4 gathers first (second hop of the ids -> rows chain), the sequential rows of the other side behind
+  auto load_rows = [&](TilePos p, int64_t idv, float4 (&x)[4], float4 (&u)[4]) {
+    int64_t id[4];
+    round_ids(idv, id);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool valid = static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N);
+      x[r] = gload4<MI_PNT_X != 0>(feat + (valid ? id[r] : 0) * 64 + l16 * 4);
+    }
+    asm volatile("" ::: "memory");
+    const char* up = reinterpret_cast<const char*>(other_tab[p.batch]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      unsigned row = p.local * 16u + r * 4u + grp;
+      row = row < B ? row : B - 1;
+      u[r] = gload4<MI_PNT_U != 0>(up + (row * 256u + l16 * 16u));
+    }
+  };
+
+  // Weights.  Plane slices -> VGPRs through LDS (one 16-B load per thread, then ds_read_b128 per lane).
+  // kPTable: the aggregate (bits @ W) / popcount takes only 2^H values, so the workgroup computes all of them once
+  // per launch into LDS (code c, lane slice l -> float4 at (c * 16 + l) * 16 B; 64 KiB at H = 8) with exactly the
+  // per-lookup arithmetic -- fmaf chain over the bucket rows in plane order from +0, one correctly rounded division
+  // (code 0 -> 0/0 -> the reference's NaN row) -- and a lookup becomes one ds_read_b128 at its code: same bits,
+  // no bucket rows in VGPRs, ~45 % fewer VALU instructions per lookup.  A row of the table is 256 B = all 64 banks,
+  // so the bank of a read depends on the lane only: conflict-free whatever the four codes of a wave are.
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [kPTable ? 2^H : H][64] table or buckets, [H][64] planes
+  constexpr int kTabRows = kPTable ? (1 << H) : H;
+  float* splanes = sw + kTabRows * 64;
+  for (int i = threadIdx.x; i < H * 16; i += kPBlk)
+    *reinterpret_cast<float4*>(splanes + i * 4) = *reinterpret_cast<const float4*>(planes + i * 4);
+  if (kPTable) {
+    for (int i = threadIdx.x; i < kTabRows * 16; i += kPBlk) {
+      const int c = i >> 4, l = i & 15;
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      float cnt = 0.f;
+#pragma unroll
+      for (int h = 0; h < H; ++h) {
+        const float bit = ((c >> h) & 1) ? 1.f : 0.f;
+        const float4 w = *reinterpret_cast<const float4*>(buckets + (h * 16 + l) * 4);
+        cnt = cnt + bit;
+        acc.x = __builtin_fmaf(bit, w.x, acc.x);
+        acc.y = __builtin_fmaf(bit, w.y, acc.y);
+        acc.z = __builtin_fmaf(bit, w.z, acc.z);
+        acc.w = __builtin_fmaf(bit, w.w, acc.w);
+      }
+      *reinterpret_cast<float4*>(sw + i * 4) = masked_mean(acc, cnt);
+    }
+  } else {
+    for (int i = threadIdx.x; i < H * 16; i += kPBlk)
+      *reinterpret_cast<float4*>(sw + i * 4) = *reinterpret_cast<const float4*>(buckets + i * 4);
+  }
+  __syncthreads();
+  float4 pw[H], bw[kPTable ? 1 : H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    pw[h] = *reinterpret_cast<const float4*>(splanes + (h * 16 + l16) * 4);
+    if (!kPTable) bw[h] = *reinterpret_cast<const float4*>(sw + (h * 16 + l16) * 4);
+  }
+  // which two planes the lane's bank holds after rows8_sum (t0: planes {0,2,1,3}[bank], t1: 4 + that)
+  const int pl = (((l16 >> 2) & 1) << 1) | (l16 >> 3);
+  const unsigned m0 = 1u << pl, m1 = 16u << pl;
+
+  auto embed = [&](const float4& x) -> float4 {
+    if constexpr (!kPTable) {
+      return lsh64_embed_row<H>(x, pw, bw);
+    } else {
+      unsigned code;
+      if constexpr (H == 8) {
+        float p[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) p[h] = dot4_fma(x, pw[h], 0.f);
+        float t0, t1;
+        rows8_sum(p, t0, t1);
+        // >= 0, +-0 and NaN -> bit 1 (torch_hash.py:57-59); the bank's two bits, then OR over the four banks
+        code = ((t0 < 0.f) ? 0u : m0) | ((t1 < 0.f) ? 0u : m1);
+        code |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(code), 0x124, 0xF, 0xF, false));
+        code |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(code), 0x128, 0xF, 0xF, false));
+      } else {
+        code = 0;
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+          const float sdot = row16_sum(dot4_fma(x, pw[h], 0.f));
+          code |= (sdot < 0.f) ? 0u : (1u << h);
+        }
+      }
+      return *reinterpret_cast<const float4*>(sw + (code * 16u + l16) * 4u);
+    }
+  };
+
+  // stage C: reduce, score and store one tile whose rows were requested a whole iteration ago
+  auto finish = [&](TilePos p, int64_t idv, const float4 (&x)[4], const float4 (&u)[4]) {
+    int64_t id[4];
+    round_ids(idv, id);
+    gptr_f32 sp = (gptr_f32)score_tab[p.batch];
+    const bool full = p.local < nfull;
+    float sc_all = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float4 emb = embed(x[r]);
+      if (!(static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N))) emb = make_float4(qnan(), qnan(), qnan(), qnan());
+      const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
+      if (l16 == r) sc_all = s;  // lane r of the group keeps round r's score
+    }
+    // the tile's 16 contiguous scores in one store (lane r of group grp: row r * 4 + grp)
+    const unsigned row = p.local * 16u + l16 * 4u + grp;
+    if (l16 < 4 && (full || row < B)) sp[row] = sc_all;
+  };
+
+  // The steady-state loop holds NO conditional load: s_waitcnt counts are immediates, so a load that is issued on
+  // one path only would force vmcnt(0) at the join and with it the end of the pipeline.  Waves leave the loop
+  // through the drain blocks below instead.
+  TilePos pa, pb, pn;
+  {
+    const unsigned g = blockIdx.x * kPWpb + wv;
+    pa.batch = g / tpb;
+    pa.local = g - pa.batch * tpb;
+  }
+  if (pa.batch >= K) return;  // (after the barrier above)
+  int64_t ida = load_ids(pa), idb, idn;
+  float4 xa[4], ua[4], xb[4], ub[4];
+  pb = advance(pa);
+  if (pb.batch >= K) {  // one tile only
+    load_rows(pa, ida, xa, ua);
+    finish(pa, ida, xa, ua);
+    return;
+  }
+  idb = load_ids(pb);
+  asm volatile("" ::: "memory");
+  load_rows(pa, ida, xa, ua);
+  for (;;) {
+    // current tile a in (xa, ua), rows requested; ids of tile b requested
+    pn = advance(pb);
+    if (pn.batch >= K) {  // drain: b is the last tile
+      load_rows(pb, idb, xb, ub);
+      asm volatile("" ::: "memory");
+      finish(pa, ida, xa, ua);
+      finish(pb, idb, xb, ub);
+      return;
+    }
+    idn = load_ids(pn);
+    asm volatile("" ::: "memory");
+    load_rows(pb, idb, xb, ub);
+    asm volatile("" ::: "memory");
+    finish(pa, ida, xa, ua);
+    // current tile b in (xb, ub); ids of tile n requested
+    pa = advance(pn);
+    if (pa.batch >= K) {  // drain: n is the last tile
+      load_rows(pn, idn, xa, ua);
+      asm volatile("" ::: "memory");
+      finish(pb, idb, xb, ub);
+      finish(pn, idn, xa, ua);
+      return;
+    }
+    ida = load_ids(pa);
+    asm volatile("" ::: "memory");
+    load_rows(pn, idn, xa, ua);
+    asm volatile("" ::: "memory");
+    finish(pb, idb, xb, ub);
+    // rotate: tile n is current (its rows are in xa, ua), the tile after it has its ids in flight
+    pb = pa; idb = ida;
+    pa = pn; ida = idn;
+  }
+}
+
+// resident workgroups of the persistent kernel on the current device (occupancy x CUs), cached per kernel
+template <int H>
+static int resident_blocks(size_t lds) {
+  static int cached = 0;
+  if (cached > 0) return cached;
+  int dev = 0, per_cu = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lsh64_multi_kernel<H>, kPBlk, lds) != hipSuccess) return 0;
+  if (per_cu < 1 || cus < 1) return 0;
+  cached = per_cu * cus;
+  return cached;
+}
+
+template <int H>
+static int launch_multi(const int64_t* const* ids_tab, const float* const* other_tab, float* const* score_tab, int64_t K,
+                        int64_t B, const float* feat, int64_t N, const float* planes, const float* buckets,
+                        hipStream_t st) {
+  const size_t lds = ((kPTable ? (size_t(1) << H) : size_t(H)) + H) * 64 * sizeof(float);
+  if (int rc = set_lds(lsh64_multi_kernel<H>, lds)) return rc;
+  int resident = resident_blocks<H>(lds);
+  if (const char* e = getenv("MI_OOV_MULTI_BLOCKS")) {  // developer knob: grid size of the persistent launch
+    const int v = atoi(e);
+    if (v > 0) resident = v;
+  }
+  if (resident <= 0) {
+    g_last_hip_error = static_cast<int>(hipGetLastError());
+    return MI_OOV_ERR_LAUNCH;
+  }
+  const int64_t tpb = (B + 15) / 16;
+  // 32-bit tile cursor inside the kernel: at most 2^30 tiles per launch
+  const int64_t kmax = ((int64_t(1) << 30) / tpb) < 1 ? 1 : (int64_t(1) << 30) / tpb;
+  for (int64_t k0 = 0; k0 < K; k0 += kmax) {
+    const int64_t nk = (K - k0 < kmax) ? K - k0 : kmax;
+    const int64_t blocks_needed = (nk * tpb + kPWpb - 1) / kPWpb;
+    const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
+    hipLaunchKernelGGL((lsh64_multi_kernel<H>), dim3(grid), dim3(kPBlk), lds, st, ids_tab + k0, other_tab + k0,
+                       score_tab + k0, static_cast<unsigned>(nk), static_cast<unsigned>(B), feat, N, planes, buckets);
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
+}
+
+}  // namespace mi_oov
+
+extern "C" int mi_oov_lsh_embed_score_multi(const int64_t* const* ids_tab, const float* const* other_tab,
+                                            float* const* score_tab, int64_t K, int64_t B, const float* feat, int64_t N,
+                                            int64_t F, const float* planes, int64_t H, const float* buckets, int64_t D,
+                                            void* stream) {
+  using namespace mi_oov;
+  if (K < 0 || B < 0 || N <= 0) return MI_OOV_ERR_SHAPE;
+  if (K == 0 || B == 0) return MI_OOV_OK;
+  if (!ids_tab || !other_tab || !score_tab || !feat || !planes || !buckets) return MI_OOV_ERR_NULL;
+  // the persistent kernel exists for the register-resident shape only (callers fall back to K single launches)
+  if (F != 64 || D != 64 || H < 1 || H > 8 || B > (int64_t(1) << 23)) return MI_OOV_ERR_SHAPE;
+  if (!aligned16(feat) || !aligned16(planes) || !aligned16(buckets) || (reinterpret_cast<uintptr_t>(ids_tab) & 7u) ||
+      (reinterpret_cast<uintptr_t>(other_tab) & 7u) || (reinterpret_cast<uintptr_t>(score_tab) & 7u))
+    return MI_OOV_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (H) {
+#define MI_CASE(HV) \
+  case HV: return launch_multi<HV>(ids_tab, other_tab, score_tab, K, B, feat, N, planes, buckets, st);
+    MI_CASE(1) MI_CASE(2) MI_CASE(3) MI_CASE(4) MI_CASE(5) MI_CASE(6) MI_CASE(7) MI_CASE(8)
+#undef MI_CASE
+    default: return MI_OOV_ERR_SHAPE;
+  }
+}

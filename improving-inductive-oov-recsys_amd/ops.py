@@ -164,6 +164,103 @@ class LshScorer:
                         C.raw_stream(self._idx))
 
 
+class LshBatchQueue:
+    """K queued batches for the persistent multi-batch launch (mi_oov_lsh_embed_score_multi, csrc/lsh64p.hip).
+
+    The kernel reads three device arrays of K pointers (ids, rows of the other side, scores).  This object validates
+    the K tensors of each kind ONCE, builds those arrays, and keeps every tensor alive until it is dropped:
+
+        q = ops.LshBatchQueue(ids_list, other_list)            # scores allocated here ...
+        q = ops.LshBatchQueue(ids_list, other_list, score_list)  # ... or caller-owned f32[B] buffers
+        scorer.run(q)              # all K batches, one launch
+        scorer.run(q, 5, 20)       # batches 5 .. 24 of the queue (a slice costs nothing: pointer arithmetic)
+
+    Every batch of a queue has the same B; D is the embedder's width."""
+
+    __slots__ = ("ids", "other", "scores", "K", "B", "D", "device", "tab")
+
+    def __init__(self, ids_list, other_list, score_list=None):
+        K = len(ids_list)
+        if K == 0 or len(other_list) != K or (score_list is not None and len(score_list) != K):
+            raise ValueError("LshBatchQueue needs K >= 1 id tensors and as many row (and score) tensors")
+        dev, B = ids_list[0].device, ids_list[0].numel()
+        D = other_list[0].shape[-1]
+        if score_list is None:
+            block = torch.empty((K, B), dtype=torch.float32, device=dev)
+            score_list = [block[k] for k in range(K)]
+        for k in range(K):
+            i, o, s = ids_list[k], other_list[k], score_list[k]
+            for t, dt, nm in ((i, torch.int64, "ids"), (o, torch.float32, "other"), (s, torch.float32, "score")):
+                C.dev_tensor(t, dt, f"{nm}[{k}]")
+                if not t.is_contiguous() or t.device != dev:
+                    raise ValueError(f"{nm}[{k}] must be contiguous and on {dev}")
+            if i.numel() != B or o.shape != (B, D) or s.shape != (B,):
+                raise ValueError(f"batch {k}: need int64[{B}] ids, f32[{B},{D}] rows, f32[{B}] scores")
+            if o.data_ptr() % 16:
+                raise ValueError(f"other[{k}] is not 16-byte aligned")
+        self.ids, self.other, self.scores = list(ids_list), list(other_list), list(score_list)
+        self.K, self.B, self.D, self.device = K, B, D, dev
+        ptrs = [[t.data_ptr() for t in lst] for lst in (self.ids, self.other, self.scores)]
+        self.tab = torch.tensor(ptrs, dtype=torch.int64).to(dev)  # [3, K] device pointers
+
+
+class LshMultiScorer:
+    """lsh_embed_score for K batches in ONE persistent launch.  Static operands validated once (as LshScorer).
+    Shapes the persistent kernel does not serve (F or D != 64, H > 8) run as K single launches: same results."""
+
+    __slots__ = ("feat", "planes", "buckets", "N", "F", "H", "D", "device", "_idx", "_fn", "persistent")
+
+    def __init__(self, feat, planes, buckets):
+        self.feat, self.planes, self.buckets = _f32(feat, "feat"), _f32(planes, "planes"), _f32(buckets, "buckets")
+        (self.N, self.F), self.H, self.D = self.feat.shape, self.planes.shape[0], self.buckets.shape[1]
+        if self.planes.shape[1] != self.F:
+            raise ValueError(f"planes have {self.planes.shape[1]} columns, features have {self.F}")
+        if self.buckets.shape[0] != self.H:
+            raise ValueError(f"lsh needs one bucket row per plane: {self.buckets.shape[0]} vs {self.H}")
+        self.device = self.feat.device
+        self._idx = self.device.index
+        self._fn = C.lib().mi_oov_lsh_embed_score_multi
+        self.persistent = self.F == 64 and self.D == 64 and 1 <= self.H <= 8
+
+    def run(self, q, k0=0, k=None):
+        """Score batches [k0, k0 + k) of the queue (default: all).  Returns the list of score tensors."""
+        k = q.K - k0 if k is None else k
+        if k0 < 0 or k < 0 or k0 + k > q.K:
+            raise ValueError(f"batches [{k0}, {k0 + k}) are not inside a queue of {q.K}")
+        if q.device != self.device or q.D != self.D:
+            raise ValueError(f"queue is for {q.device}, D = {q.D}; scorer for {self.device}, D = {self.D}")
+        if k == 0:
+            return []
+        if not self.persistent or q.B > (1 << 23):
+            for j in range(k0, k0 + k):
+                lsh_embed_score(q.ids[j], self.feat, self.planes, self.buckets, q.other[j], score_out=q.scores[j])
+            return q.scores[k0:k0 + k]
+        base = q.tab.data_ptr()
+        step = q.K * 8
+        if C.current_device() != self._idx:
+            with C.on_device(self.feat):
+                rc = self._launch(base, step, k0, k, q.B)
+        else:
+            rc = self._launch(base, step, k0, k, q.B)
+        if rc:
+            C.check(rc, "mi_oov_lsh_embed_score_multi")
+        return q.scores[k0:k0 + k]
+
+    def _launch(self, base, step, k0, k, B):
+        off = k0 * 8
+        return self._fn(base + off, base + step + off, base + 2 * step + off, k, B, self.feat.data_ptr(), self.N, self.F,
+                        self.planes.data_ptr(), self.H, self.buckets.data_ptr(), self.D, C.raw_stream(self._idx))
+
+
+def lsh_embed_score_multi(ids_list, feat, planes, buckets, other_list, score_out=None):
+    """[lsh_embed_score(ids, feat, planes, buckets, other) for ids, other in zip(ids_list, other_list)] in one
+    persistent launch (every batch the same size).  Returns the list of f32[B] score tensors.  Inference only."""
+    q = LshBatchQueue(ids_list, other_list, score_out)
+    # (the pointer table may be released as soon as the launch is enqueued: torch's caching allocator hands a freed
+    # block only to work that is ordered behind the launch on the same stream)
+    return LshMultiScorer(feat, planes, buckets).run(q)
+
+
 class _LshTrainLookup(torch.autograd.Function):
     """BPR.get_*_embedding with an lsh plugin UNDER AUTOGRAD (bpr.py:48-125 + lsh_embedder.py:133-179), without the
     reference's boolean-mask indexing (each `ids[mask]` is a device -> host sync) and its zeros / scatter / scatter

@@ -102,6 +102,24 @@ int mi_oov_lsh_embed_score(const int64_t* ids, int64_t B,
                            const float* other, float* score,
                            float* out, void* stream);
 
+/* K batches of mi_oov_lsh_embed_score in ONE persistent launch (csrc/lsh64p.hip): what a serving / evaluation
+ * loop that has K batches queued calls instead of K launches.  Replaces K times the reference's op sequence
+ * LSHInductiveEmbedder.embed_item_ids + BPR.predict (R/inductive/lsh_embedder.py:161-179,
+ * R/model/general_recommender/bpr.py:145-149); batch k gives exactly the scores mi_oov_lsh_embed_score gives
+ * for (ids_tab[k], other_tab[k]) -- same arithmetic, same order, bit-identical.
+ *   ids_tab    DEVICE array of K device pointers, each int64[B] (8-byte aligned)
+ *   other_tab  DEVICE array of K device pointers, each f32[B,D] (16-byte aligned rows)
+ *   score_tab  DEVICE array of K device pointers, each f32[B] (written)
+ *   feat, planes, buckets as in mi_oov_lsh_embed (16-byte aligned); every batch has the same B.
+ * Only the register-resident shape is served: F == D == 64, 1 <= H <= 8, B <= 2^23; any other shape returns
+ * MI_OOV_ERR_SHAPE and the caller issues K single launches.  The pointer tables are read by the kernel: they
+ * must stay valid (and unchanged) until the launch has completed on `stream`.                          */
+int mi_oov_lsh_embed_score_multi(const int64_t* const* ids_tab, const float* const* other_tab,
+                                 float* const* score_tab, int64_t K, int64_t B,
+                                 const float* feat, int64_t N, int64_t F,
+                                 const float* planes, int64_t H,
+                                 const float* buckets, int64_t D, void* stream);
+
 /* BPR.get_user_embedding / get_item_embedding with an lsh plugin, one launch
  * (R/model/general_recommender/bpr.py:48-125): rows with id < n_vocab are copied from
  * `table`, the others take the lsh path above on feat[id].

@@ -507,3 +507,90 @@ def test_hot_kernel_chunked_launch_over_8m_lookups(ops, dev):
     r = ops.slsh_embed(ids, feat, p10, big)
     assert torch.equal(r[h:], ops.slsh_embed(ids[h:], feat, p10, big))
     assert torch.equal(ops.slsh_index(ids, feat, p10, 1000)[-5:], ops.slsh_index(ids[-5:], feat, p10, 1000))
+
+
+# ---- K batches in one persistent launch (mi_oov_lsh_embed_score_multi, csrc/lsh64p.hip) --------------------------
+@pytest.mark.parametrize("K,B,N,H", [(1, 1, 7, 8), (1, 16, 9, 8), (3, 63, 100, 8), (2, 4097, 3000, 8), (7, 1000, 500, 8),
+                                     (40, 333, 200, 8), (5, 65, 50, 1), (4, 130, 90, 3), (3, 257, 60, 5), (2, 48, 33, 7),
+                                     (300, 17, 40, 8), (2, 70001, 5000, 8)])
+def test_lsh_multi_vs_oracle(K, B, N, H, oracle, ops, dev):
+    """Every batch of a multi-batch launch equals the oracle's lsh_embed_score of that batch, bit for bit: full and
+    partial tiles, fewer tiles than resident waves and many more, batch boundaries inside a wave's stride,
+    out-of-range ids (NaN score, never a fault), every plane count the persistent kernel serves."""
+    rng = np.random.default_rng(K * 1000 + B)
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    feat[0] = 0  # the padding row: all projections 0 -> all bits 1
+    planes = rng.standard_normal((H, 64), dtype=np.float32)
+    buckets = rng.standard_normal((H, 64), dtype=np.float32)
+    ids = rng.integers(0, N, size=(K, B), dtype=np.int64)
+    ids[0, 0] = 0
+    if B > 5:
+        ids[K - 1, 3] = N + 5
+        ids[0, 4] = -1
+    other = rng.standard_normal((K, B, 64), dtype=np.float32)
+    feat_d, planes_d, buckets_d = T(feat, dev), T(planes, dev), T(buckets, dev)
+    ids_d, other_d = T(ids, dev), T(other, dev)
+    scores = ops.lsh_embed_score_multi([ids_d[k] for k in range(K)], feat_d, planes_d, buckets_d,
+                                       [other_d[k] for k in range(K)])
+    assert len(scores) == K
+    for k in range(K):
+        o_score, _ = oracle.lsh_embed_score(ids[k], feat, planes, buckets, other[k])
+        assert bits_equal(scores[k].cpu().numpy(), o_score), f"batch {k}"
+
+
+def test_lsh_multi_queue_slices_and_fallback(oracle, ops, dev):
+    """A queue can be run in slices (bench.py launches its K steps in chunks); caller-owned score buffers are written
+    and nothing else is; a shape the persistent kernel does not serve goes through K single launches."""
+    rng = np.random.default_rng(5)
+    K, B, N = 9, 200, 300
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    planes = rng.standard_normal((8, 64), dtype=np.float32)
+    buckets = rng.standard_normal((8, 64), dtype=np.float32)
+    ids = rng.integers(0, N, size=(K, B), dtype=np.int64)
+    other = rng.standard_normal((K, B, 64), dtype=np.float32)
+    ids_d, other_d = T(ids, dev), T(other, dev)
+    block = torch.full((K, B + 8), -7.0, dtype=torch.float32, device=dev)
+    outs = [block[k, :B] for k in range(K)]
+    q = ops.LshBatchQueue([ids_d[k] for k in range(K)], [other_d[k] for k in range(K)], outs)
+    scorer = ops.LshMultiScorer(T(feat, dev), T(planes, dev), T(buckets, dev))
+    assert scorer.persistent
+    scorer.run(q, 2, 4)
+    got = block.cpu().numpy()
+    assert (got[:, B:] == -7.0).all() and (got[:2, :B] == -7.0).all() and (got[6:, :B] == -7.0).all()
+    for k in range(2, 6):
+        assert bits_equal(got[k, :B], oracle.lsh_embed_score(ids[k], feat, planes, buckets, other[k])[0])
+    scorer.run(q)
+    got = block.cpu().numpy()
+    for k in range(K):
+        assert bits_equal(got[k, :B], oracle.lsh_embed_score(ids[k], feat, planes, buckets, other[k])[0])
+    with pytest.raises(ValueError):
+        scorer.run(q, 5, 5)
+    # 12 planes: not a persistent-kernel shape
+    planes12 = rng.standard_normal((12, 64), dtype=np.float32)
+    buckets12 = rng.standard_normal((12, 64), dtype=np.float32)
+    s12 = ops.LshMultiScorer(T(feat, dev), T(planes12, dev), T(buckets12, dev))
+    assert not s12.persistent
+    res = s12.run(ops.LshBatchQueue([ids_d[k] for k in range(3)], [other_d[k] for k in range(3)]))
+    for k in range(3):
+        assert bits_equal(res[k].cpu().numpy(), oracle.lsh_embed_score(ids[k], feat, planes12, buckets12, other[k])[0])
+
+
+def test_lsh_multi_raw_cabi_errors(ops, dev):
+    """Status codes of the raw entry point: unsupported shape, NULL table, misaligned table."""
+    import ctypes
+    from mi_oov import _cabi as C
+    lib = C.lib()
+    feat = torch.zeros((10, 64), device=dev)
+    planes = torch.zeros((8, 64), device=dev)
+    buckets = torch.zeros((8, 64), device=dev)
+    tab = torch.zeros((3, 4), dtype=torch.int64, device=dev)
+    st = C.stream_of(feat)
+    fn = lib.mi_oov_lsh_embed_score_multi
+    base, step = tab.data_ptr(), 32
+    args = lambda F, H, D: (base, base + step, base + 2 * step, 1, 16, feat.data_ptr(), 10, F, planes.data_ptr(), H,  # noqa: E731
+                            buckets.data_ptr(), D, st)
+    assert fn(*args(32, 8, 64)) == -2 and fn(*args(64, 9, 64)) == -2 and fn(*args(64, 8, 128)) == -2   # MI_OOV_ERR_SHAPE
+    assert fn(None, base, base, 1, 16, feat.data_ptr(), 10, 64, planes.data_ptr(), 8, buckets.data_ptr(), 64, st) == -1
+    assert fn(base + 4, base, base, 1, 16, feat.data_ptr(), 10, 64, planes.data_ptr(), 8, buckets.data_ptr(), 64, st) == -5
+    assert fn(base, base, base, 0, 16, feat.data_ptr(), 10, 64, planes.data_ptr(), 8, buckets.data_ptr(), 64, st) == 0  # K = 0
+    torch.cuda.synchronize()
