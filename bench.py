@@ -63,6 +63,12 @@ def parse():
     ap.add_argument("--hashes", type=int, default=8)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--ring-mib", type=int, default=1024, help="size of the ring of user-row buffers")
+    ap.add_argument("--batches-per-exchange", type=int, default=32, help="--table sharded: steps carried by one all-to-all")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="developer: run the sharded path at N = 1 too (one-rank RCCL group, self-exchange) to time its kernels")
+    ap.add_argument("--cap-factor", type=float, default=1.0,
+                    help="--table sharded: segment capacity = this multiple of the expected share of an exchange + 8 "
+                         "standard deviations (ids are uniform; the run fails loudly if a segment ever overflows)")
     ap.add_argument("--table", choices=["sharded", "replicated"], default="sharded",
                     help="N > 1: row-shard the feature table + RCCL all-to-all (default), or replicate it per GPU")
     ap.add_argument("--sharded", action="store_true", help="same as --table sharded (kept for round-1 command lines)")
@@ -73,6 +79,7 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-spin", action="store_true", help="do not poll the end event before the closing fence")
     return ap.parse_args()
 
 
@@ -202,8 +209,12 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.force_sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if args.dist_backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
         else:
@@ -222,7 +233,7 @@ def main():
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def reduce_max(x):
         t = torch.tensor([x], dtype=torch.float64, device=ctl_dev)
@@ -269,6 +280,12 @@ def main():
             region[0].record()
             launches = run_steps(n_ramp + W, K)
             region[1].record()
+            if not args.no_spin:
+                # poll the end event instead of sleeping in hipDeviceSynchronize: a blocking wait wakes up tens of us
+                # after the GPU is done, which at --steps 20 (a 0.11 ms region) is a third of the measurement.  The
+                # closing fence below then finds an idle device.
+                while not region[1].query():
+                    pass
             fence()
             t1 = time.perf_counter()
         return reduce_max(t1 - t0), reduce_max(region[0].elapsed_time(region[1])), launches
@@ -286,7 +303,7 @@ def main():
                     scorer.run(q, k0, min(bpl, i0 + n - k0))
                     launches += 1
                 return launches
-            return run_steps, "lsh64_multi_kernel<8>", "mi_oov_lsh_embed_score_multi"
+            return run_steps, "lsh64_persistent_kernel<8, 0, true>", "mi_oov_lsh_embed_score_multi"
         if mode == "per_batch":
             scorer = ops.LshScorer(feat, planes, buckets)
             graphs = {}
@@ -321,18 +338,87 @@ def main():
 
     per_lookup = (16 + 4 * F + 4 * D + 4) if mode != "unfused" else (8 + 4 * F + 4 * D)
     moved = per_lookup - 8 if mode != "unfused" else per_lookup
+    def sharded_runner():
+        """N > 1, `--table sharded`: the feature table row-sharded over the ranks, every rank's batches looked up through
+        the owner-computes exchange (mi_oov.sharded: ids out, 8-byte codes back, both by RCCL all_to_all_single), steps
+        software-pipelined three deep.  One exchange carries `--batches-per-exchange` steps."""
+        from mi_oov import sharded
+        S = max(1, min(args.batches_per_exchange, ring, n_ramp))
+        lo, hi, _ = sharded.shard_bounds(N, world, rank)
+        feat_l, planes_l, buckets_l = make_inputs(args, dev, hi - lo, lo)
+
+        class TimedPrims(sharded.HipPrims):  # HIP events around every launch of the owner kernel
+            events = []
+
+            @staticmethod
+            def codes(local_ids, feat_local, planes_t):
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+                out = sharded.HipPrims.codes(local_ids, feat_local, planes_t)
+                ev[1].record()
+                TimedPrims.events.append(ev)
+                return out
+
+        table = sharded.ShardedLSHTable(feat_l, N, prims=TimedPrims, cap_factor=args.cap_factor, max_batch=S * B)
+        pipe = sharded.LshPipeline(table, planes_l, buckets_l)
+        flat_ids = all_ids.view(-1)
+        ramp_rows, ring_rows, ring_scores = ramp_users.view(-1, D), users.view(-1, D), scores.view(-1)
+
+        def blocks(i0, n):
+            """[i0, i0+n) in exchanges of up to S steps whose user rows are contiguous (cut where the ring wraps)."""
+            out = []
+            while n > 0:
+                if i0 < n_ramp:
+                    take = min(n, S, n_ramp - i0)
+                    rows, sc0 = ramp_rows[i0 * B:(i0 + take) * B], (i0 % ring)
+                    take = min(take, ring - sc0)
+                    rows = ramp_rows[i0 * B:(i0 + take) * B]
+                else:
+                    sc0 = (i0 - n_ramp) % ring
+                    take = min(n, S, ring - sc0)
+                    rows = ring_rows[sc0 * B:(sc0 + take) * B]
+                out.append((flat_ids[i0 * B:(i0 + take) * B], rows, ring_scores[sc0 * B:(sc0 + take) * B]))
+                i0, n = i0 + take, n - take
+            return out
+
+        def run_steps(i0, n):
+            bl = blocks(i0, n)
+            TimedPrims.events = []
+            pipe.run([b[0] for b in bl], [b[1] for b in bl], [b[2] for b in bl])
+            return len(bl)
+
+        elapsed_s, region_ms, n_blocks = time_region(run_steps)
+        torch.cuda.synchronize()
+        owner_ms = reduce_max(sum(a.elapsed_time(b) for a, b in TimedPrims.events) / max(1, len(TimedPrims.events)))
+        dropped = reduce_max(float(table.overflow.item()))  # every rank learns of an overflow on any rank
+        if dropped:
+            raise RuntimeError(f"--cap-factor {args.cap_factor} too tight: a segment overflowed by {int(dropped)} lookups")
+        if rank != 0:
+            return {}
+        owner_bytes = (8 + 4 * F + H) * B * K / n_blocks  # per launch of the owner kernel: ids in, feature rows, codes out
+        achieved = owner_bytes / (owner_ms * 1e-3) / 1e9 if owner_ms > 0 else 0.0
+        return {"value": world * B * K / elapsed_s, "ms_per_step": 1e3 * elapsed_s / K,
+                "table": f"feature table row-sharded over {world} ranks ({hi - lo} rows here), planes + bucket table replicated",
+                "entry_point": "mi_oov_bucket_by_owner + mi_oov_lsh_embed(bits) + mi_oov_lsh_codes_embed",
+                "launch_mode": f"owner-computes exchange, {S} steps per exchange, three exchanges in flight",
+                "roofline": {"bound": "hbm", "kernel": "lsh64_persistent_kernel<8, 1, false> (owner: feature rows -> codes)",
+                             "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                             "bytes_per_lookup": 8 + 4 * F + H, "lookups_per_launch": B * K / n_blocks,
+                             "launches": n_blocks, "avg_launch_us": owner_ms * 1e3, "traffic": None,
+                             "note": "HIP events around each owner-kernel launch; exchanges of neighbouring steps run beside it"},
+                "detail": {"steps_per_exchange": S, "exchanges": n_blocks, "segment_capacity": table.capacity(S * B),
+                           "cap_factor": args.cap_factor, "bytes_on_wire_per_lookup": 8 + H,
+                           "region_ms_hip_events": region_ms, "us_per_step_hip_events": region_ms * 1e3 / K,
+                           "overflowed_lookups": 0}}
+
     sharded_line = None
-    if world > 1 and args.table == "sharded":
+    if (world > 1 or args.force_sharded) and args.table == "sharded":
         try:
-            from mi_oov import sharded
-            sharded_line = sharded.bench_sharded(args, dev, rank, world, all_ids, user_of, scores, ring, n_ramp,
-                                                 make_inputs, time_region, ctl_dev)
+            sharded_line = sharded_runner()
         except Exception as e:  # noqa: BLE001 -- the replicated line is still worth printing
-            sharded_line = {"error": f"{type(e).__name__}: {e}"}
-            try:
-                fence()
-            except Exception:  # noqa: BLE001
-                pass
+            import traceback
+            sharded_line = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().splitlines()[-3:]}
+        torch.cuda.empty_cache()
 
     feat, planes, buckets = make_inputs(args, dev, N)
     run_steps, kernel, entry = replicated_runner(feat, planes, buckets)
@@ -396,7 +482,7 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "lookups/s", "cores": host_cores(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,226 @@
+// Row-sharded tables: the two device-side ends of the owner-computes exchange.
+// New functionality -- the reference has no table sharding (its only multi-GPU mode is DDP replicas,
+// R/trainer/trainer.py:68-72); the arithmetic at both ends is the reference's lsh arithmetic
+// (R/inductive/lsh_embedder.py:133-179), split where the data lives:
+//
+//   requester                                   owner of the feature row
+//   ---------                                   ------------------------
+//   bucket_by_owner: ids -> per-owner send      mi_oov_lsh_embed(bits only): feature row -> H sign bits
+//   segments of LOCAL row numbers + the slot    (the F-wide row never leaves its GPU; 8 B of id in,
+//   each lookup's answer will come back in      H bytes of code out)
+//        ... all_to_all(ids) ...                     ... all_to_all(codes) ...
+//   lsh_codes_embed: code at slot[b] -> masked mean of the (replicated) bucket rows -> score against the
+//   requester's own row of the other side.
+//
+// Segments have a FIXED capacity, so the collective needs no counts from the device (no host sync anywhere in a
+// step); a segment that would overflow drops the lookup (slot -1, NaN result) and leaves the true count in
+// counts[w] > cap for the caller to see.  With cap = B nothing can overflow.
+#include "common.hpp"
+
+namespace mi_oov {
+
+// A workgroup owns a contiguous chunk of the batch and reserves its share of every owner's segment with ONE global
+// atomic per owner (a per-lookup or even per-wave atomic serialises on `world` addresses: 189 us for 1 M lookups;
+// this form: see DESIGN.md section 6).  Two passes over the chunk (the second one re-reads the ids from L2):
+//   pass 1  count the chunk's lookups per owner (wave ballot + popcount, one LDS atomic per wave and owner)
+//           -> thread w reserves counts[w] += n_w and keeps the base
+//   pass 2  the same ballots hand every lookup a position base + (LDS running count) + (rank inside the wave)
+__global__ __launch_bounds__(256) void bucket_by_owner_kernel(const int64_t* __restrict__ ids, int64_t B, int64_t n_rows,
+                                                             int64_t per, int world, int64_t cap, int64_t chunk,
+                                                             int64_t* __restrict__ send, int32_t* __restrict__ slot,
+                                                             int32_t* __restrict__ counts, int32_t* __restrict__ overflow) {
+  extern __shared__ int32_t sh[];  // [world] chunk counts -> running positions, [world] global bases
+  int32_t* s_cnt = sh;
+  int32_t* s_base = sh + world;
+  const int lane = threadIdx.x & 63;
+  for (int w = threadIdx.x; w < world; w += 256) s_cnt[w] = 0;
+  __syncthreads();
+  const int64_t lo = static_cast<int64_t>(blockIdx.x) * chunk;
+  const int64_t hi = (lo + chunk < B) ? lo + chunk : B;
+  const int64_t iters = (chunk + 255) / 256;  // every wave runs every iteration: the ballots need all 64 lanes
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int64_t it = 0; it < iters; ++it) {
+      const int64_t b = lo + it * 256 + threadIdx.x;
+      const bool live = b < hi;
+      const int64_t id = live ? ids[b] : -1;
+      const bool valid = live && static_cast<uint64_t>(id) < static_cast<uint64_t>(n_rows);
+      int owner = 0;
+      if (valid) {
+        const int64_t o = id / per;
+        owner = static_cast<int>(o < world ? o : world - 1);
+      }
+      int32_t my_slot = -2;  // invalid id: never sent, NaN at the requester (as the single-GPU kernel)
+      uint64_t todo = __ballot(valid);
+      while (todo) {
+        const int leader = __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo));
+        const int w = __builtin_amdgcn_readlane(owner, leader);
+        const uint64_t mine = __ballot(valid && owner == w);
+        int32_t base = 0;
+        if (lane == leader) base = atomicAdd(s_cnt + w, static_cast<int32_t>(__builtin_popcountll(mine)));
+        if (pass == 1) {
+          base = __builtin_amdgcn_readlane(base, leader);
+          if (valid && owner == w) {
+            const int64_t pos = static_cast<int64_t>(s_base[w]) + base + __builtin_popcountll(mine & ((uint64_t(1) << lane) - 1));
+            if (pos < cap) {
+              send[static_cast<int64_t>(w) * cap + pos] = id - static_cast<int64_t>(w) * per;  // the owner's LOCAL row
+              my_slot = static_cast<int32_t>(static_cast<int64_t>(w) * cap + pos);
+            } else {
+              my_slot = -1;  // dropped: counts[w] > cap tells the caller
+            }
+          }
+        }
+        todo &= ~mine;
+      }
+      if (pass == 1 && live) slot[b] = my_slot;
+    }
+    __syncthreads();
+    if (pass == 0) {
+      for (int w = threadIdx.x; w < world; w += 256) {
+        const int32_t n = s_cnt[w];
+        const int32_t base = n ? atomicAdd(counts + w, n) : 0;
+        s_base[w] = base;
+        s_cnt[w] = 0;
+        // the largest excess of any segment over its capacity, kept across calls (the caller reads it when it likes)
+        if (overflow && static_cast<int64_t>(base) + n > cap) atomicMax(overflow, static_cast<int32_t>(base + n - cap));
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Requester side: codes u8[M,H] as they came back, slot i32[B] -> emb f32[B,D] and / or score f32[B].
+// A 16-lane row owns a lookup; lane l holds 4-float chunks l, l+16, ... of the output row (the canonical order of
+// DESIGN.md section 4): acc = fmaf(bit_h, W[h][d], acc) for h = 0..H-1 from +0, one IEEE division by the exact count,
+// score = 16-lane tree over the lanes' multiply-then-add chains.  Same operations as lsh_fused_kernel (lsh.hip).
+template <int DC>
+__global__ __launch_bounds__(256) void lsh_codes_embed_kernel(const uint8_t* __restrict__ codes, int64_t M,
+                                                             const int32_t* __restrict__ slot, int64_t B, int H,
+                                                             const float* __restrict__ buckets, int D,
+                                                             const float* __restrict__ other, float* __restrict__ score,
+                                                             float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];  // [H][DC*64], zero padded
+  constexpr int DP = DC * 64;
+  for (int i = threadIdx.x; i < H * DP; i += 256) {
+    const int h = i / DP, e = i - h * DP;
+    sW[i] = (e < D) ? buckets[h * D + e] : 0.f;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const bool vec = (D % 4) == 0;
+  const int64_t ngroups = (B + 3) / 4;  // a wave takes 4 lookups per pass
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wv; g < ngroups; g += static_cast<int64_t>(gridDim.x) * 4) {
+    const int64_t b = g * 4 + grp;
+    const bool live = b < B;
+    const int32_t s = live ? slot[b] : -1;
+    const bool have = s >= 0 && s < M;
+    const uint8_t* crow = codes + static_cast<int64_t>(have ? s : 0) * H;
+    float4 acc[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cnt = 0.f;
+    bool ok = have;
+    for (int h = 0; h < H; ++h) {
+      const uint8_t cb = crow[h];
+      if (cb > 1) ok = false;  // 0xFF: the owner saw an id outside its shard
+      const float bit = (cb == 1) ? 1.f : 0.f;
+      cnt = cnt + bit;
+#pragma unroll
+      for (int c = 0; c < DC; ++c) {
+        const float4 w = *reinterpret_cast<const float4*>(sW + h * DP + (c * 16 + l16) * 4);
+        acc[c].x = __builtin_fmaf(bit, w.x, acc[c].x);
+        acc[c].y = __builtin_fmaf(bit, w.y, acc[c].y);
+        acc[c].z = __builtin_fmaf(bit, w.z, acc[c].z);
+        acc[c].w = __builtin_fmaf(bit, w.w, acc[c].w);
+      }
+    }
+    float sp = 0.f;
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+      const int e = (c * 16 + l16) * 4;
+      float4 emb;
+      emb.x = acc[c].x / cnt;  // 0/0 -> NaN row, as lsh_embedder.py:178
+      emb.y = acc[c].y / cnt;
+      emb.z = acc[c].z / cnt;
+      emb.w = acc[c].w / cnt;
+      if (!ok) emb = make_float4(qnan(), qnan(), qnan(), qnan());
+      if (out && live) {
+        if (vec) store4<true>(out + b * D, e, D, emb);
+        else store4<false>(out + b * D, e, D, emb);
+      }
+      if (score) {
+        const float* orow = other + (live ? b : 0) * D;
+        float4 o = vec ? load4<true>(orow, e, D) : load4<false>(orow, e, D);
+        if (e + 0 >= D) emb.x = 0.f;  // padded tail: exact zeros, as lsh_fused_kernel
+        if (e + 1 >= D) emb.y = 0.f;
+        if (e + 2 >= D) emb.z = 0.f;
+        if (e + 3 >= D) emb.w = 0.f;
+        sp = dot4_muladd(o, emb, sp);
+      }
+    }
+    if (score) {
+      const float tot = row16_sum(sp);
+      if (l16 == 0 && live) score[b] = tot;
+    }
+  }
+}
+
+// lsh64p.hip: the persistent, software-pipelined requester kernel for D = 64, H = 8, score only
+int launch_lsh64_from_codes(const uint8_t* codes, int64_t M, const int32_t* slot, int64_t B, const float* buckets,
+                            const float* other, float* score, hipStream_t st);
+
+}  // namespace mi_oov
+
+extern "C" int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_rows, int64_t rows_per_rank, int64_t world,
+                                      int64_t cap, int64_t* send, int32_t* slot, int32_t* counts, int32_t* overflow,
+                                      void* stream) {
+  using namespace mi_oov;
+  if (B < 0 || n_rows <= 0 || rows_per_rank <= 0 || world <= 0 || world > 1024 || cap <= 0) return MI_OOV_ERR_SHAPE;
+  if (world * cap > (int64_t(1) << 31) - 1) return MI_OOV_ERR_SHAPE;  // slots are int32
+  if (!send || !counts) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // unused entries of a segment are -1: the owner's kernel answers them with a 0xFF code without touching its table
+  if (hipMemsetAsync(send, 0xFF, static_cast<size_t>(world * cap) * sizeof(int64_t), st) != hipSuccess ||
+      hipMemsetAsync(counts, 0, static_cast<size_t>(world) * sizeof(int32_t), st) != hipSuccess) {
+    g_last_hip_error = static_cast<int>(hipGetLastError());
+    return MI_OOV_ERR_LAUNCH;
+  }
+  if (B == 0) return MI_OOV_OK;
+  if (!ids || !slot) return MI_OOV_ERR_NULL;
+  // chunks of >= 1024 lookups, at most ~1024 workgroups: <= 1024 reservations per owner counter
+  int64_t chunk = (B + 1023) / 1024;
+  chunk = (chunk < 1024) ? 1024 : (chunk + 255) / 256 * 256;
+  const int grid = static_cast<int>((B + chunk - 1) / chunk);
+  hipLaunchKernelGGL(bucket_by_owner_kernel, dim3(grid), dim3(256), 2 * world * sizeof(int32_t), st, ids, B, n_rows,
+                     rows_per_rank, static_cast<int>(world), cap, chunk, send, slot, counts, overflow);
+  return check_launch();
+}
+
+extern "C" int mi_oov_lsh_codes_embed(const uint8_t* codes, int64_t M, const int32_t* slot, int64_t B, int64_t H,
+                                      const float* buckets, int64_t D, const float* other, float* score, float* out,
+                                      void* stream) {
+  using namespace mi_oov;
+  if (B < 0 || M < 0 || H <= 0 || D <= 0 || D > 256) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!codes || !slot || !buckets || (!score && !out) || (score && !other)) return MI_OOV_ERR_NULL;
+  if (D % 4 == 0 && ((out && !aligned16(out)) || (other && !aligned16(other)))) return MI_OOV_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (D == 64 && H == 8 && score && !out && M > 0 && (reinterpret_cast<uintptr_t>(codes) & 7u) == 0 && aligned16(buckets))
+    return launch_lsh64_from_codes(codes, M, slot, B, buckets, other, score, st);
+  const int dc = static_cast<int>((D + 63) / 64);
+  const int dcq = dc <= 1 ? 1 : (dc <= 2 ? 2 : 4);
+  const size_t lds = static_cast<size_t>(H) * dcq * 64 * sizeof(float);
+  if (static_cast<int64_t>(lds) > kLdsLimit) return MI_OOV_ERR_SHAPE;
+  const int grid = grid_for(B, 16);
+#define MI_GO(DCV)                                                                                                    \
+  {                                                                                                                   \
+    auto k = lsh_codes_embed_kernel<DCV>;                                                                             \
+    if (int rc = set_lds(k, lds)) return rc;                                                                          \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, codes, M, slot, B, static_cast<int>(H), buckets,            \
+                       static_cast<int>(D), other, score, out);                                                       \
+    return check_launch();                                                                                            \
+  }
+  if (dcq == 1) MI_GO(1)
+  if (dcq == 2) MI_GO(2)
+  MI_GO(4)
+#undef MI_GO
+}

@@ -40,6 +40,8 @@
 // latency exposed); per-workgroup 2^H-row code table in LDS replacing aggregate + division (13.2 us
 // with 1024-thread groups, 17.3 us with 256: build + barrier cost more than they save); v_pk_fma_f32
 // math; non-temporal loads; 64 / 128 / 512 / 1024-thread workgroups; user rows requested late.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "lsh64_tile.hpp"
 
@@ -531,6 +533,17 @@ static int launch64_h(const int64_t* ids, int64_t B, const float* feat, int64_t 
 #undef MI_GO
 }
 
+int launch_lsh64_codes_persistent(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes,
+                                  uint8_t* bits, hipStream_t st);  // lsh64p.hip
+constexpr int64_t kCodesMinB = 262144;
+static bool codes_persistent_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("MI_OOV_CODES_PERSISTENT");  // developer A/B knob; default on
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+
 // Host entry used by run_lsh (lsh.hip) when the shape qualifies: F = D = 64, 1 <= H <= 8; `bits` (the u8[B,H] codes,
 // what the training forward keeps for its backward) only with H == 8, no score and no in-vocabulary table.
 int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable, int64_t n_vocab,
@@ -551,6 +564,9 @@ int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, co
   }
   if (bits) {
     if (H != 8 || score || vtable) return MI_OOV_ERR_SHAPE;
+    // codes only, many lookups (the owner side of a sharded table answers a million per exchange): the persistent,
+    // software-pipelined kernel of lsh64p.hip.  Below kCodesMinB a wave has one or two tiles and nothing to pipeline.
+    if (!out && B >= kCodesMinB && codes_persistent_enabled()) return launch_lsh64_codes_persistent(ids, B, feat, N, planes, bits, st);
     if (out) return launch64<8, false, true, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);
     return launch64<8, false, false, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);
   }

@@ -1,17 +1,36 @@
-// lsh, hot shape F = D = 64, H <= 8, fused with the pairwise score: K batches in ONE persistent launch.
+// lsh, hot shape F = D = 64, H <= 8: the PERSISTENT, software-pipelined form of the fused hash-gather-aggregate.
 //
-// What it replaces: K back-to-back launches of lsh64_kernel<H, SCORE> (lsh64.hip), i.e. K times the reference's
-// per-batch op sequence LSHInductiveEmbedder.embed_item_ids (lsh_embedder.py:161-179) + BPR.predict
-// (bpr.py:145-149).  A serialised launch of 65536 lookups spends ~2 of its 8.5 us in a head nothing overlaps
-// (launch ramp, ids hop, first gathered row) and a tail; the row traffic itself moves at ~5.2 TB/s
-// (DESIGN.md section 5).  Here the waves stay resident and walk the tiles of ALL batches (tile t of the launch =
-// 16 consecutive lookups of batch t / tiles_per_batch), software-pipelined three deep per wave:
+//   lsh64_persistent_kernel<H, MODE_SCORE, TAB = true>   K queued batches, fused with the pairwise score
+//       (mi_oov_lsh_embed_score_multi).  Replaces K back-to-back launches of lsh64_kernel<H, SCORE> (lsh64.hip), i.e.
+//       K times the reference's per-batch op sequence LSHInductiveEmbedder.embed_item_ids
+//       (lsh_embedder.py:161-179) + BPR.predict (bpr.py:145-149).
+//   lsh64_persistent_kernel<8, MODE_CODES, TAB = false>  one large batch, codes only (TorchLSHash.hash_points,
+//       torch_hash.py:55-60, over gathered rows): what mi_oov_lsh_embed(bits only) runs for B >= kCodesMinB, e.g. the
+//       owner side of a row-sharded table (sharded.py), which answers a million ids per exchange.
+//   lsh64_persistent_kernel<8, MODE_FROM_CODES, TAB = false>  the REQUESTER side of that exchange for D = 64: the
+//       "feature row" of a lookup is the 8-byte code an owner sent back (at row slot[b] of the answer array), the rest
+//       -- table of aggregates, sequential rows of the other side, score -- is the score mode
+//       (mi_oov_lsh_codes_embed with score only; csrc/exchange.hip holds the general-shape kernel).
+//
+// A serialised launch of 65536 lookups spends ~2 of its 8.5 us in a head nothing overlaps (launch ramp, ids hop,
+// first gathered row) and a tail; the row traffic itself moves at ~5.2 TB/s.  Here the waves
+// stay resident and walk the tiles of ALL batches (tile t of the launch = 16 consecutive lookups of batch
+// t / tiles_per_batch), software-pipelined three deep per wave:
 //     ids of tile i+2   requested   (one 8-byte load per lane, handed round with row_newbcast)
 //     rows of tile i+1  requested   (4 gathered feature rows + 4 sequential rows of the other side per lane)
 //     tile i            reduced, scored, stored
 // in that ISSUE ORDER: vmcnt retires in order, so a wait for the ids of tile i+2 must not have the rows of tile
-// i+1 queued in front of it.  The arithmetic per lookup is lsh64_embed_row (lsh64_tile.hpp), the same additions in
-// the same order as the per-batch kernel: results are bit-identical (tests/test_gpu_parity.py).
+// i+1 queued in front of it.  The steady-state loop holds no conditional load (an s_waitcnt count is an immediate: a
+// load issued on one path only forces vmcnt(0) at the join); waves leave it through drain blocks.
+//
+// The aggregate (bits @ W) / popcount takes only 2^H values, so the workgroup computes all of them once per launch
+// into LDS (code c, lane slice l -> float4 at (c * 16 + l) * 16 B; 64 KiB at H = 8) with exactly the per-lookup
+// arithmetic -- fmaf chain over the bucket rows in plane order from +0, one correctly rounded division (code 0 ->
+// 0/0 -> the reference's NaN row) -- and a lookup becomes one ds_read_b128 at its code: same bits, no bucket rows in
+// VGPRs, ~45 % fewer VALU instructions per lookup.  A row of the table is 256 B = all 64 banks, so the bank of a read
+// depends on the lane only: conflict-free whatever the four codes of a wave are.  Projections: dot4_fma chain per
+// lane + the bank-masked 16-lane tree of lsh64_tile.hpp -- the same additions in the same order as the per-batch
+// kernel, so results are bit-identical (tests/test_gpu_parity.py).
 //
 // Measured on MI355X (tools/multi_bench.cpp: N = 10 M x 64, B = 65536, H = 8, 512 distinct id batches, 1 GiB ring of
 // user rows, so nothing is re-read out of the 256 MiB Infinity Cache; gpurun_out/r02_multi_ab*.log), per batch:
@@ -27,28 +46,35 @@
 // Scheduling is static (wave g of G takes tiles g, g+G, ...): uniform work per tile, no counter to contend for, and
 // the sequential rows of the other side are then swept by all waves as one moving front (DRAM page locality).
 // Every wave's loop is bounded by the tile count, so the grid always drains.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "lsh64_tile.hpp"
 
 namespace mi_oov {
 
-// Developer knobs (tools/multi_bench.sh builds the variants): MI_PW = waves per SIMD the register allocation is
-// bounded for; MI_PWPB = waves per workgroup; MI_PTABLE = 1: the aggregate comes from a per-workgroup table in LDS.
+// Developer knobs (tools/multi_bench.sh builds variants): MI_PW = waves per SIMD the register allocation is bounded
+// for; MI_PWPB = waves per workgroup; MI_PNT_X / MI_PNT_U = non-temporal loads for the gathered / sequential rows.
 #ifndef MI_PW
 #define MI_PW 2
 #endif
 #ifndef MI_PWPB
 #define MI_PWPB 8
 #endif
-#ifndef MI_PTABLE
-#define MI_PTABLE 1
+#ifndef MI_PNT_X
+#define MI_PNT_X 0
+#endif
+#ifndef MI_PNT_U
+#define MI_PNT_U 1
 #endif
 constexpr int kPWpb = MI_PWPB, kPBlk = 64 * kPWpb;
-constexpr bool kPTable = MI_PTABLE != 0;
+constexpr int kModeScore = 0, kModeCodes = 1, kModeFromCodes = 2;
 
 typedef const int64_t __attribute__((address_space(1))) * gptr_i64;
-typedef const float __attribute__((address_space(1))) * gptr_cf32;
 typedef float __attribute__((address_space(1))) * gptr_f32;
+typedef uint32_t v2u __attribute__((ext_vector_type(2)));
+typedef v2u __attribute__((address_space(1))) * gptr_u2;
+typedef const int32_t __attribute__((address_space(1))) * gptr_i32;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const v4f __attribute__((address_space(1))) * gptr_cv4;
 // 16-byte load through a pointer KNOWN to be global: a pointer read from a table in memory is generic to the
@@ -58,12 +84,6 @@ __device__ __forceinline__ float4 gload4(const void* p) {
   const v4f v = NT ? __builtin_nontemporal_load((gptr_cv4)p) : *(gptr_cv4)p;
   return make_float4(v.x, v.y, v.z, v.w);
 }
-#ifndef MI_PNT_X
-#define MI_PNT_X 0
-#endif
-#ifndef MI_PNT_U
-#define MI_PNT_U 1
-#endif
 
 struct TilePos {
   unsigned batch, local;  // wave-uniform
@@ -83,18 +103,33 @@ __device__ __forceinline__ void round_ids(int64_t idv, int64_t (&id)[4]) {
   id[3] = bcast_id<3>(idv);
 }
 
-template <int H>
-__global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_multi_kernel(const int64_t* const* __restrict__ ids_tab,
-                                                                   const float* const* __restrict__ other_tab,
-                                                                   float* const* __restrict__ score_tab, unsigned K,
-                                                                   unsigned B, const float* __restrict__ feat, int64_t N,
-                                                                   const float* __restrict__ planes,
-                                                                   const float* __restrict__ buckets) {
+// TAB: ids_src / other_src / out_src are device arrays of K pointers (one per batch); otherwise they ARE the
+// pointers of the single batch (K = 1).  MODE_SCORE writes f32[B] scores; MODE_CODES writes u8[B,8] codes (H == 8).
+template <int H, int MODE, bool TAB>
+__global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const void* __restrict__ ids_src,
+                                                                        const void* __restrict__ other_src,
+                                                                        void* __restrict__ out_src, unsigned K, unsigned B,
+                                                                        const float* __restrict__ feat, int64_t N,
+                                                                        const float* __restrict__ planes,
+                                                                        const float* __restrict__ buckets) {
+  static_assert(MODE == kModeScore || H == 8, "codes are written as one 8-byte word per lookup");
+  constexpr bool kFromCodes = MODE == kModeFromCodes;  // ids = int32 slots, feat = u8[N,8] codes
+  constexpr bool kScore = MODE == kModeScore || kFromCodes;
+  constexpr int NU = kScore ? 4 : 1;
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
   const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned tpb = (B + 15) / 16, nfull = B / 16;
   const unsigned G = gridDim.x * kPWpb;
 
+  auto ids_of = [&](unsigned batch) -> gptr_i64 {
+    return TAB ? (gptr_i64) reinterpret_cast<const int64_t* const*>(ids_src)[batch] : (gptr_i64)ids_src;
+  };
+  auto other_of = [&](unsigned batch) -> const char* {
+    return TAB ? reinterpret_cast<const char* const*>(other_src)[batch] : reinterpret_cast<const char*>(other_src);
+  };
+  auto out_of = [&](unsigned batch) -> void* {
+    return TAB ? reinterpret_cast<void* const*>(out_src)[batch] : out_src;
+  };
   auto advance = [&](TilePos p) {
     p.local += G;
     while (p.local >= tpb) {
@@ -106,43 +141,62 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_multi_kernel(const int64_t
   // stage A: the ids of a tile.  Lane (grp, l16) asks for the id of row (l16 & 3) * 4 + grp, i.e. lane r of a row
   // holds the id of round r (16 distinct addresses = one 128-B line per instruction).
   auto load_ids = [&](TilePos p) -> int64_t {
-    gptr_i64 idp = (gptr_i64)ids_tab[p.batch];
     unsigned row = p.local * 16u + (l16 & 3) * 4u + grp;
     row = row < B ? row : B - 1;  // tail tiles recompute the last row
+    if constexpr (kFromCodes) return static_cast<int64_t>(((gptr_i32)ids_src)[row]);  // -1 / -2: no answer
+    gptr_i64 idp = ids_of(p.batch);
     return idp[row];
   };
   // stage B: the 4 gathers first (second hop of the ids -> rows chain), the sequential rows of the other side behind
-  auto load_rows = [&](TilePos p, int64_t idv, float4 (&x)[4], float4 (&u)[4]) {
+  auto load_rows = [&](TilePos p, int64_t idv, float4 (&x)[4], float4 (&u)[NU]) {
     int64_t id[4];
     round_ids(idv, id);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const bool valid = static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N);
-      x[r] = gload4<MI_PNT_X != 0>(feat + (valid ? id[r] : 0) * 64 + l16 * 4);
+      if constexpr (kFromCodes) {
+        const v2u c = ((gptr_u2)feat)[valid ? id[r] : 0];  // one address per 16-lane row
+        x[r].x = __uint_as_float(c.x);
+        x[r].y = __uint_as_float(c.y);
+      } else {
+        x[r] = gload4<MI_PNT_X != 0>(feat + (valid ? id[r] : 0) * 64 + l16 * 4);
+      }
     }
-    asm volatile("" ::: "memory");
-    const char* up = reinterpret_cast<const char*>(other_tab[p.batch]);
+    if constexpr (kScore) {
+      asm volatile("" ::: "memory");
+      const char* up = other_of(p.batch);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      unsigned row = p.local * 16u + r * 4u + grp;
-      row = row < B ? row : B - 1;
-      u[r] = gload4<MI_PNT_U != 0>(up + (row * 256u + l16 * 16u));
+      for (int r = 0; r < 4; ++r) {
+        unsigned row = p.local * 16u + r * 4u + grp;
+        row = row < B ? row : B - 1;
+        u[r] = gload4<MI_PNT_U != 0>(up + (row * 256u + l16 * 16u));
+      }
     }
   };
 
-  // Weights.  Plane slices -> VGPRs through LDS (one 16-B load per thread, then ds_read_b128 per lane).
-  // kPTable: the aggregate (bits @ W) / popcount takes only 2^H values, so the workgroup computes all of them once
-  // per launch into LDS (code c, lane slice l -> float4 at (c * 16 + l) * 16 B; 64 KiB at H = 8) with exactly the
-  // per-lookup arithmetic -- fmaf chain over the bucket rows in plane order from +0, one correctly rounded division
-  // (code 0 -> 0/0 -> the reference's NaN row) -- and a lookup becomes one ds_read_b128 at its code: same bits,
-  // no bucket rows in VGPRs, ~45 % fewer VALU instructions per lookup.  A row of the table is 256 B = all 64 banks,
-  // so the bank of a read depends on the lane only: conflict-free whatever the four codes of a wave are.
-  extern __shared__ __attribute__((aligned(16))) float sw[];  // [kPTable ? 2^H : H][64] table or buckets, [H][64] planes
-  constexpr int kTabRows = kPTable ? (1 << H) : H;
+  // The ids of the wave's first two tiles go out before anything else: their round trip (the first hop of the ids ->
+  // rows chain) overlaps the staging of the weights and the table build instead of following them.
+  TilePos pa, pb, pn;
+  {
+    const unsigned g = blockIdx.x * kPWpb + wv;
+    pa.batch = g / tpb;
+    pa.local = g - pa.batch * tpb;
+  }
+  pb = advance(pa);
+  int64_t ida = 0, idb = 0, idn;
+  if (pa.batch < K) ida = load_ids(pa);
+  if (pb.batch < K) idb = load_ids(pb);
+
+  // Weights.  Plane slices -> VGPRs through LDS (one 16-B load per thread, then ds_read_b128 per lane); the 2^H-row
+  // table of aggregates (score mode only) is built next to them.
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [kScore ? 2^H : 0][64] table, [H][64] planes
+  constexpr int kTabRows = kScore ? (1 << H) : 0;
   float* splanes = sw + kTabRows * 64;
-  for (int i = threadIdx.x; i < H * 16; i += kPBlk)
-    *reinterpret_cast<float4*>(splanes + i * 4) = *reinterpret_cast<const float4*>(planes + i * 4);
-  if (kPTable) {
+  if constexpr (!kFromCodes) {
+    for (int i = threadIdx.x; i < H * 16; i += kPBlk)
+      *reinterpret_cast<float4*>(splanes + i * 4) = *reinterpret_cast<const float4*>(planes + i * 4);
+  }
+  if constexpr (kScore) {
     for (int i = threadIdx.x; i < kTabRows * 16; i += kPBlk) {
       const int c = i >> 4, l = i & 15;
       float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -159,87 +213,96 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_multi_kernel(const int64_t
       }
       *reinterpret_cast<float4*>(sw + i * 4) = masked_mean(acc, cnt);
     }
-  } else {
-    for (int i = threadIdx.x; i < H * 16; i += kPBlk)
-      *reinterpret_cast<float4*>(sw + i * 4) = *reinterpret_cast<const float4*>(buckets + i * 4);
   }
   __syncthreads();
-  float4 pw[H], bw[kPTable ? 1 : H];
+  float4 pw[kFromCodes ? 1 : H];
+  if constexpr (!kFromCodes) {
 #pragma unroll
-  for (int h = 0; h < H; ++h) {
-    pw[h] = *reinterpret_cast<const float4*>(splanes + (h * 16 + l16) * 4);
-    if (!kPTable) bw[h] = *reinterpret_cast<const float4*>(sw + (h * 16 + l16) * 4);
+    for (int h = 0; h < H; ++h) pw[h] = *reinterpret_cast<const float4*>(splanes + (h * 16 + l16) * 4);
   }
   // which two planes the lane's bank holds after rows8_sum (t0: planes {0,2,1,3}[bank], t1: 4 + that)
   const int pl = (((l16 >> 2) & 1) << 1) | (l16 >> 3);
   const unsigned m0 = 1u << pl, m1 = 16u << pl;
 
-  auto embed = [&](const float4& x) -> float4 {
-    if constexpr (!kPTable) {
-      return lsh64_embed_row<H>(x, pw, bw);
+  // the H sign bits of one gathered row as an integer, known to all 16 lanes of the row
+  auto code_of = [&](const float4& x) -> unsigned {
+    unsigned code;
+    if constexpr (kFromCodes) {
+      // bytes b0..b3 (each 0 / 1) of a word -> b0 + 2 b1 + 4 b2 + 8 b3: the four products land on bits 24..27 and
+      // every other partial product on a bit of its own below them (no carries)
+      const uint32_t lo = __float_as_uint(x.x), hi = __float_as_uint(x.y);
+      code = ((lo * 0x01020408u) >> 24) | (((hi * 0x01020408u) >> 24) << 4);
+      code &= 0xFFu;
+    } else if constexpr (H == 8) {
+      float p[8];
+#pragma unroll
+      for (int h = 0; h < 8; ++h) p[h] = dot4_fma(x, pw[h], 0.f);
+      float t0, t1;
+      rows8_sum(p, t0, t1);
+      // >= 0, +-0 and NaN -> bit 1 (torch_hash.py:57-59); the bank's two bits, then OR over the four banks
+      code = ((t0 < 0.f) ? 0u : m0) | ((t1 < 0.f) ? 0u : m1);
+      code |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(code), 0x124, 0xF, 0xF, false));
+      code |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(code), 0x128, 0xF, 0xF, false));
     } else {
-      unsigned code;
-      if constexpr (H == 8) {
-        float p[8];
+      code = 0;
 #pragma unroll
-        for (int h = 0; h < 8; ++h) p[h] = dot4_fma(x, pw[h], 0.f);
-        float t0, t1;
-        rows8_sum(p, t0, t1);
-        // >= 0, +-0 and NaN -> bit 1 (torch_hash.py:57-59); the bank's two bits, then OR over the four banks
-        code = ((t0 < 0.f) ? 0u : m0) | ((t1 < 0.f) ? 0u : m1);
-        code |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(code), 0x124, 0xF, 0xF, false));
-        code |= static_cast<unsigned>(__builtin_amdgcn_update_dpp(0, static_cast<int>(code), 0x128, 0xF, 0xF, false));
-      } else {
-        code = 0;
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-          const float sdot = row16_sum(dot4_fma(x, pw[h], 0.f));
-          code |= (sdot < 0.f) ? 0u : (1u << h);
-        }
+      for (int h = 0; h < H; ++h) {
+        const float sdot = row16_sum(dot4_fma(x, pw[h], 0.f));
+        code |= (sdot < 0.f) ? 0u : (1u << h);
       }
-      return *reinterpret_cast<const float4*>(sw + (code * 16u + l16) * 4u);
     }
+    return code;
   };
 
-  // stage C: reduce, score and store one tile whose rows were requested a whole iteration ago
-  auto finish = [&](TilePos p, int64_t idv, const float4 (&x)[4], const float4 (&u)[4]) {
+  // stage C: reduce and store one tile whose rows were requested a whole iteration ago
+  auto finish = [&](TilePos p, int64_t idv, const float4 (&x)[4], const float4 (&u)[NU]) {
     int64_t id[4];
     round_ids(idv, id);
-    gptr_f32 sp = (gptr_f32)score_tab[p.batch];
     const bool full = p.local < nfull;
-    float sc_all = 0.f;
+    const unsigned row = p.local * 16u + l16 * 4u + grp;  // lane r of group grp keeps round r's result
+    if constexpr (kScore) {
+      float sc_all = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      float4 emb = embed(x[r]);
-      if (!(static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N))) emb = make_float4(qnan(), qnan(), qnan(), qnan());
-      const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
-      if (l16 == r) sc_all = s;  // lane r of the group keeps round r's score
+      for (int r = 0; r < 4; ++r) {
+        float4 emb = *reinterpret_cast<const float4*>(sw + (code_of(x[r]) * 16u + l16) * 4u);
+        bool bad = !(static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N));
+        if constexpr (kFromCodes)  // a byte above 1 (0xFF): the owner saw an id outside its shard
+          bad = bad || ((__float_as_uint(x[r].x) | __float_as_uint(x[r].y)) & 0xFEFEFEFEu) != 0;
+        if (bad) emb = make_float4(qnan(), qnan(), qnan(), qnan());
+        const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
+        if (l16 == r) sc_all = s;
+      }
+      // the tile's 16 contiguous scores in one store
+      if (l16 < 4 && (full || row < B)) ((gptr_f32)out_of(p.batch))[row] = sc_all;
+    } else {
+      uint32_t lo_all = 0, hi_all = 0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned c = code_of(x[r]);
+        // byte h of the little-endian 8-byte code row = bit h (0 / 1), 0xFF bytes for an id outside the table
+        uint32_t lo = (c & 1u) | ((c & 2u) << 7) | ((c & 4u) << 14) | ((c & 8u) << 21);
+        uint32_t hi = ((c >> 4) & 1u) | ((c & 32u) << 3) | ((c & 64u) << 10) | ((c & 128u) << 17);
+        if (!(static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N))) lo = hi = 0xFFFFFFFFu;
+        if (l16 == r) {
+          lo_all = lo;
+          hi_all = hi;
+        }
+      }
+      // the tile's 16 code rows (128 contiguous bytes) in one store
+      if (l16 < 4 && (full || row < B)) {
+        v2u v = {lo_all, hi_all};
+        ((gptr_u2)out_of(p.batch))[row] = v;
+      }
     }
-    // the tile's 16 contiguous scores in one store (lane r of group grp: row r * 4 + grp)
-    const unsigned row = p.local * 16u + l16 * 4u + grp;
-    if (l16 < 4 && (full || row < B)) sp[row] = sc_all;
   };
 
-  // The steady-state loop holds NO conditional load: s_waitcnt counts are immediates, so a load that is issued on
-  // one path only would force vmcnt(0) at the join and with it the end of the pipeline.  Waves leave the loop
-  // through the drain blocks below instead.
-  TilePos pa, pb, pn;
-  {
-    const unsigned g = blockIdx.x * kPWpb + wv;
-    pa.batch = g / tpb;
-    pa.local = g - pa.batch * tpb;
-  }
   if (pa.batch >= K) return;  // (after the barrier above)
-  int64_t ida = load_ids(pa), idb, idn;
-  float4 xa[4], ua[4], xb[4], ub[4];
-  pb = advance(pa);
+  float4 xa[4], ua[NU], xb[4], ub[NU];
   if (pb.batch >= K) {  // one tile only
     load_rows(pa, ida, xa, ua);
     finish(pa, ida, xa, ua);
     return;
   }
-  idb = load_ids(pb);
-  asm volatile("" ::: "memory");
   load_rows(pa, ida, xa, ua);
   for (;;) {
     // current tile a in (xa, ua), rows requested; ids of tile b requested
@@ -276,31 +339,36 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_multi_kernel(const int64_t
   }
 }
 
-// resident workgroups of the persistent kernel on the current device (occupancy x CUs), cached per kernel
-template <int H>
-static int resident_blocks(size_t lds) {
-  static int cached = 0;
+// resident workgroups of a persistent kernel on the current device (occupancy x CUs), cached per instantiation
+template <typename Kern>
+static int resident_blocks(Kern kernel, size_t lds, int& cached) {
   if (cached > 0) return cached;
   int dev = 0, per_cu = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, lsh64_multi_kernel<H>, kPBlk, lds) != hipSuccess) return 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kPBlk, lds) != hipSuccess) return 0;
   if (per_cu < 1 || cus < 1) return 0;
   cached = per_cu * cus;
   return cached;
+}
+
+static int grid_override() {
+  static const int v = [] {
+    const char* e = getenv("MI_OOV_MULTI_BLOCKS");  // developer knob: grid size of the persistent launches
+    return e ? atoi(e) : 0;
+  }();
+  return v;
 }
 
 template <int H>
 static int launch_multi(const int64_t* const* ids_tab, const float* const* other_tab, float* const* score_tab, int64_t K,
                         int64_t B, const float* feat, int64_t N, const float* planes, const float* buckets,
                         hipStream_t st) {
-  const size_t lds = ((kPTable ? (size_t(1) << H) : size_t(H)) + H) * 64 * sizeof(float);
-  if (int rc = set_lds(lsh64_multi_kernel<H>, lds)) return rc;
-  int resident = resident_blocks<H>(lds);
-  if (const char* e = getenv("MI_OOV_MULTI_BLOCKS")) {  // developer knob: grid size of the persistent launch
-    const int v = atoi(e);
-    if (v > 0) resident = v;
-  }
+  const size_t lds = ((size_t(1) << H) + H) * 64 * sizeof(float);
+  auto kern = lsh64_persistent_kernel<H, kModeScore, true>;
+  if (int rc = set_lds(kern, lds)) return rc;
+  static int cached = 0;
+  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached);
   if (resident <= 0) {
     g_last_hip_error = static_cast<int>(hipGetLastError());
     return MI_OOV_ERR_LAUNCH;
@@ -312,8 +380,61 @@ static int launch_multi(const int64_t* const* ids_tab, const float* const* other
     const int64_t nk = (K - k0 < kmax) ? K - k0 : kmax;
     const int64_t blocks_needed = (nk * tpb + kPWpb - 1) / kPWpb;
     const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
-    hipLaunchKernelGGL((lsh64_multi_kernel<H>), dim3(grid), dim3(kPBlk), lds, st, ids_tab + k0, other_tab + k0,
-                       score_tab + k0, static_cast<unsigned>(nk), static_cast<unsigned>(B), feat, N, planes, buckets);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(ids_tab + k0),
+                       static_cast<const void*>(other_tab + k0), static_cast<void*>(const_cast<float**>(score_tab + k0)),
+                       static_cast<unsigned>(nk), static_cast<unsigned>(B), feat, N, planes, buckets);
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
+}
+
+// Codes of one large batch (H = 8, F = 64): host entry used by launch_lsh64 (lsh64.hip) for codes-only calls of at
+// least kCodesMinB lookups.  Below that a wave of the per-batch kernel has a single tile and nothing to pipeline.
+int launch_lsh64_codes_persistent(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes,
+                                  uint8_t* bits, hipStream_t st) {
+  const size_t lds = 8 * 64 * sizeof(float);
+  auto kern = lsh64_persistent_kernel<8, kModeCodes, false>;
+  static int cached = 0;
+  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached);
+  if (resident <= 0) {
+    g_last_hip_error = static_cast<int>(hipGetLastError());
+    return MI_OOV_ERR_LAUNCH;
+  }
+  constexpr int64_t kMaxRows = int64_t(1) << 23;  // 32-bit byte offsets into the batch
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxRows) {
+    const int64_t nb = (B - b0 < kMaxRows) ? B - b0 : kMaxRows;
+    const int64_t blocks_needed = ((nb + 15) / 16 + kPWpb - 1) / kPWpb;
+    const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(ids + b0),
+                       static_cast<const void*>(nullptr), static_cast<void*>(bits + b0 * 8), 1u, static_cast<unsigned>(nb),
+                       feat, N, planes, static_cast<const float*>(nullptr));
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
+}
+
+// Requester side of a sharded lookup, D = 64, H = 8, score only: host entry used by mi_oov_lsh_codes_embed
+// (exchange.hip).  codes u8[M,8] (8-byte aligned), slot i32[B], other f32[B,64], score f32[B].
+int launch_lsh64_from_codes(const uint8_t* codes, int64_t M, const int32_t* slot, int64_t B, const float* buckets,
+                            const float* other, float* score, hipStream_t st) {
+  const size_t lds = (256 + 8) * 64 * sizeof(float);
+  auto kern = lsh64_persistent_kernel<8, kModeFromCodes, false>;
+  if (int rc = set_lds(kern, lds)) return rc;
+  static int cached = 0;
+  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached);
+  if (resident <= 0) {
+    g_last_hip_error = static_cast<int>(hipGetLastError());
+    return MI_OOV_ERR_LAUNCH;
+  }
+  constexpr int64_t kMaxRows = int64_t(1) << 23;  // 32-bit byte offsets into the batch
+  for (int64_t b0 = 0; b0 < B; b0 += kMaxRows) {
+    const int64_t nb = (B - b0 < kMaxRows) ? B - b0 : kMaxRows;
+    const int64_t blocks_needed = ((nb + 15) / 16 + kPWpb - 1) / kPWpb;
+    const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(slot + b0),
+                       static_cast<const void*>(other + b0 * 64), static_cast<void*>(score + b0), 1u,
+                       static_cast<unsigned>(nb), reinterpret_cast<const float*>(codes), M,
+                       static_cast<const float*>(nullptr), buckets);
     if (int rc = check_launch()) return rc;
   }
   return MI_OOV_OK;

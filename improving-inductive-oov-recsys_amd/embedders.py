@@ -519,21 +519,21 @@ class MeanEmbedder(AbstractInductiveEmbedder):
 
     @torch.no_grad()
     def embed_user_ids(self, user_ids, model):
+        try:  # the model type is checked on EVERY call, cached mean or not (mean_embedder.py:53-61)
+            w = _general_tables(model)[0]
+        except ValueError:
+            raise ValueError("Invalid model type for mean embedder")
         if self.user_feat_mean is None:
-            try:
-                w = _general_tables(model)[0]
-            except ValueError:
-                raise ValueError("Invalid model type for mean embedder")
             self.user_feat_mean = ops.col_mean(w)
         return ops.broadcast_rows(self.user_feat_mean, len(user_ids))
 
     @torch.no_grad()
     def embed_item_ids(self, item_ids, model):
+        try:  # the model type is checked on EVERY call, cached mean or not (mean_embedder.py:75-87)
+            w = _general_tables(model)[1]
+        except ValueError:
+            raise ValueError("Invalid model type for mean embedder")
         if self.item_feat_mean is None:
-            try:
-                w = _general_tables(model)[1]
-            except ValueError:
-                raise ValueError("Invalid model type for mean embedder")
             self.item_feat_mean = ops.col_mean(w)
         return ops.broadcast_rows(self.item_feat_mean, len(item_ids))
 

@@ -261,6 +261,51 @@ def lsh_embed_score_multi(ids_list, feat, planes, buckets, other_list, score_out
     return LshMultiScorer(feat, planes, buckets).run(q)
 
 
+def bucket_by_owner(ids, n_rows, rows_per_rank, world, cap, overflow=None):
+    """Requester side of a sharded lookup (mi_oov_bucket_by_owner): -> (send int64[world, cap] of owner-local rows,
+    -1 padded; slot int32[B]; counts int32[world]).  `overflow` (int32 scalar tensor, optional) accumulates the largest
+    excess of a segment over `cap`.  Device only, no host synchronisation."""
+    ids = _ids(ids)
+    B = ids.numel()
+    send = torch.empty((world, cap), dtype=torch.int64, device=ids.device)
+    slot = torch.empty((B,), dtype=torch.int32, device=ids.device)
+    counts = torch.empty((world,), dtype=torch.int32, device=ids.device)
+    with C.on_device(ids):
+        rc = C.lib().mi_oov_bucket_by_owner(C.ptr(ids), B, n_rows, rows_per_rank, world, cap, C.ptr(send), C.ptr(slot),
+                                            C.ptr(counts), C.ptr(overflow), C.stream_of(ids))
+    C.check(rc, "mi_oov_bucket_by_owner")
+    return send, slot, counts
+
+
+def lsh_codes_embed(codes, slot, buckets, other=None, want_emb=True, score_out=None):
+    """Requester side of a sharded lsh lookup (mi_oov_lsh_codes_embed): codes u8[M,H] as the owners returned them,
+    slot int32[B] -> (score f32[B] or None, emb f32[B,D] or None), bit-identical to lsh_embed / lsh_embed_score."""
+    codes = C.dev_tensor(codes, torch.uint8, "codes")
+    slot = C.dev_tensor(slot, torch.int32, "slot")
+    buckets = _f32(buckets, "buckets")
+    codes = codes.view(-1, codes.shape[-1])
+    (M, H), B, D = codes.shape, slot.numel(), buckets.shape[1]
+    if buckets.shape[0] != H:
+        raise ValueError(f"lsh needs one bucket row per plane: {buckets.shape[0]} vs {H}")
+    score = None
+    if other is not None:
+        other = _f32(other, "other")
+        if other.shape != (B, D):
+            raise ValueError(f"other must be [{B},{D}], got {tuple(other.shape)}")
+        if score_out is None:
+            score = torch.empty((B,), dtype=torch.float32, device=codes.device)
+        else:
+            score = C.dev_tensor(score_out, torch.float32, "score_out")
+            if score.shape != (B,) or score.data_ptr() != score_out.data_ptr():
+                raise ValueError(f"score_out must be a contiguous f32[{B}] tensor on the device")
+    out = torch.empty((B, D), dtype=torch.float32, device=codes.device) if (want_emb or other is None) else None
+    with C.on_device(codes):
+        rc = C.lib().mi_oov_lsh_codes_embed(C.ptr(codes), M, C.ptr(slot), B, H, C.ptr(buckets), D, C.ptr(other),
+                                            C.ptr(score), C.ptr(out), C.stream_of(codes))
+    C.check(rc, "mi_oov_lsh_codes_embed")
+    return score, out
+
+
 class _LshTrainLookup(torch.autograd.Function):
     """BPR.get_*_embedding with an lsh plugin UNDER AUTOGRAD (bpr.py:48-125 + lsh_embedder.py:133-179), without the
     reference's boolean-mask indexing (each `ids[mask]` is a device -> host sync) and its zeros / scatter / scatter

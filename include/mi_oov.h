@@ -102,6 +102,35 @@ int mi_oov_lsh_embed_score(const int64_t* ids, int64_t B,
                            const float* other, float* score,
                            float* out, void* stream);
 
+/* ---- row-sharded feature tables: the two device-side ends of the owner-computes exchange --------------------
+ * (csrc/exchange.hip; the collective between them is the host's: torch.distributed all_to_all_single = RCCL).
+ * The reference never shards a table (its multi-GPU mode is DDP replicas, R/trainer/trainer.py:68-72); the
+ * arithmetic is R/inductive/lsh_embedder.py:133-179 split where the data lives.
+ *
+ * mi_oov_bucket_by_owner: lookups -> per-owner send segments of FIXED capacity (no counts leave the device, so a
+ * step needs no host synchronisation).  Rank w owns global rows [w*rows_per_rank, (w+1)*rows_per_rank) (the last
+ * rank up to n_rows).
+ *   ids     i64[B]  global row numbers
+ *   send    i64[world*cap]  (written) segment w = the owner-LOCAL rows asked of rank w, unused entries -1
+ *   slot    i32[B]  (written) index into the [world*cap] answer array where lookup b's answer will be;
+ *                   -2: id outside [0, n_rows) (never sent, NaN at the requester); -1: segment full (dropped)
+ *   counts  i32[world]  (written) lookups owned by each rank; counts[w] > cap means lookups were dropped
+ *   overflow i32[1] or NULL  (updated, never reset here) max over all calls of counts[w] - cap when positive: the
+ *                   caller zeroes it once and reads it whenever it chooses to synchronise
+ * Order inside a segment is unspecified (atomics); world*cap must be < 2^31.                              */
+int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_rows, int64_t rows_per_rank, int64_t world,
+                           int64_t cap, int64_t* send, int32_t* slot, int32_t* counts, int32_t* overflow,
+                           void* stream);
+
+/* Requester side of a sharded lsh lookup: the owners returned codes u8[M,H] (mi_oov_lsh_embed with bits only,
+ * 0xFF rows for ids outside their shard); lookup b's code sits at row slot[b].
+ *   emb[b] = (code @ buckets) / popcount  -- same fmaf chain and division as mi_oov_lsh_embed, bit-identical --
+ *   score[b] = sum_d other[b,d] * emb[b,d] (as mi_oov_lsh_embed_score).  NaN where slot[b] < 0 or the code is 0xFF.
+ *   buckets f32[H,D], D <= 256; other f32[B,D] (needed with score); score f32[B] or NULL; out f32[B,D] or NULL.  */
+int mi_oov_lsh_codes_embed(const uint8_t* codes, int64_t M, const int32_t* slot, int64_t B, int64_t H,
+                           const float* buckets, int64_t D, const float* other, float* score, float* out,
+                           void* stream);
+
 /* K batches of mi_oov_lsh_embed_score in ONE persistent launch (csrc/lsh64p.hip): what a serving / evaluation
  * loop that has K batches queued calls instead of K launches.  Replaces K times the reference's op sequence
  * LSHInductiveEmbedder.embed_item_ids + BPR.predict (R/inductive/lsh_embedder.py:161-179,

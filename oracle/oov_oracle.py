@@ -138,6 +138,32 @@ def mapper_map(ids, kind, n_orig, n_buckets):
     return out
 
 
+def bucket_by_owner(ids, n_rows, per, world, cap):
+    """-> (send int64[world, cap], slot int32[B], counts int32[world]); stable order inside a segment."""
+    ids = _i64(ids)
+    send = np.empty((world, cap), np.int64)
+    slot = np.empty((ids.shape[0],), np.int32)
+    counts = np.empty((world,), np.int32)
+    lib().oov_bucket_by_owner(_p(ids), _c(ids.shape[0]), _c(n_rows), _c(per), _c(world), _c(cap), _p(send), _p(slot),
+                              _p(counts))
+    return send, slot, counts
+
+
+def lsh_codes_embed(codes, slot, buckets, other=None):
+    """-> (score or None, emb) from codes u8[M,H] that came back from the owners and the slot of every lookup."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    slot = np.ascontiguousarray(slot, dtype=np.int32)
+    buckets = _f32(buckets)
+    (M, H), D, B = codes.shape, buckets.shape[1], slot.shape[0]
+    out = np.empty((B, D), np.float32)
+    score = None
+    if other is not None:
+        other = _f32(other)
+        score = np.empty((B,), np.float32)
+    lib().oov_lsh_codes_embed(_p(codes), _c(M), _p(slot), _c(B), _c(H), _p(buckets), _c(D), _p(other), _p(score), _p(out))
+    return score, out
+
+
 def gather_mean(idx, W, g=2):
     idx, W = _i64(idx).ravel(), _f32(W)
     M, (N, D) = idx.shape[0], W.shape

@@ -119,3 +119,128 @@ def test_gpu_splice_shapes(oracle, dev):
                                                    C.stream_of(tk))
             assert rc == 0
             assert bits_equal(out.cpu().numpy(), want), (B, nf, D, sum_fields)
+
+
+# ---- BASELINE config 5: knn / mean embedders reading their rows out of the fused token table ------------------------
+# (knn_embedder.py:117-123,135-144, mean_embedder.py:53-60,75-86; fixture: tests/golden/make_golden_context.py knn_mean())
+def _slices(offsets, table):
+    """user / item row windows of the fused table exactly as the reference cuts them."""
+    user = table[offsets[0]:offsets[1]]
+    item = table[offsets[1]:] if len(offsets) == 2 else table[offsets[1]:offsets[2]]
+    return user, item
+
+
+def _km_oov_rows_oracle(z, p, oracle, first_order):
+    table = z[p + ("fo_table" if first_order else "table")]
+    uw, iw = _slices(z[p + "offsets"], table)
+    n_users, n_items = int(z[p + "n_users"]), int(z[p + "n_items"])
+    tok = z[p + "tokens"]
+    nu, ni = int((tok[:, 0] >= n_users).sum()), int((tok[:, 1] >= n_items).sum())
+    if p.startswith("knn"):
+        return oracle.gather_mean(z["knn_user_idx"], uw, 2), oracle.gather_mean(z["knn_item_idx"], iw, 2)
+    D = table.shape[1]
+    return oracle.broadcast_rows(oracle.col_mean(uw), nu, D), oracle.broadcast_rows(oracle.col_mean(iw), ni, D)
+
+
+@pytest.mark.parametrize("p", ["knn_", "mean_", "mean2_"])
+def test_oracle_matches_reference_knn_mean(p, golden, oracle):
+    z = golden("context_knn_mean.npz")
+    assert (len(z[p + "offsets"]) == 2) == (p == "mean2_")
+    n_users, n_items = int(z[p + "n_users"]), int(z[p + "n_items"])
+    for first_order in (False, True):
+        ru, ri = _km_oov_rows_oracle(z, p, oracle, first_order)
+        table = z[p + ("fo_table" if first_order else "table")]
+        got = oracle.token_fields_embed(z[p + "tokens"], z[p + "offsets"], table, n_users, n_items, ru, ri,
+                                        sum_fields=first_order)
+        ref = z[p + ("first" if first_order else "second")].reshape(got.shape)
+        assert np.allclose(got, ref, rtol=1e-5, atol=1e-6)
+
+
+class _Table(torch.nn.Module):
+    def __init__(self, w):
+        super().__init__()
+        self.embedding = torch.nn.Embedding.from_pretrained(w)
+
+
+class _CtxModel(torch.nn.Module):
+    """What the knn / mean embedders read from a context model: the fused table and the field offsets."""
+
+    def __init__(self, w, offsets):
+        super().__init__()
+        self.token_embedding_table = _Table(w)
+        self.token_field_offsets = [int(o) for o in offsets]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("p", ["knn_", "mean_", "mean2_"])
+def test_gpu_knn_mean_through_token_table(p, golden, oracle, dev):
+    import mi_oov
+    from mi_oov import context
+    z = golden("context_knn_mean.npz")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    n_users, n_items = int(z[p + "n_users"]), int(z[p + "n_items"])
+    tokens = T(z[p + "tokens"])
+    for first_order in (False, True):
+        D = 1 if first_order else 16
+        table = T(z[p + ("fo_table" if first_order else "table")])
+        model = _CtxModel(table, z[p + "offsets"])
+        if p == "knn_":
+            ft_u = mi_oov.FeatureTable({"id": torch.arange(z["knn_user_feat"].shape[0]), "f": torch.from_numpy(z["knn_user_feat"])})
+            ft_i = mi_oov.FeatureTable({"id": torch.arange(z["knn_item_feat"].shape[0]), "f": torch.from_numpy(z["knn_item_feat"])})
+            emb = mi_oov.KNNInductiveEmbedder(ft_u, ft_i, n_users, n_items, 8, 8, D, dev, PRIME_PAD, n_neighbors=2)
+            emb.user_feature_mat, emb.item_feature_mat = T(z["knn_user_feat"]), T(z["knn_item_feat"])
+            tok = z[p + "tokens"]
+            uid, iid = tok[:, 0][tok[:, 0] >= n_users], tok[:, 1][tok[:, 1] >= n_items]
+            # exact search here == the exact stand-in that produced the fixture (ScaNN itself: parity unpinned)
+            # Items with identical feature rows tie exactly, and a tie may be broken either way: where the indices
+            # differ the neighbours' inner products must be the same.
+            same = {}
+            for side, ids_s, hashfn in (("user", uid, emb._hash_users), ("item", iid, emb._hash_items)):
+                idx = hashfn(T(ids_s)).cpu().numpy()
+                fx, feat = z["knn_" + side + "_idx"], z["knn_" + side + "_feat"]
+                same[side] = (idx == fx).all(1)
+                q = feat[ids_s]
+                s_mine = np.einsum("bf,bkf->bk", q, feat[idx])
+                s_fix = np.einsum("bf,bkf->bk", q, feat[fx])
+                assert np.allclose(np.sort(s_mine, 1), np.sort(s_fix, 1), rtol=0, atol=1e-6)
+                assert same[side].mean() > 0.8
+            same_u, same_i = same["user"], same["item"]
+        else:
+            ft = mi_oov.FeatureTable({"id": torch.arange(4)})
+            emb = mi_oov.MeanEmbedder(ft, ft, n_users, n_items, 8, 8, D, dev)
+        with torch.no_grad():
+            got = context.embed_token_fields(tokens, table, z[p + "offsets"], n_users, n_items, model, None, emb,
+                                             sum_fields=first_order).cpu().numpy()
+        ref = z[p + ("first" if first_order else "second")]
+        assert got.shape == ref.shape
+        if p == "knn_":  # rows whose neighbours agree with the fixture's
+            tok = z[p + "tokens"]
+            ok = np.ones(len(tok), bool)
+            ok[np.flatnonzero(tok[:, 0] >= n_users)[~same_u]] = False
+            ok[np.flatnonzero(tok[:, 1] >= n_items)[~same_i]] = False
+            assert np.allclose(got[ok], ref[ok], rtol=1e-5, atol=1e-6)
+            ru, ri = _km_oov_rows_oracle(z, p, oracle, first_order)
+            want = oracle.token_fields_embed(z[p + "tokens"], z[p + "offsets"], z[p + ("fo_table" if first_order else "table")],
+                                             n_users, n_items, ru, ri, sum_fields=first_order)
+            assert bits_equal(got.reshape(want.shape)[ok], want[ok])  # kernel vs oracle on identical neighbours: bit-exact
+        else:
+            assert np.allclose(got, ref, rtol=1e-5, atol=1e-6)
+    # unknown model type -> ValueError, as the reference
+    with pytest.raises(ValueError):
+        emb.embed_user_ids(tokens[:3, 0].contiguous(), torch.nn.Linear(2, 2))
+
+
+@pytest.mark.gpu
+def test_gpu_config5_bf16_topk_at_catalogue_size(oracle, dev):
+    """BASELINE config 5's scoring shape: Amazon-Books-sized catalogue (N = 31 094 items), D = 64, the fused
+    bf16-prefilter top-k (exact f32 re-score) against the oracle's exact top-k: identical indices and values."""
+    from mi_oov import ops
+    rng = np.random.default_rng(31094)
+    N, B, D, k = 31094, 512, 64, 10
+    items = rng.standard_normal((N, D), dtype=np.float32)
+    users = rng.standard_normal((B, D), dtype=np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    vals, idx = ops.score_topk(T(users), T(items), k)
+    o_vals, o_idx = oracle.score_topk(users, items, k)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    assert bits_equal(vals.cpu().numpy(), o_vals)

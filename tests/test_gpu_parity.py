@@ -594,3 +594,20 @@ def test_lsh_multi_raw_cabi_errors(ops, dev):
     assert fn(base + 4, base, base, 1, 16, feat.data_ptr(), 10, 64, planes.data_ptr(), 8, buckets.data_ptr(), 64, st) == -5
     assert fn(base, base, base, 0, 16, feat.data_ptr(), 10, 64, planes.data_ptr(), 8, buckets.data_ptr(), 64, st) == 0  # K = 0
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B", [262144, 300001])
+def test_lsh_bits_large_batch_persistent_codes_kernel(B, oracle, ops, dev):
+    """Codes-only calls of >= 262144 lookups (F = 64, H = 8) take the persistent, software-pipelined kernel
+    (lsh64p.hip, MODE_CODES): same bits as the oracle, 0xFF rows for ids outside the table, partial last tile."""
+    rng = np.random.default_rng(B)
+    N = 50_000
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    feat[0] = 0
+    planes = rng.standard_normal((8, 64), dtype=np.float32)
+    ids = rng.integers(0, N, size=B, dtype=np.int64)
+    ids[0], ids[7], ids[B - 1], ids[B // 2] = 0, -1, N, N + 12345
+    bits = ops.lsh_bits(T(ids, dev), T(feat, dev), T(planes, dev)).cpu().numpy()
+    _, o_bits = oracle.lsh_embed(ids, feat, planes, np.zeros((8, 1), np.float32), want_bits=True)
+    assert bits.shape == (B, 8) and np.array_equal(bits, o_bits)
+    assert (bits[7] == 0xFF).all() and (bits[B - 1] == 0xFF).all() and (bits[0] == 1).all()

@@ -268,15 +268,18 @@ def test_full_size_properties(mi, dev):
 
 
 def test_config4_slsh_wide_rows(mi, dev):
-    """BASELINE config 4 shape on ONE GPU (the 77 GB of the 100 M-row case fit 288 GB HBM, so the table
-    is replicated, not sharded; here 20 M rows keep the test short): slsh with 128-d rows gathered from
-    a catalogue-sized bucket table.  Size-independent properties: bucket id == (bits_req + popcount) %
-    n_buckets, output row == bucket row bit for bit, determinism, permutation equivariance."""
+    """BASELINE config 4 at its stated size on ONE GPU: 100 M feature rows x 64 (25.6 GB) + a 100 M x 128 bucket / item
+    table (51.2 GB) = 77 GB of the 288 GB HBM; slsh with 128-d rows gathered from the catalogue-sized table.
+    Size-independent properties: bucket id == (bits_req + popcount) % n_buckets, output row == bucket row bit for
+    bit, determinism, permutation equivariance.  (Row-sharded over ranks: tests/test_gpu_sharded.py.)"""
     from mi_oov import ops
     g = torch.Generator(device=dev).manual_seed(1)
-    N, B, F, D = 20_000_000, 65536, 64, 128
-    feat = torch.randn((N, F), generator=g, device=dev)
-    table = torch.randn((N, D), generator=g, device=dev)
+    N, B, F, D = 100_000_000, 65536, 64, 128
+    feat = torch.empty((N, F), device=dev)
+    table = torch.empty((N, D), device=dev)
+    for lo in range(0, N, 10_000_000):  # generated in place, 10 M rows at a time
+        feat[lo:lo + 10_000_000].normal_(generator=g)
+        table[lo:lo + 10_000_000].normal_(generator=g)
     H = int(np.ceil(np.log2(N)))  # 25 planes
     planes = torch.randn((H, F), generator=g, device=dev)
     ids = torch.randint(0, N, (B,), generator=g, device=dev)
@@ -290,6 +293,13 @@ def test_config4_slsh_wide_rows(mi, dev):
     assert torch.equal(ops.slsh_embed(ids[perm], feat, planes, table), out[perm])
     # the reference's popcount quirk: only bits_req + 1 distinct buckets are reachable
     assert idx.min() >= H and idx.max() <= 2 * H
+    # ids spread over the whole 100 M rows (the last row included) really reach the far end of both tables
+    far = torch.tensor([N - 1, N - 2, 0, N // 2, N], device=dev)
+    out_far = ops.slsh_embed(far, feat, planes, table)
+    idx_far = ops.slsh_index(far, feat, planes, N)
+    assert int(idx_far[4]) == -1 and torch.isnan(out_far[4]).all() and torch.equal(out_far[:4], table[idx_far[:4]])
+    del feat, table
+    torch.cuda.empty_cache()
 
 
 @pytest.mark.parametrize("tag", ["lsh", "slsh8", "slsh200", "knn", "mapper"])

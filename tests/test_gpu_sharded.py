@@ -1,0 +1,194 @@
+"""-m gpu: the row-sharded exchange on real kernels.
+
+* the two device ends (mi_oov_bucket_by_owner, mi_oov_lsh_codes_embed) against the oracle;
+* a world-size-1 RCCL group in this process: ShardedLSHTable / LshPipeline through the real collectives are
+  bit-identical to the unsharded kernels, and a step runs under torch.cuda.set_sync_debug_mode("error");
+* world size 2 on ONE device (gloo rendezvous, exchanges staged through the host -- the 1-GPU box has no second
+  GPU for RCCL): every rank's local compute is the HIP kernels on its row block, results bit-identical to the
+  unsharded kernels for lsh (BASELINE headline shape) and slsh with 128-d rows (BASELINE config 4 shape).
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import mi_oov
+    from mi_oov import ops as _ops
+    assert mi_oov.available()
+    return _ops
+
+
+@pytest.mark.parametrize("B,N,world,cap", [(1, 10, 2, 1), (1000, 777, 8, 1000), (65536, 1_000_003, 8, 9000), (5000, 64, 3, 100),
+                                           (70000, 500, 7, 70000), (300, 1000, 64, 300)])
+def test_bucket_by_owner_properties(B, N, world, cap, oracle, ops, dev):
+    rng = np.random.default_rng(B + world)
+    ids = rng.integers(-3, N + 3, size=B).astype(np.int64)
+    per = -(-N // world)
+    over = torch.zeros((1,), dtype=torch.int32, device=dev)
+    send, slot, counts = (t.cpu().numpy() for t in ops.bucket_by_owner(T(ids, dev), N, per, world, cap, over))
+    o_send, o_slot, o_counts = oracle.bucket_by_owner(ids, N, per, world, cap)
+    assert np.array_equal(counts, o_counts)  # lookups per owner (may exceed cap)
+    assert int(over.item()) == max(0, int(o_counts.max()) - cap)
+    valid = (ids >= 0) & (ids < N)
+    owner = np.minimum(ids // per, world - 1)
+    assert (slot[~valid] == -2).all()
+    placed = valid & (slot >= 0)
+    # as many lookups placed per owner as the oracle places (the rest dropped: slot -1), each in its owner's segment
+    assert np.array_equal(np.bincount(owner[placed], minlength=world), np.minimum(o_counts, cap))
+    assert (slot[valid & ~placed] == -1).all()
+    assert np.array_equal(slot[placed] // cap, owner[placed])
+    assert len(np.unique(slot[placed])) == placed.sum()  # nobody shares a slot
+    flat = send.reshape(-1)
+    assert np.array_equal(flat[slot[placed]], ids[placed] - owner[placed] * per)  # owner-local row numbers
+    assert (flat == -1).sum() == world * cap - placed.sum()  # the rest of every segment is padding
+    for w in range(world):  # a segment is filled from its start
+        n = min(int(o_counts[w]), cap)
+        assert (send[w, :n] >= 0).all() and (send[w, n:] == -1).all()
+        assert np.array_equal(np.sort(send[w, :n]), np.sort(o_send[w, :n])) or o_counts[w] > cap
+
+
+@pytest.mark.parametrize("B,H,D", [(1, 8, 64), (777, 8, 64), (4099, 3, 64), (500, 16, 36), (333, 27, 128), (129, 40, 50),
+                                   (64, 12, 256), (257, 5, 1)])
+def test_lsh_codes_embed_vs_oracle(B, H, D, oracle, ops, dev):
+    rng = np.random.default_rng(B + H)
+    M = B + 50
+    codes = rng.integers(0, 2, size=(M, H)).astype(np.uint8)
+    codes[3 % M] = 0      # an all-zero code: 0/0 -> NaN row
+    codes[7 % M] = 0xFF   # the owner's answer for an id outside its shard
+    slot = rng.permutation(M)[:B].astype(np.int32)
+    if B > 10:
+        slot[5], slot[6], slot[8] = -1, -2, 3 % M
+    buckets = rng.standard_normal((H, D), dtype=np.float32)
+    other = rng.standard_normal((B, D), dtype=np.float32)
+    o_score, o_emb = oracle.lsh_codes_embed(codes, slot, buckets, other)
+    score, emb = ops.lsh_codes_embed(T(codes, dev), T(slot, dev), T(buckets, dev), T(other, dev))
+    assert bits_equal(emb.cpu().numpy(), o_emb) and bits_equal(score.cpu().numpy(), o_score)
+    _, emb2 = ops.lsh_codes_embed(T(codes, dev), T(slot, dev), T(buckets, dev))
+    assert bits_equal(emb2.cpu().numpy(), o_emb)
+    buf = torch.full((B,), -3.0, device=dev)
+    score3, none = ops.lsh_codes_embed(T(codes, dev), T(slot, dev), T(buckets, dev), T(other, dev), want_emb=False, score_out=buf)
+    assert none is None and score3.data_ptr() == buf.data_ptr() and bits_equal(buf.cpu().numpy(), o_score)
+
+
+@pytest.fixture(scope="module")
+def rccl_world1(dev):
+    """A one-rank RCCL process group in the test process: the collectives are real RCCL calls (self-exchange)."""
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1,
+                            device_id=dev)
+    yield
+    dist.destroy_process_group()
+
+
+def test_sharded_world1_rccl_matches_unsharded_and_never_syncs(rccl_world1, ops, dev):
+    from mi_oov import sharded
+    rng = np.random.default_rng(1)
+    N, B = 50_000, 4097
+    feat = T(rng.standard_normal((N, 64), dtype=np.float32), dev)
+    planes = T(rng.standard_normal((8, 64), dtype=np.float32), dev)
+    buckets = T(rng.standard_normal((8, 64), dtype=np.float32), dev)
+    ids_np = rng.integers(0, N, size=B).astype(np.int64)
+    ids_np[5], ids_np[6] = -1, N + 9
+    ids = T(ids_np, dev)
+    other = T(rng.standard_normal((B, 64), dtype=np.float32), dev)
+    table = sharded.ShardedLSHTable(feat, N, max_batch=B)
+    want_emb = ops.lsh_embed(ids, feat, planes, buckets)
+    want_score = ops.lsh_embed_score(ids, feat, planes, buckets, other)
+    assert bits_equal(table.embed(ids, planes, buckets).cpu().numpy(), want_emb.cpu().numpy())  # also warms RCCL up
+    out = torch.empty((B,), device=dev)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")  # any host synchronisation inside the step raises
+    try:
+        table.embed_score(ids, planes, buckets, other, score_out=out)
+        steps = [ids, ids.flip(0).contiguous(), ids.roll(7).contiguous(), ids]
+        oth = [other, other.flip(0).contiguous(), other.roll(7, 0).contiguous(), other]
+        sc = [torch.empty((B,), device=dev) for _ in steps]
+        sharded.LshPipeline(table, planes, buckets).run(steps, oth, sc)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert bits_equal(out.cpu().numpy(), want_score.cpu().numpy())
+    for i, o, s in zip(steps, oth, sc):
+        assert bits_equal(s.cpu().numpy(), ops.lsh_embed_score(i, feat, planes, buckets, o).cpu().numpy())
+    table.check_overflow()
+
+
+def _rank_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    fails = []
+    try:
+        import mi_oov  # noqa: F401
+        from mi_oov import ops, sharded
+        dev = torch.device("cuda:0")  # every rank on the one device of the box
+        g = torch.Generator(device=dev).manual_seed(11)  # same tables on every rank
+        N, B, F = 2_000_003, 65536, 64
+        feat = torch.nn.functional.normalize(torch.randn((N, F), generator=g, device=dev), dim=-1)
+        planes = torch.randn((8, F), generator=g, device=dev)
+        buckets = torch.randn((8, 64), generator=g, device=dev)
+        lo, hi, per = sharded.shard_bounds(N, world, rank)
+        gr = torch.Generator(device=dev).manual_seed(100 + rank)  # every rank its own batch
+        ids = torch.randint(0, N, (B,), generator=gr, device=dev)
+        ids[3], ids[4] = -7, N
+        other = torch.randn((B, 64), generator=gr, device=dev)
+        want_score = ops.lsh_embed_score(ids, feat, planes, buckets, other)
+        want_emb = ops.lsh_embed(ids, feat, planes, buckets)
+        for cap_factor in (None, 1.0):
+            table = sharded.ShardedLSHTable(feat[lo:hi].contiguous(), N, cap_factor=cap_factor, max_batch=B)
+            if not torch.equal(torch.nan_to_num(table.embed(ids, planes, buckets), 7.0), torch.nan_to_num(want_emb, 7.0)):
+                fails.append(f"lsh embed cap_factor={cap_factor}")
+            sc = [torch.empty((B,), device=dev) for _ in range(4)]
+            sharded.LshPipeline(table, planes, buckets).run([ids] * 4, [other] * 4, sc)
+            for s in sc:
+                if not torch.equal(torch.nan_to_num(s, 7.0), torch.nan_to_num(want_score, 7.0)):
+                    fails.append(f"lsh pipeline cap_factor={cap_factor}")
+            table.check_overflow()
+        # BASELINE config 4 shape: slsh, 128-d rows, feature table AND bucket table row-sharded
+        NB, D = N, 128
+        n_pl = int(np.ceil(np.log2(NB)))
+        planes_s = torch.randn((n_pl, F), generator=g, device=dev)
+        big = torch.randn((NB, D), generator=g, device=dev)
+        blo, bhi, _ = sharded.shard_bounds(NB, world, rank)
+        window, win_lo = sharded.ShardedSLSHTable.gather_window(big[blo:bhi].contiguous(), NB, n_pl)
+        st = sharded.ShardedSLSHTable(feat[lo:hi].contiguous(), N, window, win_lo, NB)
+        got, gidx = st.embed(ids, planes_s)
+        want = ops.slsh_embed(ids, feat, planes_s, big)
+        widx = ops.slsh_index(ids, feat, planes_s, NB)
+        if not torch.equal(gidx, widx):
+            fails.append("slsh idx")
+        if not torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want, 7.0)):
+            fails.append("slsh rows")
+        torch.cuda.synchronize()
+        ret[rank] = fails
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world2_single_device_hip_local_compute(dev):
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: [], 1: []}

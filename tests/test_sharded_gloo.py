@@ -1,6 +1,7 @@
 """CPU, world_size 2 (gloo): the N > 1 exchange logic of mi_oov.sharded with the per-rank compute
 injected (the oracle), checked against the unsharded oracle.  Covers ragged splits, ids that all
-live on one rank, empty local batches and the top-k merge."""
+live on one rank, empty local batches, tight capacities that overflow, the software-pipelined
+sequence of steps, the replicated slsh window and the top-k merge."""
 import os
 import socket
 
@@ -15,6 +16,60 @@ def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         return s.getsockname()[1]
+
+
+class OraclePrims:
+    """mi_oov.sharded's local compute with the CPU oracle in the place of the HIP kernels (tests only)."""
+
+    @staticmethod
+    def bucket(ids, n_rows, per, world, cap, overflow):
+        from oracle import oov_oracle as oracle
+        send, slot, counts = oracle.bucket_by_owner(ids.numpy(), n_rows, per, world, cap)
+        overflow[0] = max(int(overflow[0]), int(counts.max()) - cap, 0)
+        return torch.from_numpy(send), torch.from_numpy(slot), torch.from_numpy(counts)
+
+    @staticmethod
+    def codes(local_ids, feat_local, planes):
+        from oracle import oov_oracle as oracle
+        H = planes.shape[0]
+        if feat_local.shape[0] == 0:
+            return torch.full((local_ids.numel(), H), 255, dtype=torch.uint8)
+        _, bits = oracle.lsh_embed(local_ids.numpy(), feat_local.numpy(), planes.numpy(), np.zeros((H, 1), np.float32),
+                                   want_bits=True)
+        return torch.from_numpy(bits)
+
+    @staticmethod
+    def codes_embed(codes, slot, buckets, other, want_emb, score_out=None):
+        from oracle import oov_oracle as oracle
+        score, emb = oracle.lsh_codes_embed(codes.numpy().reshape(-1, codes.shape[-1]), slot.numpy(), buckets.numpy(),
+                                            None if other is None else other.numpy())
+        if score is not None and score_out is not None:
+            score_out.copy_(torch.from_numpy(score))
+            score = score_out
+        elif score is not None:
+            score = torch.from_numpy(score)
+        return score, torch.from_numpy(emb)
+
+    @staticmethod
+    def slsh_index(local_ids, feat_local, planes, n_buckets):
+        from oracle import oov_oracle as oracle
+        if feat_local.shape[0] == 0:
+            return torch.full((local_ids.numel(),), -1, dtype=torch.int64)
+        _, idx = oracle.slsh_embed(local_ids.numpy(), feat_local.numpy(), planes.numpy(), np.zeros((n_buckets, 1), np.float32))
+        return torch.from_numpy(idx)
+
+    @staticmethod
+    def gather_rows(idx, table):
+        li, rows = idx.numpy(), table.numpy()
+        out = np.full((len(li), rows.shape[1]), np.nan, np.float32)
+        okm = (li >= 0) & (li < rows.shape[0])
+        out[okm] = rows[li[okm]]
+        return torch.from_numpy(out)
+
+
+def _same(a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    return a.shape == b.shape and np.array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0))
 
 
 def _worker(rank, world, port, ret):
@@ -32,64 +87,83 @@ def _worker(rank, world, port, ret):
         buckets = rng.standard_normal((H, D), dtype=np.float32)
         lo, hi, per = sharded.shard_bounds(N, world, rank)
         assert per == 501 and (hi - lo) == (501 if rank == 0 else 500)
-
-        def local_embed(local_ids, feat_local, planes_t, buckets_t):
-            out = oracle.lsh_embed(local_ids.numpy(), feat_local.numpy(), planes_t.numpy(), buckets_t.numpy())
-            return torch.from_numpy(out)
-
-        table = sharded.ShardedLSHTable(torch.from_numpy(feat[lo:hi]), N, local_embed=local_embed)
+        T = torch.from_numpy
+        table = sharded.ShardedLSHTable(T(feat[lo:hi]), N, prims=OraclePrims)
         cases = {
             "ragged": np.random.default_rng(10 + rank).integers(0, N, size=300 + 77 * rank),
             "all_on_rank0": np.random.default_rng(20 + rank).integers(0, 400, size=64),
             "all_on_rank1": np.random.default_rng(30 + rank).integers(600, N, size=50),
             "empty_here": np.zeros((0,), np.int64) if rank == 0 else np.arange(900, 1001),
-            "edges": np.array([0, 500, 501, 1000, 500, 0]),
+            "edges": np.array([0, 500, 501, 1000, 500, 0, N + 3, -2]),  # the last two: outside the table -> NaN rows
         }
-        ok = True
+        fails = []
+
+        def chk(line, cond):
+            if not cond:
+                fails.append(line)
+
         for name, ids in cases.items():
             ids = ids.astype(np.int64)
-            got = table.embed(torch.from_numpy(ids), torch.from_numpy(planes), torch.from_numpy(buckets)).numpy()
-            want = oracle.lsh_embed(ids, feat, planes, buckets)
-            same = got.shape == want.shape and np.array_equal(np.nan_to_num(got, nan=7.0), np.nan_to_num(want, nan=7.0))
-            ok = ok and same
-        # slsh over a row-sharded feature table AND a row-sharded bucket table (BASELINE config 4), two exchanges
-        NB, D2 = 777, 20
-        planes_s = rng.standard_normal((10, F), dtype=np.float32)  # bits_req of 777 buckets
-        big = rng.standard_normal((NB, D2), dtype=np.float32)
-        blo, bhi, _ = sharded.shard_bounds(NB, world, rank)
+            got = table.embed(T(ids), T(planes), T(buckets)).numpy()
+            chk(102, _same(got, oracle.lsh_embed(ids, feat, planes, buckets)))
+            other = np.random.default_rng(40 + rank).standard_normal((len(ids), D), dtype=np.float32)
+            sc = table.embed_score(T(ids), T(planes), T(buckets), T(other)).numpy()
+            chk(105, _same(sc, oracle.lsh_embed_score(ids, feat, planes, buckets, other)[0]))
+        chk(106, int(table.overflow) == 0)
+        table.check_overflow()
 
-        def local_index(local_ids, feat_local, planes_t, nb):
-            _, idx = oracle.slsh_embed(local_ids.numpy(), feat_local.numpy(), planes_t.numpy(),
-                                       np.zeros((nb, 1), np.float32))
-            return torch.from_numpy(idx)
+        # a tight capacity with every id on rank 0: the segment overflows, the dropped lookups are NaN and flagged
+        tight = sharded.ShardedLSHTable(T(feat[lo:hi]), N, prims=OraclePrims, cap_factor=1.0, max_batch=1000)
+        chk(111, tight.capacity(64) == 64 and tight.capacity(1000) == 704)
+        big = np.random.default_rng(50 + rank).integers(0, 400, size=1000).astype(np.int64)  # 1000 ids -> segment of 704 (500 + 8 sigma, rounded up to 64)
+        got = tight.embed(T(big), T(planes), T(buckets)).numpy()
+        want = oracle.lsh_embed(big, feat, planes, buckets)
+        kept = ~np.isnan(got).all(1) | np.isnan(want).all(1)
+        chk(116, int(tight.overflow) == 1000 - 704 and 250 < int((~kept).sum()) <= 1000 - 704 and _same(got[kept], want[kept]))
+        try:
+            tight.check_overflow()
+            fails.append("check_overflow did not raise")
+        except RuntimeError:
+            pass
 
-        def local_gather(local_idx, rows):
-            li = local_idx.numpy()
-            out = np.full((len(li), rows.shape[1]), np.nan, np.float32)
-            okm = (li >= 0) & (li < rows.shape[0])
-            out[okm] = rows.numpy()[li[okm]]
-            return torch.from_numpy(out)
+        # software-pipelined steps (three in flight) == the steps one by one
+        n_steps, M = 5, 200
+        r2 = np.random.default_rng(60 + rank)
+        ids_l = [r2.integers(0, N, size=M).astype(np.int64) for _ in range(n_steps)]
+        oth_l = [r2.standard_normal((M, D), dtype=np.float32) for _ in range(n_steps)]
+        sc_l = [torch.empty(M) for _ in range(n_steps)]
+        for n_run in (1, 2, n_steps):
+            sharded.LshPipeline(table, T(planes), T(buckets)).run([T(i) for i in ids_l[:n_run]], [T(o) for o in oth_l[:n_run]],
+                                                                  sc_l[:n_run])
+            for t in range(n_run):
+                chk(133, _same(sc_l[t].numpy(), oracle.lsh_embed_score(ids_l[t], feat, planes, buckets, oth_l[t])[0]))
 
-        st = sharded.ShardedSLSHTable(torch.from_numpy(feat[lo:hi]), N, torch.from_numpy(big[blo:bhi]), NB,
-                                      local_index=local_index, local_gather=local_gather)
-        for name, ids in cases.items():
-            ids = ids.astype(np.int64)
-            if name == "edges":
-                ids = np.concatenate((ids, [N + 3, -2]))  # outside the table: NaN rows, index -1
-            got, gidx = st.embed(torch.from_numpy(ids), torch.from_numpy(planes_s))
-            want, widx = oracle.slsh_embed(ids, feat, planes_s, big)
-            ok = ok and np.array_equal(gidx.numpy(), widx)
-            ok = ok and np.array_equal(np.nan_to_num(got.numpy(), nan=7.0), np.nan_to_num(want, nan=7.0))
+        # slsh over a row-sharded feature table; the bucket table row-sharded too, its reachable window replicated
+        for NB, n_pl in ((777, 10), (12, 10), (21, 10)):  # window inside the table / wrapping ids: whole table replicated
+            D2 = 20
+            planes_s = rng.standard_normal((n_pl, F), dtype=np.float32)
+            bigt = rng.standard_normal((NB, D2), dtype=np.float32)
+            bigt[n_pl] = -0.0  # a row of negative zeros must survive the window gather bit for bit
+            blo, bhi, _ = sharded.shard_bounds(NB, world, rank)
+            window, win_lo = sharded.ShardedSLSHTable.gather_window(T(bigt[blo:bhi]), NB, n_pl)
+            wlo, whi = sharded.ShardedSLSHTable.window_bounds(n_pl, NB)
+            chk(144, win_lo == wlo and np.array_equal(window.numpy().view(np.uint32), bigt[wlo:whi].view(np.uint32)))
+            st = sharded.ShardedSLSHTable(T(feat[lo:hi]), N, window, win_lo, NB, prims=OraclePrims)
+            for name, ids in cases.items():
+                ids = ids.astype(np.int64)
+                got, gidx = st.embed(T(ids), T(planes_s))
+                want, widx = oracle.slsh_embed(ids, feat, planes_s, bigt)
+                chk(150, np.array_equal(gidx.numpy(), widx) and _same(got.numpy(), want))
         # top-k merge over an item-sharded catalogue
         U = rng.standard_normal((9, D), dtype=np.float32)
         E = rng.standard_normal((N, D), dtype=np.float32)
         E[700] = E[3]  # a tie across shards -> the lower global index wins
         k = 5
         lv, li = oracle.score_topk(U, E[lo:hi], k)
-        mv, mi = sharded.merge_topk(torch.from_numpy(lv), torch.from_numpy(li + lo), k)
+        mv, mi = sharded.merge_topk(T(lv), T(li + lo), k)
         wv, wi = oracle.score_topk(U, E, k)
-        ok = ok and np.array_equal(mi.numpy(), wi) and np.array_equal(mv.numpy(), wv)
-        ret[rank] = bool(ok)
+        chk(159, np.array_equal(mi.numpy(), wi) and np.array_equal(mv.numpy(), wv))
+        ret[rank] = fails
     finally:
         dist.destroy_process_group()
 
@@ -101,7 +175,7 @@ def test_exchange_lookup_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {0: [], 1: []}
 
 
 def test_shard_bounds():
@@ -115,3 +189,34 @@ def test_shard_bounds():
         covered.append((lo, hi))
     assert covered[0][0] == 0 and covered[-1][1] == 100_000_001
     assert all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    assert sharded.ShardedSLSHTable.window_bounds(27, 100_000_000) == (27, 55)
+    assert sharded.ShardedSLSHTable.window_bounds(3, 8) == (3, 7) and sharded.ShardedSLSHTable.window_bounds(4, 8) == (0, 8)
+
+
+def test_oracle_bucket_and_codes_embed():
+    """The oracle's two exchange ends against plain numpy: stable partition, and codes -> rows == lsh_embed."""
+    from oracle import oov_oracle as oracle
+    rng = np.random.default_rng(3)
+    N, world, B = 1000, 4, 700
+    per = -(-N // world)
+    ids = rng.integers(-5, N + 5, size=B).astype(np.int64)
+    send, slot, counts = oracle.bucket_by_owner(ids, N, per, world, B)
+    valid = (ids >= 0) & (ids < N)
+    owner = np.minimum(ids // per, world - 1)
+    assert np.array_equal(counts, np.bincount(owner[valid], minlength=world))
+    assert (slot[~valid] == -2).all() and np.array_equal(slot[valid] // B, owner[valid])
+    assert np.array_equal(send.reshape(-1)[slot[valid]], ids[valid] - owner[valid] * per)
+    assert (send.reshape(-1) == -1).sum() == world * B - valid.sum()
+    for w in range(world):  # stable: order of appearance
+        assert np.array_equal(send[w, :counts[w]], (ids - w * per)[valid & (owner == w)])
+    F, H, D = 20, 7, 36
+    feat = rng.standard_normal((N, F), dtype=np.float32)
+    planes = rng.standard_normal((H, F), dtype=np.float32)
+    buckets = rng.standard_normal((H, D), dtype=np.float32)
+    other = rng.standard_normal((B, D), dtype=np.float32)
+    emb, bits = oracle.lsh_embed(ids, feat, planes, buckets, want_bits=True)
+    score, emb2 = oracle.lsh_codes_embed(bits, np.arange(B, dtype=np.int32), buckets, other)
+    want_score, _ = oracle.lsh_embed_score(ids, feat, planes, buckets, other)
+    assert _same(emb2, emb) and _same(score, want_score)
+    score3, emb3 = oracle.lsh_codes_embed(bits, np.full(B, -1, np.int32), buckets, other)
+    assert np.isnan(emb3).all() and np.isnan(score3).all()

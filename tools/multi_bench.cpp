@@ -11,6 +11,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <vector>
@@ -53,7 +54,7 @@ int main(int argc, char** argv) {
   const int64_t B = argc > 6 ? atoll(argv[6]) : 65536;
   const int64_t H = argc > 7 ? atoll(argv[7]) : 8;
   const int64_t T = std::max<int64_t>(K, argc > 8 ? atoll(argv[8]) : 512) / K * K;  // distinct batches, multiple of K
-  void* lib = dlopen(argv[1], RTLD_NOW);
+  void* lib = dlopen(argv[1], RTLD_LAZY);
   if (!lib) { printf("dlopen: %s\n", dlerror()); return 2; }
   multi_fn multi = (multi_fn)dlsym(lib, "mi_oov_lsh_embed_score_multi");
   single_fn single = (single_fn)dlsym(lib, "mi_oov_lsh_embed_score");
@@ -139,6 +140,24 @@ int main(int argc, char** argv) {
     const double us = ms * 1e3 / (L * K);
     printf("multi : K=%lld x %d launches: %.3f us per batch, %.2f TB/s (532 B/lookup), frac %.3f\n", (long long)K, L, us,
            bytes / us * 1e-6, bytes / us * 1e-6 / 8.0);
+  }
+  if (getenv("MB_ISOLATED")) {  // every launch on its own, the stream drained (and the host asleep) before it
+    std::vector<float> t;
+    const int idle_us = atoi(getenv("MB_ISOLATED"));
+    for (int i = 0; i < 40; ++i) {
+      CK(hipStreamSynchronize(st));
+      if (idle_us > 0) usleep(idle_us);
+      CK(hipEventRecord(e0, st));
+      run_multi();
+      CK(hipEventRecord(e1, st));
+      CK(hipStreamSynchronize(st));
+      float ms;
+      CK(hipEventElapsedTime(&ms, e0, e1));
+      t.push_back(ms * 1e3f / K);
+    }
+    std::sort(t.begin(), t.end());
+    printf("isolated launches (idle %d us before each): per batch min %.3f  p25 %.3f  median %.3f  p75 %.3f  max %.3f us\n",
+           idle_us, t[0], t[10], t[20], t[30], t[39]);
   }
   for (int rep = 0; rep < 2; ++rep) {
     CK(hipEventRecord(e0, st));
