@@ -244,3 +244,74 @@ def test_gpu_config5_bf16_topk_at_catalogue_size(oracle, dev):
     o_vals, o_idx = oracle.score_topk(users, items, k)
     assert np.array_equal(idx.cpu().numpy(), o_idx)
     assert bits_equal(vals.cpu().numpy(), o_vals)
+
+
+# ---- the splice under autograd: gradients pinned on the reference's autograd (make_golden_context_grad.py) -----------
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["lsh", "mapper"])
+def test_gpu_splice_gradients_match_reference(kind, golden, dev):
+    import mi_oov
+    from mi_oov import context
+    z = golden("context_grad.npz")
+    p = kind + "_"
+    T = lambda k: torch.from_numpy(z[k]).to(dev)  # noqa: E731
+    n_users, n_items = int(z[p + "n_users"]), int(z[p + "n_items"])
+    tokens = T(p + "tokens")
+
+    class Side(torch.nn.Module):
+        def __init__(self, ub, ib):
+            super().__init__()
+            self.user_oov_buckets = torch.nn.Embedding.from_pretrained(ub, freeze=False)
+            self.item_oov_buckets = torch.nn.Embedding.from_pretrained(ib, freeze=False)
+
+    loss = 0.0
+    params = {}
+    for first_order in (False, True):
+        fo = "fo_" if first_order else ""
+        D = 1 if first_order else 16
+        model = Side(T(p + fo + "user_buckets"), T(p + fo + "item_buckets"))
+        table = torch.nn.Parameter(T(p + fo + "table"))
+        mapper = embedder = None
+        if kind == "mapper":
+            ft = mi_oov.FeatureTable({"id": torch.arange(4)})
+            mapper = mi_oov.RandomOOVInductiveMapper(ft, ft, n_users, n_items, 8, 8, D, dev, PRIME_PAD, "3round")
+        else:
+            ft_u = mi_oov.FeatureTable({"id": torch.arange(z["lsh_user_feat"].shape[0]), "f": torch.from_numpy(z["lsh_user_feat"])})
+            ft_i = mi_oov.FeatureTable({"id": torch.arange(z["lsh_item_feat"].shape[0]), "f": torch.from_numpy(z["lsh_item_feat"])})
+            embedder = mi_oov.LSHInductiveEmbedder(ft_u, ft_i, n_users, n_items, 8, 8, D, dev, PRIME_PAD, "none",
+                                                   mi_oov.InductiveFeatureCache())
+            embedder.load_state_dict({"user_lsh.uniform_planes.0": T("lsh_" + fo + "user_planes"),
+                                      "item_lsh.uniform_planes.0": T("lsh_" + fo + "item_planes")})
+        got = context.embed_token_fields(tokens, table, z[p + "offsets"], n_users, n_items, model, mapper, embedder,
+                                         model.user_oov_buckets.weight, model.item_oov_buckets.weight,
+                                         sum_fields=first_order)
+        assert got.requires_grad
+        ref = z[p + ("first" if first_order else "second")]
+        assert np.allclose(got.detach().cpu().numpy(), ref, rtol=1e-5, atol=1e-6, equal_nan=True)
+        loss = loss + (got * T(p + ("w1" if first_order else "w2"))).sum()
+        params[fo] = (table, model)
+    assert abs(float(loss) - float(z[p + "loss"])) <= 1e-4 * max(1.0, abs(float(z[p + "loss"])))
+    loss.backward()
+    for fo, (table, model) in params.items():
+        for name, t in (("table", table), ("user_buckets", model.user_oov_buckets.weight),
+                        ("item_buckets", model.item_oov_buckets.weight)):
+            want = z[p + "g_" + fo + name]
+            got = t.grad.cpu().numpy()
+            assert got.shape == want.shape, (fo, name)
+            scale = max(1e-30, float(np.abs(want).max()))
+            assert float(np.abs(got - want).max()) <= 1e-5 * scale, (fo, name)  # north_star: 1e-5 relative
+
+
+@pytest.mark.gpu
+def test_gpu_splice_forward_only_when_nothing_needs_grad(golden, dev):
+    """No autograd node when no input requires a gradient (the inference path stays one launch)."""
+    import mi_oov
+    from mi_oov import context
+    z = golden("context_grad.npz")
+    T = lambda k: torch.from_numpy(z[k]).to(dev)  # noqa: E731
+    ft = mi_oov.FeatureTable({"id": torch.arange(4)})
+    n_users, n_items = int(z["mapper_n_users"]), int(z["mapper_n_items"])
+    mapper = mi_oov.RandomOOVInductiveMapper(ft, ft, n_users, n_items, 8, 8, 16, dev, PRIME_PAD, "3round")
+    out = context.embed_token_fields(T("mapper_tokens"), T("mapper_table"), z["mapper_offsets"], n_users, n_items, None, mapper,
+                                     None, T("mapper_user_buckets"), T("mapper_item_buckets"))
+    assert not out.requires_grad and np.allclose(out.cpu().numpy(), z["mapper_second"], rtol=1e-5, atol=1e-6)
