@@ -72,7 +72,8 @@ DEFAULTS = dict(  # R/properties/overall.yaml:59-119 and the driver's own settin
     oov_train_ratio=0.2, oov_feature_mask_rate=0.2, oov_prime_pad=112062759511, oov_hash_function="3round",
     oov_only_epoch=True, oov_freeze_embedding=False, dhe_num_hashes=128, dhe_layer_size=512,
     oov_knn_num_neighbors=2, oov_normalization_type="per-feature", topk=[10, 20], oov_fraction=0.2,
-    data_path="dataset", USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", eval_negatives=250)
+    data_path="dataset", USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", eval_negatives=250,
+    nan_policy="skip")  # 'raise' = the reference's _check_nan; 'skip' counts the batch and fails on a no-op phase
 
 
 # ---- atomic files ---------------------------------------------------------------------------------------
@@ -372,13 +373,23 @@ def run(args):
     bs = int(cfg["train_batch_size"])
     neg_hi = n_items if ds.split is not None else ds.item_num  # pre-split: negatives from the training catalogue
     if cfg["load_checkpoint"]:
-        # reference checkpoints keep their tensors under 'state_dict' next to a pickled Config (trainer.py:304-313):
-        # only the tensors are read (weights_only), whichever of the two layouts the file has
-        blob = torch.load(cfg["load_checkpoint"], map_location=device, weights_only=True)
+        # Loaded with weights_only=True: nothing in the file is executed.  This package's own checkpoints are
+        # {'state_dict': tensors}.  A checkpoint written by the REFERENCE (trainer.py:304-313) pickles its Config object and
+        # the optimizer state next to 'state_dict'; the safe loader refuses such a file (it does not skip the foreign
+        # objects), so it has to be re-exported as tensors only first -- the state_dict KEYS are the reference's.
+        import pickle
+        try:
+            blob = torch.load(cfg["load_checkpoint"], map_location=device, weights_only=True)
+        except pickle.UnpicklingError as e:
+            raise RuntimeError(
+                f"{cfg['load_checkpoint']} holds pickled non-tensor objects (a reference checkpoint stores its Config and "
+                "optimizer next to 'state_dict') and is not loaded: re-export it where it was written with "
+                "torch.save({'state_dict': model.state_dict()}, path)") from e
         model.load_state_dict(blob["state_dict"] if isinstance(blob, dict) and "state_dict" in blob else blob)
         print(f"loaded {cfg['load_checkpoint']}")
     for epoch in range(0 if cfg["eval_only"] else int(cfg["epochs"])):
         t0, total, nb = time.time(), 0.0, 0
+        skipped = {"iv": [0, 0], "oov": [0, 0]}  # phase -> [batches with a non-finite loss, batches tried]
         perm = torch.randperm(len(tu), generator=gen, device=device)
         oov_pass = bool(cfg["train_oov"]) and bool(cfg["oov_only_epoch"])
         for phase in (("iv", "oov") if oov_pass else ("iv",)):
@@ -396,7 +407,14 @@ def run(args):
                     model.set_oov_train(no_freeze=True)
                     batch = augment_with_oov(batch, cfg, ukey, ikey)
                 loss = model.calculate_loss(batch)
-                if not torch.isfinite(loss):  # NaN rows of all-zero lsh codes (reference: _check_nan aborts)
+                skipped[phase][1] += 1
+                if not torch.isfinite(loss):
+                    # an lsh row whose code is all zeros is 0/0 = NaN (lsh_embedder.py:178) and poisons the batch loss.
+                    # The reference aborts here (trainer.py _check_nan: ValueError); nan_policy='skip' drops the batch,
+                    # counts it, and refuses to let a whole phase turn into a silent no-op.
+                    if cfg["nan_policy"] == "raise":
+                        raise ValueError("Training loss is nan")
+                    skipped[phase][0] += 1
                     continue
                 opt.zero_grad()
                 loss.backward()
@@ -404,7 +422,14 @@ def run(args):
                 total, nb = total + loss.item(), nb + 1
             if phase == "oov":
                 model.set_oov_eval()
-        print(f"epoch {epoch}: loss {total / max(1, nb):.4f} over {nb} batches, {time.time() - t0:.2f}s")
+            bad, tried = skipped[phase]
+            if tried and bad == tried:
+                raise ValueError(f"epoch {epoch}: every one of the {tried} batches of the '{phase}' phase had a non-finite "
+                                 "loss (all-zero lsh codes give NaN rows): the phase trained nothing")
+        n_bad = skipped["iv"][0] + skipped["oov"][0]
+        print(f"epoch {epoch}: loss {total / max(1, nb):.4f} over {nb} batches, {time.time() - t0:.2f}s"
+              + (f"; {n_bad} batches skipped for a non-finite loss (iv {skipped['iv'][0]}/{skipped['iv'][1]}, "
+                 f"oov {skipped['oov'][0]}/{skipped['oov'][1]})" if n_bad else ""))
     if cfg["save_checkpoint"]:
         torch.save({"state_dict": model.state_dict()}, cfg["save_checkpoint"])  # tensors only: weights_only-loadable
         print(f"saved {cfg['save_checkpoint']}")

@@ -17,7 +17,9 @@ Same class names, constructor keywords, attribute names and error behaviour as t
 
 The per-batch work of every embed_*_ids goes through the HIP kernels (ops.py); torch is used to
 hold parameters/feature matrices in HBM and for the one-off constructor-time feature build.
-`state_dict()` keys are those of the reference, so reference checkpoints load unchanged.
+`state_dict()` keys are those of the reference (a reference checkpoint re-exported as tensors only,
+`{'state_dict': ...}`, loads as it is; the reference's own file also pickles its Config and optimizer, which the
+safe loader used here refuses: driver.py).
 """
 import json
 import os

@@ -156,6 +156,32 @@ def test_checkpoint_round_trip(tmp_path, monkeypatch, dev):
 
 
 
+@pytest.mark.gpu
+def test_foreign_checkpoint_and_nan_policy(tmp_path, monkeypatch, dev):
+    """A file laid out like the REFERENCE's checkpoint (a pickled Config object next to 'state_dict',
+    trainer.py:304-313) is refused by the safe loader with a message that says what to do; nan_policy='raise' is the
+    reference's _check_nan; the default policy counts the skipped batches in the epoch line."""
+    import argparse
+    from mi_oov import driver
+    monkeypatch.chdir(tmp_path)
+    root = write_dataset(str(tmp_path))
+    common = ["x", "--dataset=toy", f"--data_path={root}", "--model=BPR", "--embedding_size=32", "--user_oov_buckets=8",
+              "--item_oov_buckets=8", "--inductive_embedder=lsh", "--add_oov_buckets", "--train_oov", "--train_batch_size=512"]
+    ck = str(tmp_path / "foreign.pth")
+    torch.save({"config": argparse.Namespace(a=1), "state_dict": {}}, ck)  # a non-tensor object, as the reference pickles
+    with pytest.raises(RuntimeError, match="re-export"):
+        driver.run(driver.custom_parse_args(common + ["--eval_only", f"--load_checkpoint={ck}"]))
+    # a loss that is NaN (what an all-zero lsh code does to its batch): the reference aborts (_check_nan), and so does
+    # nan_policy=raise; the default policy skips and counts, and refuses a phase in which every batch was skipped
+    from mi_oov import model as model_mod
+    real = model_mod.BPR.calculate_loss
+    monkeypatch.setattr(model_mod.BPR, "calculate_loss", lambda self, batch: real(self, batch) * float("nan"))
+    with pytest.raises(ValueError, match="Training loss is nan"):
+        driver.run(driver.custom_parse_args(common + ["--epochs=1", "--nan_policy=raise"]))
+    with pytest.raises(ValueError, match="trained nothing"):
+        driver.run(driver.custom_parse_args(common + ["--epochs=1"]))
+
+
 def test_inductive_dataset_pair_matches_reference():
     """The on-disk step either side of the path: a transductive dataset and its `X_ind` twin
     (`benchmark_filename = [train, empty, test_filt]`, `is_new` column) loaded by driver.AtomicDataset, and

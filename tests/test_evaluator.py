@@ -1,5 +1,7 @@
 """Sampled-ranking evaluation against what the REAL reference's Collector + Evaluator
 produced for the same sparse batches (tests/golden/eval_uni.npz, made by make_golden_eval.py)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -225,3 +227,39 @@ def test_topk_metrics_edge_cases():
     assert m["ndcg@3"] == pytest.approx(want, abs=1e-6)
     zero = mi_oov.evaluator.topk_metrics(np.array([[0, 0, 3]]), [2], ("recall", "hit"))
     assert zero == {"recall@2": 0.0, "hit@2": 0.0}
+
+
+@pytest.mark.gpu
+def test_reference_filtered_collectors_block_for_block(dev):
+    """InductiveEvaluator's seven collectors on sampled batches, bug for bug (row-indexed user ids, in-place column
+    masks shared by later collectors, shifted new-item positives): every rec.topk block and every metric of the
+    fixture produced by the REAL FilteredCollector + FastUserItemCollectorFilter (make_golden_eval_filtered.py)."""
+    import mi_oov  # noqa: F401
+    from mi_oov import evaluator
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "eval_filtered.npz"))
+    topk = [int(k) for k in z["topk"]]
+    ev = evaluator.ReferenceFilteredEvaluator(topk, int(z["n_old_users"]), int(z["n_old_items"]),
+                                              metrics=("recall", "hit", "ndcg", "mrr"))
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    for b in range(int(z["n_batches"])):
+        ev.eval_batch(T(z[f"b{b}_scores"]), T(z[f"b{b}_row_uid"]), T(z[f"b{b}_row_idx"]), T(z[f"b{b}_col_idx"]),
+                      T(z[f"b{b}_pos_u"]), T(z[f"b{b}_pos_i"]))
+    res = ev.evaluate()
+    names = [str(n) for n in z["metric_names"]]
+    for name in ("overall", "old_users", "new_users", "old_old", "old_new", "new_old", "new_new"):
+        want = z[name + "_rec_topk"]
+        assert (z[name + "_finite_k"] >= max(topk)).all()  # the fixture's rows are fully determined
+        got = ev.rec[name].cpu().numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), name
+        assert ev.undetermined[name] == 0
+        for mname, mval in zip(names, z[name + "_metric_values"]):
+            assert abs(res[name][mname] - float(mval)) < 1e-9, (name, mname)
+    # and the two forms differ where the reference's quirks bite: the intended new_new slice finds new-item positives
+    # among new-item candidates, the reference compares shifted positives with unshifted columns
+    intended = evaluator.SampledRankingEvaluator(topk, n_old_users=int(z["n_old_users"]), n_old_items=int(z["n_old_items"]))
+    for b in range(int(z["n_batches"])):
+        intended.eval_batch(T(z[f"b{b}_scores"]), T(z[f"b{b}_uid_of"]), T(z[f"b{b}_row_idx"]), T(z[f"b{b}_col_idx"]),
+                            T(z[f"b{b}_pos_u"]), T(z[f"b{b}_pos_i"]))
+    ires = intended.evaluate()
+    assert ires["overall"] == res["overall"]  # the unfiltered collector is the same in both
+    assert ires["new_new"]["recall@10"] > res["new_new"]["recall@10"]
