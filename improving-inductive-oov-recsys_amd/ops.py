@@ -163,6 +163,23 @@ class LshScorer:
                         self.buckets.data_ptr(), self.D, other.data_ptr(), score_out.data_ptr(), None,
                         C.raw_stream(self._idx))
 
+    def bind(self, ids, other, score_out):
+        """A prevalidated launch for ONE (ids, other, score_out) triple of preallocated buffers: `launch = scorer.bind(...)`
+        checks them now; `launch()` then costs ~1 us of Python on top of the hipLaunchKernel inside the library, so a
+        loop that cannot be captured in a HIP graph stays bound by the 8.5 us kernel instead of by the host.  The caller
+        keeps the three tensors alive and unmoved; their CONTENTS may change between launches."""
+        B = ids.numel()
+        if (ids.dtype is not torch.int64 or other.dtype is not torch.float32 or ids.device != self.device
+                or other.device != self.device or not ids.is_contiguous() or not other.is_contiguous()
+                or other.shape != (B, self.D)):
+            raise ValueError(f"LshScorer needs contiguous int64[B] ids and f32[B,{self.D}] rows on {self.device}")
+        if (score_out.dtype is not torch.float32 or score_out.device != self.device or score_out.shape != (B,)
+                or not score_out.is_contiguous()):
+            raise ValueError(f"score_out must be a contiguous f32[{B}] tensor on {self.device}")
+        return C.BoundCall("mi_oov_lsh_embed_score", self._idx, ids.data_ptr(), B, self.feat.data_ptr(), self.N, self.F,
+                           self.planes.data_ptr(), self.H, self.buckets.data_ptr(), self.D, other.data_ptr(),
+                           score_out.data_ptr(), None)
+
 
 class LshBatchQueue:
     """K queued batches for the persistent multi-batch launch (mi_oov_lsh_embed_score_multi, csrc/lsh64p.hip).

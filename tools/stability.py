@@ -33,6 +33,38 @@ with torch.no_grad():
         out.append(a.elapsed_time(b) / K * 1e3)
 print("us per launch:", " ".join(f"{v:.2f}" for v in out))
 
+
+def loop_time(launches):
+    res = []
+    for rep in range(6):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for fn in launches:
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        res.append(a.elapsed_time(b) / len(launches) * 1e3)
+    return res
+
+
+# the same loop through the validated-once forms: LshScorer (static operands checked once) and LshScorer.bind (every
+# argument converted once: a call descriptor per preallocated buffer triple)
+scorer = ops.LshScorer(feat, planes, buckets)
+sbuf = torch.empty((8, B), device=dev)
+with torch.no_grad():
+    res = loop_time([(lambda i=i: scorer(ids[i], users[i % 8], sbuf[i % 8])) for i in range(K)])
+    print("LshScorer, us per launch:", " ".join(f"{v:.2f}" for v in res))
+    keep = [(ids[i], users[i % 8], sbuf[i % 8]) for i in range(K)]
+    bound = [scorer.bind(*t) for t in keep]
+    res = loop_time(bound)
+    print("LshScorer.bind, us per launch:", " ".join(f"{v:.2f}" for v in res))
+    t0 = time.perf_counter()
+    for fn in bound:
+        fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    print("LshScorer.bind host time per call: %.2f us" % ((t1 - t0) / K * 1e6))
+
 # the same K launches captured once into a HIP graph (stream capture sees the C-ABI launches because they
 # go to torch's current stream) and replayed: no per-launch host work at all
 gr = torch.cuda.CUDAGraph()
