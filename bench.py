@@ -272,9 +272,15 @@ def main():
                 j += 1
                 if (settled and now - t_ramp >= args.ramp_seconds) or now - t_ramp >= 5 * args.ramp_seconds:
                     break
+            region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             if W:
                 run_steps(n_ramp, W)
-            region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            # first use of an event creates it (~40 us) and the first query / synchronize after one is slower too
+            # (tools/region_cost.py): done here, untimed, so that the K steps are what the region holds
+            region[0].record()
+            region[1].record()
+            while not region[1].query():
+                pass
             fence()
             t0 = time.perf_counter()
             region[0].record()

@@ -20,11 +20,117 @@
 namespace mi_oov {
 
 // A workgroup owns a contiguous chunk of the batch and reserves its share of every owner's segment with ONE global
-// atomic per owner (a per-lookup or even per-wave atomic serialises on `world` addresses: 189 us for 1 M lookups;
-// this form: see DESIGN.md section 6).  Two passes over the chunk (the second one re-reads the ids from L2):
-//   pass 1  count the chunk's lookups per owner (wave ballot + popcount, one LDS atomic per wave and owner)
-//           -> thread w reserves counts[w] += n_w and keeps the base
-//   pass 2  the same ballots hand every lookup a position base + (LDS running count) + (rank inside the wave)
+// atomic per owner (a per-lookup or even per-wave atomic serialises on `world` addresses: 189 us for 1 M lookups).
+// Two passes over the chunk (the second one re-reads the ids from L2):
+//   pass 1  count the chunk's lookups per owner -> thread w reserves counts[w] += n_w and keeps the base
+//   pass 2  hand every lookup a position base + (running count) + (rank inside the wave's ballot)
+// The owner of a row is id / per, taken as a double-precision product with one correction step (ids < 2^52): a
+// 64-bit integer division is ~40 instructions per lookup and pass.
+__device__ __forceinline__ int owner_of(int64_t id, int64_t per, double inv_per, int world) {
+  int64_t o = static_cast<int64_t>(static_cast<double>(id) * inv_per);
+  if (o * per > id) --o;
+  else if ((o + 1) * per <= id) ++o;
+  return static_cast<int>(o < world ? o : world - 1);
+}
+
+// world <= kSmallWorld (every single-node job): the per-owner counts of a wave live in registers -- `world` ballots
+// and popcounts per 64 lookups, no atomics at all inside the loops; a wave takes its range of the chunk's share with
+// one LDS atomic per owner, the workgroup its range of the segment with one global atomic per owner.
+constexpr int kSmallWorld = 16, kUnroll = 4;
+__global__ __launch_bounds__(256) void bucket_by_owner_small_kernel(const int64_t* __restrict__ ids, int64_t B, int64_t n_rows,
+                                                                   int64_t per, int world, int64_t cap, int64_t chunk,
+                                                                   int64_t* __restrict__ send, int32_t* __restrict__ slot,
+                                                                   int32_t* __restrict__ counts, int32_t* __restrict__ overflow) {
+  __shared__ int32_t s_cnt[kSmallWorld], s_base[kSmallWorld];
+  const int lane = threadIdx.x & 63;
+  if (threadIdx.x < kSmallWorld) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const double inv_per = 1.0 / static_cast<double>(per);
+  const int64_t lo = static_cast<int64_t>(blockIdx.x) * chunk;
+  const int64_t hi = (lo + chunk < B) ? lo + chunk : B;
+  const int64_t iters = (chunk + 255) / 256;  // (a multiple of kUnroll: the host rounds the chunk to 1024 lookups)
+  const uint64_t below = (uint64_t(1) << lane) - 1;
+  int32_t wcnt[kSmallWorld];  // wave-uniform
+#pragma unroll
+  for (int w = 0; w < kSmallWorld; ++w) wcnt[w] = 0;
+  // kUnroll ids per thread are requested together (the ballots make the iterations dependent: without this one load
+  // round trip per 256 lookups is exposed)
+  for (int64_t it = 0; it < iters; it += kUnroll) {
+    int64_t idv[kUnroll];
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t b = lo + (it + j) * 256 + threadIdx.x;
+      idv[j] = (b < hi) ? ids[b] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      const bool valid = static_cast<uint64_t>(idv[j]) < static_cast<uint64_t>(n_rows);
+      const int owner = valid ? owner_of(idv[j], per, inv_per, world) : -1;
+#pragma unroll
+      for (int w = 0; w < kSmallWorld; ++w)
+        if (w < world) wcnt[w] += static_cast<int32_t>(__builtin_popcountll(__ballot(owner == w)));
+    }
+  }
+  // lane w of the wave takes the wave's range inside the chunk's share of owner w
+  int32_t mine_cnt = 0;
+#pragma unroll
+  for (int w = 0; w < kSmallWorld; ++w)
+    if (lane == w) mine_cnt = wcnt[w];
+  int32_t wave_base = 0;
+  if (lane < world && mine_cnt) wave_base = atomicAdd(s_cnt + lane, mine_cnt);
+  __syncthreads();
+  if (threadIdx.x < world) {
+    const int32_t n = s_cnt[threadIdx.x];
+    const int32_t base = n ? atomicAdd(counts + threadIdx.x, n) : 0;
+    s_base[threadIdx.x] = base;
+    // the largest excess of any segment over its capacity, kept across calls (the caller reads it when it likes)
+    if (overflow && static_cast<int64_t>(base) + n > cap) atomicMax(overflow, static_cast<int32_t>(base + n - cap));
+  }
+  __syncthreads();
+  int64_t run[kSmallWorld];  // wave-uniform: next free position of this wave in segment w
+#pragma unroll
+  for (int w = 0; w < kSmallWorld; ++w)
+    run[w] = (w < world) ? static_cast<int64_t>(s_base[w]) + __builtin_amdgcn_readlane(wave_base, w) : 0;
+  for (int64_t it = 0; it < iters; it += kUnroll) {
+    int64_t idv[kUnroll];
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t b = lo + (it + j) * 256 + threadIdx.x;
+      idv[j] = (b < hi) ? ids[b] : -1;
+    }
+#pragma unroll
+    for (int j = 0; j < kUnroll; ++j) {
+      const int64_t b = lo + (it + j) * 256 + threadIdx.x;
+      const bool live = b < hi;
+      const int64_t id = idv[j];
+      const bool valid = static_cast<uint64_t>(id) < static_cast<uint64_t>(n_rows);
+      const int owner = valid ? owner_of(id, per, inv_per, world) : -1;
+      int64_t pos = 0;
+#pragma unroll
+      for (int w = 0; w < kSmallWorld; ++w) {
+        if (w < world) {
+          const uint64_t m = __ballot(owner == w);
+          if (owner == w) pos = run[w] + __builtin_popcountll(m & below);
+          run[w] += __builtin_popcountll(m);
+        }
+      }
+      if (live) {
+        int32_t my_slot = -2;  // invalid id: never sent, NaN at the requester (as the single-GPU kernel)
+        if (valid) {
+          if (pos < cap) {
+            send[static_cast<int64_t>(owner) * cap + pos] = id - static_cast<int64_t>(owner) * per;  // the owner's LOCAL row
+            my_slot = static_cast<int32_t>(static_cast<int64_t>(owner) * cap + pos);
+          } else {
+            my_slot = -1;  // dropped: counts[w] > cap tells the caller
+          }
+        }
+        slot[b] = my_slot;
+      }
+    }
+  }
+}
+
+// any world size: the counts live in LDS (one LDS atomic per wave, owner and iteration in both passes)
 __global__ __launch_bounds__(256) void bucket_by_owner_kernel(const int64_t* __restrict__ ids, int64_t B, int64_t n_rows,
                                                              int64_t per, int world, int64_t cap, int64_t chunk,
                                                              int64_t* __restrict__ send, int32_t* __restrict__ slot,
@@ -35,6 +141,7 @@ __global__ __launch_bounds__(256) void bucket_by_owner_kernel(const int64_t* __r
   const int lane = threadIdx.x & 63;
   for (int w = threadIdx.x; w < world; w += 256) s_cnt[w] = 0;
   __syncthreads();
+  const double inv_per = 1.0 / static_cast<double>(per);
   const int64_t lo = static_cast<int64_t>(blockIdx.x) * chunk;
   const int64_t hi = (lo + chunk < B) ? lo + chunk : B;
   const int64_t iters = (chunk + 255) / 256;  // every wave runs every iteration: the ballots need all 64 lanes
@@ -44,11 +151,7 @@ __global__ __launch_bounds__(256) void bucket_by_owner_kernel(const int64_t* __r
       const bool live = b < hi;
       const int64_t id = live ? ids[b] : -1;
       const bool valid = live && static_cast<uint64_t>(id) < static_cast<uint64_t>(n_rows);
-      int owner = 0;
-      if (valid) {
-        const int64_t o = id / per;
-        owner = static_cast<int>(o < world ? o : world - 1);
-      }
+      const int owner = valid ? owner_of(id, per, inv_per, world) : 0;
       int32_t my_slot = -2;  // invalid id: never sent, NaN at the requester (as the single-GPU kernel)
       uint64_t todo = __ballot(valid);
       while (todo) {
@@ -80,7 +183,6 @@ __global__ __launch_bounds__(256) void bucket_by_owner_kernel(const int64_t* __r
         const int32_t base = n ? atomicAdd(counts + w, n) : 0;
         s_base[w] = base;
         s_cnt[w] = 0;
-        // the largest excess of any segment over its capacity, kept across calls (the caller reads it when it likes)
         if (overflow && static_cast<int64_t>(base) + n > cap) atomicMax(overflow, static_cast<int32_t>(base + n - cap));
       }
       __syncthreads();
@@ -174,7 +276,8 @@ extern "C" int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_r
                                       int64_t cap, int64_t* send, int32_t* slot, int32_t* counts, int32_t* overflow,
                                       void* stream) {
   using namespace mi_oov;
-  if (B < 0 || n_rows <= 0 || rows_per_rank <= 0 || world <= 0 || world > 1024 || cap <= 0) return MI_OOV_ERR_SHAPE;
+  if (B < 0 || n_rows <= 0 || n_rows >= (int64_t(1) << 52) || rows_per_rank <= 0 || world <= 0 || world > 1024 || cap <= 0)
+    return MI_OOV_ERR_SHAPE;
   if (world * cap > (int64_t(1) << 31) - 1) return MI_OOV_ERR_SHAPE;  // slots are int32
   if (!send || !counts) return MI_OOV_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -186,12 +289,17 @@ extern "C" int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_r
   }
   if (B == 0) return MI_OOV_OK;
   if (!ids || !slot) return MI_OOV_ERR_NULL;
-  // chunks of >= 1024 lookups, at most ~1024 workgroups: <= 1024 reservations per owner counter
-  int64_t chunk = (B + 1023) / 1024;
-  chunk = (chunk < 1024) ? 1024 : (chunk + 255) / 256 * 256;
+  // chunks of a multiple of 1024 lookups, at most ~512 workgroups: <= 512 reservations per owner counter (an
+  // atomic on one address costs ~11 ns at the memory side whoever issues it)
+  int64_t chunk = (B + 511) / 512;
+  chunk = (chunk < 1024) ? 1024 : (chunk + 1023) / 1024 * 1024;
   const int grid = static_cast<int>((B + chunk - 1) / chunk);
-  hipLaunchKernelGGL(bucket_by_owner_kernel, dim3(grid), dim3(256), 2 * world * sizeof(int32_t), st, ids, B, n_rows,
-                     rows_per_rank, static_cast<int>(world), cap, chunk, send, slot, counts, overflow);
+  if (world <= kSmallWorld)
+    hipLaunchKernelGGL(bucket_by_owner_small_kernel, dim3(grid), dim3(256), 0, st, ids, B, n_rows, rows_per_rank,
+                       static_cast<int>(world), cap, chunk, send, slot, counts, overflow);
+  else
+    hipLaunchKernelGGL(bucket_by_owner_kernel, dim3(grid), dim3(256), 2 * world * sizeof(int32_t), st, ids, B, n_rows,
+                       rows_per_rank, static_cast<int>(world), cap, chunk, send, slot, counts, overflow);
   return check_launch();
 }
 

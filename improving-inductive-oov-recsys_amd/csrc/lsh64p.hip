@@ -187,15 +187,28 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   if (pa.batch < K) ida = load_ids(pa);
   if (pb.batch < K) idb = load_ids(pb);
 
-  // Weights.  Plane slices -> VGPRs through LDS (one 16-B load per thread, then ds_read_b128 per lane); the 2^H-row
-  // table of aggregates (score mode only) is built next to them.
-  extern __shared__ __attribute__((aligned(16))) float sw[];  // [kScore ? 2^H : 0][64] table, [H][64] planes
+  // Weights.  Planes and bucket rows are staged global -> LDS first; then -- the ids have landed with them, vmcnt
+  // retires in order -- the rows of the wave's FIRST tile are requested, and the 2^H-row table of aggregates (score
+  // modes) is built out of LDS while they are in flight: the build issues no vector-memory instruction, so nothing
+  // it waits for has the row gathers queued in front of it (MI_PEARLY=0: rows requested after the build, +~2 us per launch).
+#ifndef MI_PEARLY
+#define MI_PEARLY 1
+#endif
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [kScore ? 2^H : 0][64] table, [H][64] planes, [H][64] buckets
   constexpr int kTabRows = kScore ? (1 << H) : 0;
   float* splanes = sw + kTabRows * 64;
+  float* sbuckets = splanes + H * 64;
   if constexpr (!kFromCodes) {
     for (int i = threadIdx.x; i < H * 16; i += kPBlk)
       *reinterpret_cast<float4*>(splanes + i * 4) = *reinterpret_cast<const float4*>(planes + i * 4);
   }
+  if constexpr (kScore) {
+    for (int i = threadIdx.x; i < H * 16; i += kPBlk)
+      *reinterpret_cast<float4*>(sbuckets + i * 4) = *reinterpret_cast<const float4*>(buckets + i * 4);
+  }
+  __syncthreads();
+  float4 xa[4], ua[NU], xb[4], ub[NU];
+  if (MI_PEARLY && pa.batch < K) load_rows(pa, ida, xa, ua);
   if constexpr (kScore) {
     for (int i = threadIdx.x; i < kTabRows * 16; i += kPBlk) {
       const int c = i >> 4, l = i & 15;
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
 #pragma unroll
       for (int h = 0; h < H; ++h) {
         const float bit = ((c >> h) & 1) ? 1.f : 0.f;
-        const float4 w = *reinterpret_cast<const float4*>(buckets + (h * 16 + l) * 4);
+        const float4 w = *reinterpret_cast<const float4*>(sbuckets + (h * 16 + l) * 4);
         cnt = cnt + bit;
         acc.x = __builtin_fmaf(bit, w.x, acc.x);
         acc.y = __builtin_fmaf(bit, w.y, acc.y);
@@ -213,8 +226,8 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
       }
       *reinterpret_cast<float4*>(sw + i * 4) = masked_mean(acc, cnt);
     }
+    __syncthreads();
   }
-  __syncthreads();
   float4 pw[kFromCodes ? 1 : H];
   if constexpr (!kFromCodes) {
 #pragma unroll
@@ -296,14 +309,12 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     }
   };
 
-  if (pa.batch >= K) return;  // (after the barrier above)
-  float4 xa[4], ua[NU], xb[4], ub[NU];
+  if (pa.batch >= K) return;  // (after the barriers above)
+  if (!MI_PEARLY) load_rows(pa, ida, xa, ua);
   if (pb.batch >= K) {  // one tile only
-    load_rows(pa, ida, xa, ua);
     finish(pa, ida, xa, ua);
     return;
   }
-  load_rows(pa, ida, xa, ua);
   for (;;) {
     // current tile a in (xa, ua), rows requested; ids of tile b requested
     pn = advance(pb);
@@ -364,7 +375,7 @@ template <int H>
 static int launch_multi(const int64_t* const* ids_tab, const float* const* other_tab, float* const* score_tab, int64_t K,
                         int64_t B, const float* feat, int64_t N, const float* planes, const float* buckets,
                         hipStream_t st) {
-  const size_t lds = ((size_t(1) << H) + H) * 64 * sizeof(float);
+  const size_t lds = ((size_t(1) << H) + 2 * H) * 64 * sizeof(float);
   auto kern = lsh64_persistent_kernel<H, kModeScore, true>;
   if (int rc = set_lds(kern, lds)) return rc;
   static int cached = 0;
@@ -417,7 +428,7 @@ int launch_lsh64_codes_persistent(const int64_t* ids, int64_t B, const float* fe
 // (exchange.hip).  codes u8[M,8] (8-byte aligned), slot i32[B], other f32[B,64], score f32[B].
 int launch_lsh64_from_codes(const uint8_t* codes, int64_t M, const int32_t* slot, int64_t B, const float* buckets,
                             const float* other, float* score, hipStream_t st) {
-  const size_t lds = (256 + 8) * 64 * sizeof(float);
+  const size_t lds = (256 + 2 * 8) * 64 * sizeof(float);
   auto kern = lsh64_persistent_kernel<8, kModeFromCodes, false>;
   if (int rc = set_lds(kern, lds)) return rc;
   static int cached = 0;

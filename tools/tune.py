@@ -63,7 +63,7 @@ def main():
     feat = torch.nn.functional.normalize(torch.randn((N, F), generator=g, device=dev), dim=-1)
     planes = torch.randn((H, F), generator=g, device=dev)
     buckets = torch.randn((H, D), generator=g, device=dev)
-    total = args.iters + 5
+    total = max(args.iters + 5, 55)
     ids = torch.randint(0, N, (total, B), generator=g, device=dev)
     users = torch.randn((8, B, D), generator=g, device=dev)
     emb = torch.randn((B, D), generator=g, device=dev)
@@ -116,6 +116,23 @@ def main():
         "scatter_add_rows into 10M x 64 (gather backward)": (lambda i: ops.scatter_add_rows(ids[i], users[i % 8], N, out=gtab), B, 8 + 12 * D, 0),
         "segment_topk 4096 users x 1506 candidates k=20": (lambda i: ops.segment_topk(seg_scores, seg_cols, seg_ptr, 20), seg_scores.numel(), 12, 0),
     }
+    # round 2: the persistent launch and the two ends of the sharded exchange (1 M lookups = 16 batches per call)
+    BIG = 16 * B
+    big_ids = ids[:16].reshape(-1)
+    q50 = ops.LshBatchQueue([ids[i] for i in range(50)], [users[i % 8] for i in range(50)])
+    multi = ops.LshMultiScorer(feat, planes, buckets)
+    codes_big = (torch.rand((BIG, H), generator=g, device=dev) < 0.5).to(torch.uint8)
+    slot_big = torch.randperm(BIG, generator=g, device=dev).to(torch.int32)
+    users_big = torch.randn((BIG, D), generator=g, device=dev)
+    sc_big = torch.empty((BIG,), device=dev)
+    over = torch.zeros((1,), dtype=torch.int32, device=dev)
+    cases.update({
+        "lsh_embed_score_multi 50 batches per launch (persistent kernel)": (lambda i: multi.run(q50), 50 * B, 16 + 4 * F + 4 * D + 4, 0),
+        "lsh_bits 1M lookups (persistent codes kernel, sharded owner side)": (lambda i: ops.lsh_bits(big_ids, feat, planes), BIG, 8 + 4 * F + H, 0),
+        "lsh_codes_embed 1M lookups score only (sharded requester side)": (lambda i: ops.lsh_codes_embed(codes_big, slot_big, buckets, users_big, want_emb=False, score_out=sc_big), BIG, 4 + H + 4 * D + 4, 0),
+        "bucket_by_owner 1M lookups world=8": (lambda i: ops.bucket_by_owner(big_ids, N, -(-N // 8), 8, BIG // 8 + 8192, over), BIG, 8 + 8 + 4, 0),
+        "bucket_by_owner 65536 lookups world=8": (lambda i: ops.bucket_by_owner(ids[i], N, -(-N // 8), 8, B // 8 + 2048, over), B, 8 + 8 + 4, 0),
+    })
     if args.only.startswith("score_topk_excl"):  # full-sort evaluation: histories masked (bitmap in the kernel vs top-(k + h_max))
         gh = torch.Generator(device=dev).manual_seed(5)
         for hmean, hmax in ((60, 120), (100, 230), (100, 1500)):
