@@ -62,6 +62,9 @@ _SIGNATURES = {
     "mi_oov_rowdot": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "mi_oov_full_sort_scores": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "mi_oov_linear_act": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
+    "mi_oov_act_forward": (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp]),
+    "mi_oov_act_backward": (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
+    "mi_oov_transpose": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "mi_oov_score_topk_workspace": (_i64, [_i64, _i64, _i64]),
     "mi_oov_score_topk": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
 }

@@ -300,11 +300,12 @@ def _hash_mlp(in_features, hidden, out_features, device):
 
 
 def _run_hash_net(net, x):
-    """The reference's `*_hash_net(x)`.  Without autograd the Linear+GELU / Linear+Sigmoid pairs run
-    on mi_oov_linear_act (f32 MFMA, activation fused in the epilogue); when a gradient is required
-    the nn.Sequential itself runs so that torch autograd sees it."""
-    if torch.is_grad_enabled() and any(p.requires_grad for p in net.parameters()):
-        return net(x)
+    """The reference's `*_hash_net(x)`.  Without autograd the Linear+GELU / Linear+Sigmoid pairs run on
+    mi_oov_linear_act (f32 MFMA, activation fused in the epilogue); when a gradient is required the same GEMM kernel
+    runs the forward unfused (pre-activations kept) and the backward (`ops.hash_net_train`): torch autograd only links
+    the pieces, it computes nothing."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in net.parameters())):
+        return ops.hash_net_train(net, x)
     return ops.hash_net_forward(net, x)
 
 

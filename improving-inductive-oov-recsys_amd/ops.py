@@ -1,10 +1,11 @@
 """Torch-facing operators over the C ABI (include/mi_oov.h).  One function per entry point.
 
 Forward passes are the hand-written HIP kernels.  Where the reference's outputs carry gradients
-(SURVEY.md section 8b "Autograd": bucket tables for lsh/slsh, the item table for knn, both sides for
-the scores) a torch.autograd.Function supplies the backward with device-side torch ops
-(index_add_/matmul on the same ROCm device); hand-written backward kernels are the next row of
-the scope table.  Nothing here ever computes on the CPU.
+(SURVEY.md section 8b "Autograd": bucket tables for lsh/slsh, the item table for knn, the MLP weights of
+dhe/fdhe/dnn, both sides for the scores) a torch.autograd.Function supplies the backward, and every backward
+is itself made of this library's kernels (deterministic bucket reductions, mi_oov_scatter_add_rows, the f32-MFMA
+GEMM + mi_oov_transpose + mi_oov_act_backward for the hash nets and the full-sort scores): torch autograd links
+the pieces and computes nothing.  Nothing here ever computes on the CPU.
 """
 import torch
 
@@ -701,9 +702,12 @@ class _FullSort(torch.autograd.Function):
         return _full_sort_forward(U, E)
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g):  # dU = g E, dE = g^T U: the same GEMM kernel, contracted dimension put last by `transpose`
         U, E = ctx.saved_tensors
-        return g @ E, g.t() @ U
+        g = g.contiguous()
+        dU = _full_sort_forward(g, transpose(E)) if ctx.needs_input_grad[0] else None
+        dE = _full_sort_forward(transpose(g), transpose(U)) if ctx.needs_input_grad[1] else None
+        return dU, dE
 
 
 def full_sort_scores(U, E):
@@ -730,24 +734,110 @@ def linear_act(X, W, bias, act=None):
     return Y
 
 
-def hash_net_forward(net, x):
-    """Run an nn.Sequential of Linear / GELU / Sigmoid (the reference's *_hash_net) through
-    mi_oov_linear_act, fusing each activation into the producing layer's epilogue.  Used when no
-    gradient is needed; otherwise the caller falls back to the module itself (torch autograd)."""
-    mods = list(net)
-    i = 0
+def _hash_net_layers(net):
+    """[(Linear, act name or None), ...] of an nn.Sequential of Linear / GELU (erf form) / Sigmoid."""
+    mods, layers, i = list(net), [], 0
     while i < len(mods):
         lin = mods[i]
         if not isinstance(lin, torch.nn.Linear) or lin.bias is None:
-            raise TypeError("hash_net_forward expects Linear(+bias) layers followed by GELU / Sigmoid")
+            raise TypeError("a hash net is Linear(+bias) layers, each optionally followed by GELU / Sigmoid")
         act = None
         if i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.GELU) and mods[i + 1].approximate == "none":
             act, i = "gelu", i + 1
         elif i + 1 < len(mods) and isinstance(mods[i + 1], torch.nn.Sigmoid):
             act, i = "sigmoid", i + 1
-        x = linear_act(x, lin.weight, lin.bias, act)
+        layers.append((lin, act))
         i += 1
+    return layers
+
+
+def hash_net_forward(net, x):
+    """Run an nn.Sequential of Linear / GELU / Sigmoid (the reference's *_hash_net) through
+    mi_oov_linear_act, fusing each activation into the producing layer's epilogue.  Inference form; under autograd
+    `hash_net_train` keeps the pre-activations and supplies the backward on the same GEMM kernel."""
+    for lin, act in _hash_net_layers(net):
+        x = linear_act(x, lin.weight, lin.bias, act)
     return x
+
+
+def _elementwise(name, act, *tensors):
+    out = torch.empty_like(tensors[-1])
+    n = out.numel()
+    with C.on_device(out):
+        rc = getattr(C.lib(), name)(*[C.ptr(t) for t in tensors], n, ACTS[act], C.ptr(out), C.stream_of(out))
+    C.check(rc, name)
+    return out
+
+
+def act_forward(Z, act):
+    """act(Z) elementwise (mi_oov_act_forward): the expressions of mi_oov_linear_act's fused epilogue."""
+    return _elementwise("mi_oov_act_forward", act, _f32(Z, "Z"))
+
+
+def act_backward(dY, Z, act):
+    """dY * act'(Z) (mi_oov_act_backward): GELU (erf form) Phi(z) + z phi(z); Sigmoid y (1 - y)."""
+    return _elementwise("mi_oov_act_backward", act, _f32(dY, "dY"), _f32(Z, "Z"))
+
+
+def transpose(A):
+    """A.T as a dense row-major matrix (mi_oov_transpose): the [rows, k] layout the GEMM kernel contracts over."""
+    A = _f32(A, "A")
+    R, Cc = A.shape
+    At = torch.empty((Cc, R), dtype=torch.float32, device=A.device)
+    with C.on_device(A):
+        rc = C.lib().mi_oov_transpose(C.ptr(A), R, Cc, C.ptr(At), C.stream_of(A))
+    C.check(rc, "mi_oov_transpose")
+    return At
+
+
+class _HashNet(torch.autograd.Function):
+    """The reference's *_hash_net under autograd (dh_embedder.py:70-89,191-217; dnn_embedder.py:65-109) on this
+    library's kernels only.  forward keeps every layer's input and pre-activation; backward per layer:
+        dZ = dY * act'(Z)     dW = dZ^T X     db = 1^T dZ     dX = dZ W
+    -- three products on the f32-MFMA GEMM (`_full_sort_forward`: one fmaf chain per element over increasing k) after
+    `transpose` has put the contracted dimension last."""
+
+    @staticmethod
+    def forward(ctx, x, acts, *params):
+        h, saved = _f32(x, "x"), []
+        for li, act in enumerate(acts):
+            W, b = params[2 * li], params[2 * li + 1]
+            z = linear_act(h, W, b, None)
+            saved += [h, z]
+            h = act_forward(z, act) if act else z
+        ctx.save_for_backward(*saved, *[p for i, p in enumerate(params) if i % 2 == 0])
+        ctx.acts = acts
+        ctx.x_needs = x.requires_grad
+        return h
+
+    @staticmethod
+    def backward(ctx, g):
+        n = len(ctx.acts)
+        saved, Ws = ctx.saved_tensors[:2 * n], ctx.saved_tensors[2 * n:]
+        g = g.contiguous()
+        grads = [None] * (2 * n)
+        ones = None
+        for li in range(n - 1, -1, -1):
+            h, z = saved[2 * li], saved[2 * li + 1]
+            dz = act_backward(g, z, ctx.acts[li]) if ctx.acts[li] else g
+            dzt = transpose(dz)  # [out, B]
+            grads[2 * li] = _full_sort_forward(dzt, transpose(h))  # [out, in]
+            if ones is None:
+                ones = torch.ones((1, dz.shape[0]), dtype=torch.float32, device=dz.device)
+            grads[2 * li + 1] = _full_sort_forward(ones, dzt).view(-1)  # [out]
+            if li > 0 or ctx.x_needs:
+                g = _full_sort_forward(dz, transpose(Ws[li]))  # [B, in]
+        return (g if ctx.x_needs else None, None, *grads)
+
+
+def hash_net_train(net, x):
+    """`net(x)` with gradients to the Linear weights / biases (and to x when it requires one), every forward and
+    backward operation a kernel of this library."""
+    layers = _hash_net_layers(net)
+    params = []
+    for lin, _ in layers:
+        params += [lin.weight, lin.bias]
+    return _HashNet.apply(x, tuple(a for _, a in layers), *params)
 
 
 _TOPK_WORKSPACE_MAX_BYTES = 2 << 30

@@ -284,6 +284,19 @@ enum { MI_OOV_ACT_NONE = 0, MI_OOV_ACT_GELU = 1, MI_OOV_ACT_SIGMOID = 2 };
 int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, const float* bias,
                       int64_t N_out, int act, float* Y, void* stream);
 
+/* Training of the hash nets on this library's GEMM (csrc/mlp.hip): what torch autograd does for the reference's
+ * nn.Sequential(Linear, GELU, ..., Linear, Sigmoid) (dh_embedder.py:70-89,191-217, dnn_embedder.py:65-109).
+ *   forward   Z = mi_oov_linear_act(X, W, b, MI_OOV_ACT_NONE);  Y = mi_oov_act_forward(Z, act)      (Z is kept)
+ *   backward  dZ = mi_oov_act_backward(dY, Z, act)                       dY * act'(Z)
+ *             dX = mi_oov_full_sort_scores(dZ,   W^T)                    [B,out] x [in,out]^T -> [B,in]
+ *             dW = mi_oov_full_sort_scores(dZ^T, X^T)                    [out,B] x [in,B]^T   -> [out,in]
+ *             db = mi_oov_full_sort_scores(1[1,B], dZ^T)                 column sums of dZ
+ *   with the layouts made by mi_oov_transpose (At[c,r] = A[r,c], A f32[R,C]).
+ * n = number of elements; pointers 16-byte aligned; act as in mi_oov_linear_act.                        */
+int mi_oov_act_forward(const float* Z, int64_t n, int act, float* Y, void* stream);
+int mi_oov_act_backward(const float* dY, const float* Z, int64_t n, int act, float* dZ, void* stream);
+int mi_oov_transpose(const float* A, int64_t R, int64_t C, float* At, void* stream);
+
 /* Fused full-sort score + per-row top-k (the [B,N] matrix is never written).  Serves
  *   - the evaluator's torch.topk(scores, k) (R/evaluator/collector.py:158-167), and
  *   - the exact kNN search standing in for ScaNN (R/inductive/knn_embedder.py:100-102).

@@ -24,12 +24,14 @@ from recbole.data.interaction import Interaction  # noqa: E402
 PRIME_PAD = mg.PRIME_PAD
 
 
-def one_case(tag, build, n_users, n_items, n_new_u, n_new_i, D, n_ub, n_ib, seed, out):
+def one_case(tag, build, n_users, n_items, n_new_u, n_new_i, D, n_ub, n_ib, seed, out, post=None):
     uf = mg.features(n_new_u, [("a", 1, "float"), ("v", 9, "float")], seed, "user_id")
     itf = mg.features(n_new_i, [("y", 1, "float"), ("w", 20, "float")], seed + 1, "item_id")
     torch.manual_seed(seed + 2)
     mapper, emb = build(uf, itf)
     model = mg.make_bpr(n_users, n_items, D, mapper, emb, n_ub, n_ib, seed + 3)
+    if post is not None:
+        post(model)
     model.train()
     if emb is not None and hasattr(emb, "set_train"):
         emb.set_train()
@@ -137,6 +139,42 @@ def main():
     directau_case(out, n_users, n_items, n_new_u, n_new_i, D)
     np.savez_compressed(os.path.join(HERE, "bpr_grad.npz"), **out)
     print("bpr_grad.npz", os.path.getsize(os.path.join(HERE, "bpr_grad.npz")), "bytes")
+    hash_net_cases(*args)
+
+
+def hash_net_cases(n_users, n_items, n_new_u, n_new_i, D):
+    """The MLP plugins under the reference's autograd: `dnn` (features -> MLP) and `dhe` (1024... here 32 SipHash values
+    -> MLP) in one BPR.calculate_loss; gradients of every Linear weight / bias and of both embedding tables.
+    The dhe net is fed raw hashes up to 1.6e7, which saturate its sigmoid with default weights (every gradient would
+    be exactly 0): its first layer is scaled by 1e-7 here so that the step is not vacuous.  -> hash_net_grad.npz"""
+    from recbole.inductive.dnn_embedder import DNNEmbedder
+    from recbole.inductive.dh_embedder import DeepHashEmbedder
+    out = {}
+    K = 32
+    for tag, seed in (("dnn", 760), ("dhe", 770)):
+        os.makedirs("hash_keys", exist_ok=True)
+        if tag == "dhe":
+            import json
+            keys = [bytes((j * 7 + i) % 256 for i in range(16)) for j in range(K)]
+            with open(os.path.join("hash_keys", f"{K}.hashes"), "w") as f:
+                json.dump([k.hex() for k in keys], f)
+            out["dhe__keys"] = np.frombuffer(b"".join(keys), dtype=np.uint8).reshape(K, 16)
+
+        def build(uf, itf, tag=tag):
+            if tag == "dnn":
+                return None, DNNEmbedder(uf, itf, n_users, n_items, 8, 8, D, "cpu", PRIME_PAD, dhe_layer_size=48)
+            e = DeepHashEmbedder(uf, itf, n_users, n_items, 8, 8, D, "cpu", PRIME_PAD, num_hashes=K)
+            return None, e
+
+        def post(model, tag=tag):  # after BPR's xavier re-initialisation of the Linear layers (bpr.py:46)
+            if tag == "dhe":
+                with torch.no_grad():
+                    for net in (model.inductive_embedder.user_hash_net, model.inductive_embedder.item_hash_net):
+                        net[0].weight.mul_(1e-7)
+
+        one_case(tag, build, n_users, n_items, n_new_u, n_new_i, D, 8, 8, seed, out, post=post)
+    np.savez_compressed(os.path.join(HERE, "hash_net_grad.npz"), **out)
+    print("hash_net_grad.npz", os.path.getsize(os.path.join(HERE, "hash_net_grad.npz")), "bytes")
 
 
 if __name__ == "__main__":
