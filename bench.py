@@ -42,7 +42,6 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable)
-INFINITY_CACHE = 256 << 20
 
 
 def parse():
@@ -374,11 +373,9 @@ def main():
             """[i0, i0+n) in exchanges of up to S steps whose user rows are contiguous (cut where the ring wraps)."""
             out = []
             while n > 0:
-                if i0 < n_ramp:
+                if i0 < n_ramp:  # the clock ramp's own batches and user rows
                     take = min(n, S, n_ramp - i0)
-                    rows, sc0 = ramp_rows[i0 * B:(i0 + take) * B], (i0 % ring)
-                    take = min(take, ring - sc0)
-                    rows = ramp_rows[i0 * B:(i0 + take) * B]
+                    rows, sc0 = ramp_rows[i0 * B:(i0 + take) * B], 0
                 else:
                     sc0 = (i0 - n_ramp) % ring
                     take = min(n, S, ring - sc0)
