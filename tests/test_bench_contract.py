@@ -67,9 +67,9 @@ def test_pmc_traffic_and_rocprof_duration_agree_with_the_line():
     assert timed["kernel"] == kernel and timed["launches"] == under["roofline"]["launches"]
     assert timed["batches_per_launch"] == line["roofline"]["batches_per_launch"]
     # rocprof's kernel duration of the timed launch against the bench's HIP events: the plain run within 5 %, the run
-    # under the profiler (whose event records carry the tool's own overhead around a single launch) within 12 %
+    # under the profiler (whose event records carry the tool's own overhead around a single launch) within 15 %
     assert abs(timed["avg_us"] - line["roofline"]["avg_launch_us"]) < 0.05 * timed["avg_us"]
-    assert 0 <= under["roofline"]["avg_launch_us"] - timed["avg_us"] < 0.12 * timed["avg_us"]
+    assert 0 <= under["roofline"]["avg_launch_us"] - timed["avg_us"] < 0.15 * timed["avg_us"]
     assert timed["avg_us"] * 1e-6 > 0  # and the roofline fraction it implies meets north_star's 0.70
     frac = line["roofline"]["bytes_per_lookup"] * line["roofline"]["lookups_per_launch"] / (timed["avg_us"] * 1e-6) / 8e12
     assert frac >= 0.70
