@@ -187,6 +187,25 @@ def test_no_cpu_fallback(ds):
         bpr.predict({"user_id": torch.tensor([1, 2]), "item_id": torch.tensor([3, 30])})
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         mi_oov.ops.mapper_map(torch.arange(4), "fast", 2, 3)
+    # round-2 entry points: queued batches, the two ends of the sharded exchange, the hash-net training pieces
+    ids, rows = torch.zeros(4, dtype=torch.int64), torch.zeros(4, 64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mi_oov.ops.LshBatchQueue([ids], [rows])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mi_oov.ops.lsh_embed_score_multi([ids], torch.zeros(9, 64), torch.zeros(8, 64), torch.zeros(8, 64), [rows])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mi_oov.ops.bucket_by_owner(ids, 100, 50, 2, 4)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mi_oov.ops.lsh_codes_embed(torch.zeros(4, 8, dtype=torch.uint8), torch.zeros(4, dtype=torch.int32), torch.zeros(8, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mi_oov.ops.transpose(rows)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mi_oov.ops.hash_net_train(torch.nn.Sequential(torch.nn.Linear(64, 8), torch.nn.Sigmoid()), rows)
+    # a sharded table's default local compute is the HIP kernels: no process group, no silent alternative either
+    import torch.distributed as dist
+    assert not dist.is_initialized()
+    with pytest.raises((RuntimeError, ValueError)):
+        mi_oov.sharded.ShardedLSHTable(torch.zeros(4, 64), 4)
 
 
 def test_deepcopy_survives(ds, tmp_path, monkeypatch):
