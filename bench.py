@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--hashes", type=int, default=8)
     ap.add_argument("--batch", type=int, default=65536)
     ap.add_argument("--ring-mib", type=int, default=1024, help="size of the ring of user-row buffers")
-    ap.add_argument("--batches-per-exchange", type=int, default=32, help="--table sharded: steps carried by one all-to-all")
+    ap.add_argument("--batches-per-exchange", type=int, default=64, help="--table sharded: steps carried by one all-to-all")
     ap.add_argument("--force-sharded", action="store_true",
                     help="developer: run the sharded path at N = 1 too (one-rank RCCL group, self-exchange) to time its kernels")
     ap.add_argument("--cap-factor", type=float, default=1.0,
