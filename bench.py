@@ -364,7 +364,7 @@ def main():
                 TimedPrims.events.append(ev)
                 return out
 
-        table = sharded.ShardedLSHTable(feat_l, N, prims=TimedPrims, cap_factor=args.cap_factor, max_batch=S * B)
+        table = sharded.ShardedLSHTable(feat_l, N, prims=TimedPrims, cap_factor=args.cap_factor, uniform_batches=True)
         pipe = sharded.LshPipeline(table, planes_l, buckets_l)
         flat_ids = all_ids.view(-1)
         ramp_rows, ring_rows, ring_scores = ramp_users.view(-1, D), users.view(-1, D), scores.view(-1)
@@ -409,7 +409,7 @@ def main():
                              "bytes_per_lookup": 8 + 4 * F + H, "lookups_per_launch": B * K / n_blocks,
                              "launches": n_blocks, "avg_launch_us": owner_ms * 1e3, "traffic": None,
                              "note": "HIP events around each owner-kernel launch; exchanges of neighbouring steps run beside it"},
-                "detail": {"steps_per_exchange": S, "exchanges": n_blocks, "segment_capacity": table.capacity(S * B),
+                "detail": {"steps_per_exchange": S, "exchanges": n_blocks, "segment_capacity": table.capacity(min(S, K) * B),
                            "cap_factor": args.cap_factor, "bytes_on_wire_per_lookup": 8 + H,
                            "region_ms_hip_events": region_ms, "us_per_step_hip_events": region_ms * 1e3 / K,
                            "overflowed_lookups": 0}}

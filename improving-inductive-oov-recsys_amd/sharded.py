@@ -89,7 +89,8 @@ class _Pending:
 
 
 class _ShardedBase:
-    def __init__(self, feat_local, n_rows_global, group=None, prims=None, cap_factor=None, max_batch=None):
+    def __init__(self, feat_local, n_rows_global, group=None, prims=None, cap_factor=None, max_batch=None,
+                 uniform_batches=False):
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
@@ -101,6 +102,7 @@ class _ShardedBase:
         self.prims = prims or HipPrims
         self.cap_factor = cap_factor
         self.max_batch = max_batch
+        self.uniform_batches = uniform_batches
         # largest excess of a segment over its capacity so far (updated by the bucket kernel, read by check_overflow)
         self.overflow = torch.zeros((1,), dtype=torch.int32, device=feat_local.device)
 
@@ -116,9 +118,13 @@ class _ShardedBase:
         return max(64, min(B, -(-want // 64) * 64))
 
     def _agreed_capacity(self, B):
-        """Every rank must use the same segment size.  With `max_batch` (an upper bound of the per-rank batch that
-        all ranks were constructed with) that is a local computation and the step stays free of host
-        synchronisation; without it the ranks agree on max(B) with one tiny all_reduce whose result the host reads."""
+        """Every rank must use the same segment size.  `uniform_batches` (every rank passes the same number of lookups
+        to the same call: a benchmark, a lock-step serving loop) or `max_batch` (an upper bound of the per-rank batch
+        that all ranks were constructed with; segments are then sized for it) make that a local computation and the
+        step stays free of host synchronisation; without either the ranks agree on max(B) with one tiny all_reduce
+        whose result the host reads."""
+        if self.uniform_batches:
+            return self.capacity(B)
         if self.max_batch is not None:
             if B > self.max_batch:
                 raise ValueError(f"batch of {B} lookups exceeds max_batch={self.max_batch}")
@@ -225,8 +231,8 @@ class ShardedSLSHTable(_ShardedBase):
     ids wrap); `gather_window` builds it from row-sharded bucket blocks with one all_gather at construction."""
 
     def __init__(self, feat_local, n_feat_rows, window, win_lo, n_buckets, group=None, prims=None, cap_factor=None,
-                 max_batch=None):
-        super().__init__(feat_local, n_feat_rows, group, prims, cap_factor, max_batch)
+                 max_batch=None, uniform_batches=False):
+        super().__init__(feat_local, n_feat_rows, group, prims, cap_factor, max_batch, uniform_batches)
         self.window, self.win_lo, self.n_buckets = window, win_lo, n_buckets
 
     @staticmethod

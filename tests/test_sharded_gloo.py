@@ -126,6 +126,16 @@ def _worker(rank, world, port, ret):
         except RuntimeError:
             pass
 
+        # uniform_batches: the capacity follows the batch of the call (every rank passes the same size)
+        uni = sharded.ShardedLSHTable(T(feat[lo:hi]), N, prims=OraclePrims, cap_factor=1.0, uniform_batches=True)
+        for nb in (64, 1000):
+            idsu = np.random.default_rng(70 + rank).integers(0, N, size=nb).astype(np.int64)
+            p = uni.begin(T(idsu))
+            chk(130, p.cap == uni.capacity(nb))
+            uni.owner(p, T(planes))
+            chk(131, _same(uni.finish(p, T(buckets))[1].numpy(), oracle.lsh_embed(idsu, feat, planes, buckets)))
+        chk(132, int(uni.overflow) == 0)
+
         # software-pipelined steps (three in flight) == the steps one by one
         n_steps, M = 5, 200
         r2 = np.random.default_rng(60 + rank)
