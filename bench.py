@@ -97,13 +97,16 @@ def spawn_ranks(args):
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
     rc = 0
+    while any(p.poll() is None for p in procs):
+        if any(p.poll() not in (None, 0) for p in procs):  # a rank that died leaves the others in a collective: end them
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.05)
     for p in procs:
         p.wait()
         rc = rc or p.returncode
-    if rc:  # a rank that died leaves the others in a collective: end them
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
     return rc
 
 
@@ -269,7 +272,10 @@ def main():
                 settled = prev is not None and abs(burst - prev) <= 0.02 * burst
                 prev = burst
                 j += 1
-                if (settled and now - t_ramp >= args.ramp_seconds) or now - t_ramp >= 5 * args.ramp_seconds:
+                done = (settled and now - t_ramp >= args.ramp_seconds) or now - t_ramp >= 5 * args.ramp_seconds
+                # the ranks must leave the ramp TOGETHER: a step of the sharded path is a collective, and a rank that
+                # has settled earlier would otherwise go on to the warm-up exchange while another repeats the ramp's
+                if reduce_max(0.0 if done else 1.0) == 0.0:
                     break
             region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             if W:
