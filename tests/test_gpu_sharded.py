@@ -192,3 +192,27 @@ def test_world2_single_device_hip_local_compute(dev):
     ret = mgr.dict()
     mp.spawn(_rank_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     assert dict(ret) == {0: [], 1: []}
+
+
+def test_bench_self_spawned_two_ranks_sharded_line(dev):
+    """`python bench.py --gpus 2` from a bare shell: the parent starts the ranks itself, the N > 1 headline is the
+    row-sharded mode with the replicated figure beside it.  Two ranks on the one device, gloo rendezvous (rehearsal
+    backend).  Run twice with a short clock ramp: ranks whose ramps settle at different times must still leave the
+    ramp together (they once did not, and the exchanges of the two ranks then mismatched)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for rep in range(2):
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--single-device", "--dist-backend",
+                            "gloo", "--steps", "9", "--warmup", "3", "--items", "600001", "--batch", "8192", "--ring-mib", "64",
+                            "--ramp-seconds", "0.05", "--batches-per-exchange", "4"],
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, p.stdout[-2000:]
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 9 and d["scaling"] == "weak" and d["config"]["backend"] == "gloo"
+        assert "row-sharded over 2 ranks" in d["config"]["table"] and d["sharded"]["overflowed_lookups"] == 0
+        assert d["sharded"]["bytes_on_wire_per_lookup"] == 16 and d["sharded"]["exchanges"] >= 3
+        assert d["replicated"]["value"] > 0 and d["value"] > 0 and d["roofline"]["bound"] == "hbm"
