@@ -9,7 +9,7 @@ the same module objects.
 """
 import sys as _sys
 
-from . import _cabi, ops, embedders, mapper, factory, model, sharded, context, evaluator, driver  # noqa: F401
+from . import _cabi, ops, embedders, mapper, factory, model, sharded, context, evaluator, driver, torch_ops  # noqa: F401
 from ._cabi import LIB_PATH, MiOovError, available  # noqa: F401
 from .embedders import (AbstractInductiveEmbedder, DeepHashEmbedder, DNNEmbedder, FeatDeepHashEmbedder,  # noqa: F401
                         FeatureTable, InductiveFeatureCache, KNNInductiveEmbedder, LSHInductiveEmbedder, MeanEmbedder,
@@ -20,6 +20,7 @@ from .model import BPR, DirectAU, InductiveGeneralRecommender  # noqa: F401
 
 __version__ = "0.1.0"
 
-for _name in ("_cabi", "ops", "embedders", "mapper", "factory", "model", "sharded", "context", "evaluator", "driver"):
+for _name in ("_cabi", "ops", "embedders", "mapper", "factory", "model", "sharded", "context", "evaluator", "driver",
+              "torch_ops"):
     _sys.modules.setdefault("mi_oov." + _name, _sys.modules[__name__ + "." + _name])
 _sys.modules.setdefault("mi_oov", _sys.modules[__name__])

@@ -554,3 +554,34 @@ def test_dhe_full_size_properties(mi, oracle, dev):
     # the activations go through expf / erff, whose device and host implementations differ in the last ulp
     assert np.abs(got - ref).max() <= 2e-6
     assert (got > 0).all() and (got < 1).all()
+
+
+def test_torch_ops_dispatch_and_autograd(mi, dev):
+    """torch.ops.mi_oov.* run the same kernels as mi_oov.ops (identical results) and carry the bucket-table gradients."""
+    from mi_oov import ops
+    g = torch.Generator(device=dev).manual_seed(9)
+    N, B = 3000, 1001
+    feat = torch.randn((N, 64), generator=g, device=dev)
+    planes, buckets = torch.randn((8, 64), generator=g, device=dev), torch.randn((8, 64), generator=g, device=dev)
+    ids = torch.randint(0, N, (B,), generator=g, device=dev)
+    other = torch.randn((B, 64), generator=g, device=dev)
+    same = lambda a, b: torch.equal(torch.nan_to_num(a, 7.0), torch.nan_to_num(b, 7.0))  # noqa: E731
+    assert same(torch.ops.mi_oov.lsh_embed(ids, feat, planes, buckets), ops.lsh_embed(ids, feat, planes, buckets))
+    assert torch.equal(torch.ops.mi_oov.lsh_bits(ids, feat, planes), ops.lsh_bits(ids, feat, planes))
+    assert same(torch.ops.mi_oov.lsh_embed_score(ids, feat, planes, buckets, other), ops.lsh_embed_score(ids, feat, planes, buckets, other))
+    many = torch.ops.mi_oov.lsh_embed_score_multi([ids, ids.flip(0).contiguous()], feat, planes, buckets,
+                                                  [other, other.flip(0).contiguous()])
+    assert same(many[0], ops.lsh_embed_score(ids, feat, planes, buckets, other)) and same(many[1].flip(0), many[0])
+    big = torch.randn((37, 64), generator=g, device=dev)
+    assert same(torch.ops.mi_oov.slsh_embed(ids, feat, planes, big), ops.slsh_embed(ids, feat, planes, big))
+    assert torch.equal(torch.ops.mi_oov.mapper_map(ids, "3round", 2000, 77), ops.mapper_map(ids, "3round", 2000, 77))
+    v1, i1 = torch.ops.mi_oov.score_topk(other[:64].contiguous(), feat, 5, 1)
+    v2, i2 = ops.score_topk(other[:64].contiguous(), feat, 5, 1)
+    assert torch.equal(i1, i2) and torch.equal(v1, v2)
+    # gradients through the dispatcher == gradients of mi_oov.ops (same backward kernels)
+    keep = ops.lsh_bits(ids, feat, planes).sum(1) > 0  # all-zero codes are NaN rows: leave them out of the loss
+    for op_t, op_o, table in ((torch.ops.mi_oov.lsh_embed, ops.lsh_embed, buckets), (torch.ops.mi_oov.slsh_embed, ops.slsh_embed, big)):
+        w1, w2 = table.clone().requires_grad_(True), table.clone().requires_grad_(True)
+        (op_t(ids[keep], feat, planes, w1) * other[keep][:, :table.shape[1]]).sum().backward()
+        (op_o(ids[keep], feat, planes, w2) * other[keep][:, :table.shape[1]]).sum().backward()
+        assert w1.grad is not None and torch.equal(w1.grad, w2.grad)

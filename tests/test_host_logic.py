@@ -218,3 +218,28 @@ def test_deepcopy_survives(ds, tmp_path, monkeypatch):
         assert list(clone.state_dict().keys()) == list(bpr.state_dict().keys())
     knn = factory.get_inductive_embedder(base_cfg(inductive_embedder="knn", oov_knn_num_neighbors=5), ds)
     assert copy.deepcopy(knn).n_neighbors == 2  # the reference's __deepcopy__ drops n_neighbors (knn_embedder.py:95-98)
+
+
+def test_torch_library_registration():
+    """`torch.ops.mi_oov.*` (mi_oov/torch_ops.py): every op has a schema, the CPU key raises instead of computing, and
+    the fake-tensor rule gives shapes / dtypes without a device."""
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    from mi_oov import torch_ops
+    for name in torch_ops.OPS:
+        assert hasattr(torch.ops.mi_oov, name), name
+    ids = torch.zeros(3, dtype=torch.int64)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torch.ops.mi_oov.lsh_embed(ids, torch.zeros(5, 64), torch.zeros(8, 64), torch.zeros(8, 64))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        torch.ops.mi_oov.mapper_map(ids, "3round", 2, 3)
+    with FakeTensorMode():
+        fids = torch.zeros(7, dtype=torch.int64, device="cuda")
+        feat, planes = torch.zeros(5, 64, device="cuda"), torch.zeros(8, 64, device="cuda")
+        out = torch.ops.mi_oov.lsh_embed(fids, feat, planes, torch.zeros(8, 32, device="cuda"))
+        assert out.shape == (7, 32) and out.dtype == torch.float32
+        assert torch.ops.mi_oov.lsh_bits(fids, feat, planes).dtype == torch.uint8
+        vals, idx = torch.ops.mi_oov.score_topk(torch.zeros(4, 64, device="cuda"), torch.zeros(100, 64, device="cuda"), 5, 1)
+        assert vals.shape == (4, 5) and idx.dtype == torch.int64
+        many = torch.ops.mi_oov.lsh_embed_score_multi([fids, fids], feat, planes, torch.zeros(8, 64, device="cuda"),
+                                                      [torch.zeros(7, 64, device="cuda")] * 2)
+        assert len(many) == 2 and many[0].shape == (7,)
