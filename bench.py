@@ -349,6 +349,7 @@ def main():
 
     per_lookup = (16 + 4 * F + 4 * D + 4) if mode != "unfused" else (8 + 4 * F + 4 * D)
     moved = per_lookup - 8 if mode != "unfused" else per_lookup
+
     def sharded_runner():
         """N > 1, `--table sharded`: the feature table row-sharded over the ranks, every rank's batches looked up through
         the owner-computes exchange (mi_oov.sharded: ids out, 8-byte codes back, both by RCCL all_to_all_single), steps
@@ -357,20 +358,7 @@ def main():
         S = max(1, min(args.batches_per_exchange, ring, n_ramp))
         lo, hi, _ = sharded.shard_bounds(N, world, rank)
         feat_l, planes_l, buckets_l = make_inputs(args, dev, hi - lo, lo)
-
-        class TimedPrims(sharded.HipPrims):  # HIP events around every launch of the owner kernel
-            events = []
-
-            @staticmethod
-            def codes(local_ids, feat_local, planes_t):
-                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev[0].record()
-                out = sharded.HipPrims.codes(local_ids, feat_local, planes_t)
-                ev[1].record()
-                TimedPrims.events.append(ev)
-                return out
-
-        table = sharded.ShardedLSHTable(feat_l, N, prims=TimedPrims, cap_factor=args.cap_factor, uniform_batches=True)
+        table = sharded.ShardedLSHTable(feat_l, N, cap_factor=args.cap_factor, uniform_batches=True)
         pipe = sharded.LshPipeline(table, planes_l, buckets_l)
         flat_ids = all_ids.view(-1)
         ramp_rows, ring_rows, ring_scores = ramp_users.view(-1, D), users.view(-1, D), scores.view(-1)
@@ -392,29 +380,32 @@ def main():
 
         def run_steps(i0, n):
             bl = blocks(i0, n)
-            TimedPrims.events = []
             pipe.run([b[0] for b in bl], [b[1] for b in bl], [b[2] for b in bl])
             return len(bl)
 
         elapsed_s, region_ms, n_blocks = time_region(run_steps)
         torch.cuda.synchronize()
-        owner_ms = reduce_max(sum(a.elapsed_time(b) for a, b in TimedPrims.events) / max(1, len(TimedPrims.events)))
         dropped = reduce_max(float(table.overflow.item()))  # every rank learns of an overflow on any rank
         if dropped:
             raise RuntimeError(f"--cap-factor {args.cap_factor} too tight: a segment overflowed by {int(dropped)} lookups")
         if rank != 0:
             return {}
-        owner_bytes = (8 + 4 * F + H) * B * K / n_blocks  # per launch of the owner kernel: ids in, feature rows, codes out
-        achieved = owner_bytes / (owner_ms * 1e-3) / 1e9 if owner_ms > 0 else 0.0
+        # The three kernels of an exchange (bucketing of step t+2, owner of step t, requester of step t-1) run on three
+        # streams at once and share HBM, so no kernel has a duration of its own: the roofline object is the whole step --
+        # algorithmic bytes of all three per lookup over the HIP-event time of the region.
+        step_bytes = (8 + 8 + 4) + (8 + 4 * F + H) + (4 + H + 4 * D + 4)
+        step_us = region_ms * 1e3 / K
+        achieved = step_bytes * B / (step_us * 1e-6) / 1e9 if step_us > 0 else 0.0
         return {"value": world * B * K / elapsed_s, "ms_per_step": 1e3 * elapsed_s / K,
                 "table": f"feature table row-sharded over {world} ranks ({hi - lo} rows here), planes + bucket table replicated",
                 "entry_point": "mi_oov_bucket_by_owner + mi_oov_lsh_embed(bits) + mi_oov_lsh_codes_embed",
-                "launch_mode": f"owner-computes exchange, {S} steps per exchange, three exchanges in flight",
-                "roofline": {"bound": "hbm", "kernel": "lsh64_persistent_kernel<8, 1, false> (owner: feature rows -> codes)",
+                "launch_mode": f"owner-computes exchange, up to {S} steps per exchange, three exchanges in flight on three streams",
+                "roofline": {"bound": "hbm", "kernel": "bucket_by_owner_small_kernel + lsh64_persistent_kernel<8, 1, false> (owner) + "
+                                                       "lsh64_persistent_kernel<8, 2, false> (requester), concurrent",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                             "bytes_per_lookup": 8 + 4 * F + H, "lookups_per_launch": B * K / n_blocks,
-                             "launches": n_blocks, "avg_launch_us": owner_ms * 1e3, "traffic": None,
-                             "note": "HIP events around each owner-kernel launch; exchanges of neighbouring steps run beside it"},
+                             "bytes_per_lookup": step_bytes, "lookups_per_launch": B * K / n_blocks,
+                             "launches": n_blocks, "avg_launch_us": region_ms * 1e3 / n_blocks, "traffic": None,
+                             "note": "one 'launch' = one exchange (three kernels + two all-to-alls); HIP events over the timed region"},
                 "detail": {"steps_per_exchange": S, "exchanges": n_blocks, "segment_capacity": table.capacity(min(S, K) * B),
                            "cap_factor": args.cap_factor, "bytes_on_wire_per_lookup": 8 + H,
                            "region_ms_hip_events": region_ms, "us_per_step_hip_events": region_ms * 1e3 / K,

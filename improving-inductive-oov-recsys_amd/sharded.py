@@ -196,28 +196,77 @@ class LshPipeline:
 
         step t:   wait ids_t -> owner_t -> send codes_t | finish_{t-1} (codes_{t-1} arrived long ago)
                   | bucket_{t+2} -> send ids_{t+2}
-    The collectives are asynchronous (RCCL's own stream); the kernels stay on the caller's stream, which only ever
-    waits for an exchange issued a whole step earlier."""
+    The collectives are asynchronous (RCCL's own stream) and a kernel only ever waits for an exchange issued a whole
+    step earlier.
 
-    def __init__(self, table, planes, buckets):
+    `streams=True` (the default on a ROCm device with the RCCL backend) puts the three stages on three streams: the
+    owner kernel of step t (random 256-B rows of the local shard), the requester kernel of step t-1 (the sequential
+    rows of the other side) and the bucketing of step t+2 are independent, and run side by side they share HBM the way
+    the fused single-GPU kernel's gather and stream do -- the owner kernel keeps 2 waves per SIMD at 111 VGPRs, the
+    requester kernel 2 at 92, 72 KiB of LDS together, so both are resident on every CU.  Tensors that cross streams
+    are recorded on the stream that reads them (torch's allocator then keeps their memory until that stream has
+    passed); the caller's stream waits for all three at the end of `run`."""
+
+    def __init__(self, table, planes, buckets, streams=None):
         self.table, self.planes, self.buckets = table, planes, buckets
+        dev = table.feat_local.device
+        if streams is None:
+            streams = dev.type == "cuda" and _backend(table.group) == "nccl"
+        self.streams = [torch.cuda.Stream(dev) for _ in range(3)] if streams else None
 
     def run(self, ids, others, scores):
         """ids[t] int64[M], others[t] f32[M,D], scores[t] f32[M] (written).  No host synchronisation."""
         t_, n = self.table, len(ids)
         if n == 0:
             return
-        pend = [t_.begin(ids[t], async_op=True) for t in range(min(2, n))]
+        if self.streams is None:
+            pend = [t_.begin(ids[t], async_op=True) for t in range(min(2, n))]
+            prev = None
+            for t in range(n):
+                p = pend.pop(0)
+                t_.owner(p, self.planes, async_op=True)
+                if prev is not None:
+                    t_.finish(prev[0], self.buckets, others[prev[1]], want_emb=False, score_out=scores[prev[1]])
+                if t + 2 < n:
+                    pend.append(t_.begin(ids[t + 2], async_op=True))
+                prev = (p, t)
+            t_.finish(prev[0], self.buckets, others[prev[1]], want_emb=False, score_out=scores[prev[1]])
+            return
+        s_bucket, s_owner, s_req = self.streams
+        caller = torch.cuda.current_stream(t_.feat_local.device)
+        for s in self.streams:  # the inputs were produced on the caller's stream
+            s.wait_stream(caller)
+
+        def begin(t):
+            with torch.cuda.stream(s_bucket):
+                return t_.begin(ids[t], async_op=True)
+
+        def owner(p):
+            with torch.cuda.stream(s_owner):
+                p.recv.record_stream(s_owner)  # allocated on the bucket stream, read here
+                t_.owner(p, self.planes, async_op=True)
+
+        def finish(p, t):
+            with torch.cuda.stream(s_req):
+                p.slot.record_stream(s_req)  # bucket stream -> here
+                t_._wait(p.w_back)
+                p.w_back = None
+                p.back.record_stream(s_req)  # owner stream -> here
+                t_.finish(p, self.buckets, others[t], want_emb=False, score_out=scores[t])
+
+        pend = [begin(t) for t in range(min(2, n))]
         prev = None
         for t in range(n):
             p = pend.pop(0)
-            t_.owner(p, self.planes, async_op=True)
+            owner(p)
             if prev is not None:
-                t_.finish(prev[0], self.buckets, others[prev[1]], want_emb=False, score_out=scores[prev[1]])
+                finish(*prev)
             if t + 2 < n:
-                pend.append(t_.begin(ids[t + 2], async_op=True))
+                pend.append(begin(t + 2))
             prev = (p, t)
-        t_.finish(prev[0], self.buckets, others[prev[1]], want_emb=False, score_out=scores[prev[1]])
+        finish(*prev)
+        for s in self.streams:  # results (and the overflow counter) are visible to the caller's stream
+            caller.wait_stream(s)
 
 
 class ShardedSLSHTable(_ShardedBase):
