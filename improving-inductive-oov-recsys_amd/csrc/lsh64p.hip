@@ -120,6 +120,16 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned tpb = (B + 15) / 16, nfull = B / 16;
   const unsigned G = gridDim.x * kPWpb;
+#ifdef MI_PSTAMPS  // developer build (tools/multi_bench MB_STAMPS=1): per-wave s_memrealtime stamps behind the bucket table
+  uint64_t* stamps = reinterpret_cast<uint64_t*>(const_cast<float*>(buckets) + H * 64) + (blockIdx.x * kPWpb + wv) * 4;
+  const uint64_t st0 = __builtin_amdgcn_s_memrealtime();
+  uint64_t st1 = 0, st2 = 0;
+#define MI_STAMP(v) v = __builtin_amdgcn_s_memrealtime()
+#define MI_STAMPS_OUT() do { if (lane == 0) { stamps[0] = st0; stamps[1] = st1; stamps[2] = st2; stamps[3] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define MI_STAMP(v)
+#define MI_STAMPS_OUT()
+#endif
 
   auto ids_of = [&](unsigned batch) -> gptr_i64 {
     return TAB ? (gptr_i64) reinterpret_cast<const int64_t* const*>(ids_src)[batch] : (gptr_i64)ids_src;
@@ -210,21 +220,43 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   float4 xa[4], ua[NU], xb[4], ub[NU];
   if (MI_PEARLY && pa.batch < K) load_rows(pa, ida, xa, ua);
   if constexpr (kScore) {
-    for (int i = threadIdx.x; i < kTabRows * 16; i += kPBlk) {
-      const int c = i >> 4, l = i & 15;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      float cnt = 0.f;
+    // Table build (stamps: 5.5 us with one independent 8-step chain per entry).  The chain of a code runs over the planes
+    // in increasing order, so all codes with the same LOW bits share its first steps: a thread takes one lane slice and one
+    // pattern of the low kLow planes, runs that prefix once, and finishes the 2^(H - kLow) codes above it -- every
+    // fmaf(bit, w, acc) of the per-lookup chain is still executed (zero bits included: a non-finite bucket weight must
+    // poison the row exactly as it does there), in the same order, so the entries are the same bits as before.
+    constexpr int kLow = H < 5 ? H : 5, kHigh = H - kLow;
+    for (int i = threadIdx.x; i < (16 << kLow); i += kPBlk) {
+      const int m = i >> 4, l = i & 15;
+      float4 w[H];
 #pragma unroll
-      for (int h = 0; h < H; ++h) {
-        const float bit = ((c >> h) & 1) ? 1.f : 0.f;
-        const float4 w = *reinterpret_cast<const float4*>(sbuckets + (h * 16 + l) * 4);
-        cnt = cnt + bit;
-        acc.x = __builtin_fmaf(bit, w.x, acc.x);
-        acc.y = __builtin_fmaf(bit, w.y, acc.y);
-        acc.z = __builtin_fmaf(bit, w.z, acc.z);
-        acc.w = __builtin_fmaf(bit, w.w, acc.w);
+      for (int h = 0; h < H; ++h) w[h] = *reinterpret_cast<const float4*>(sbuckets + (h * 16 + l) * 4);
+      float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+      float cpre = 0.f;
+#pragma unroll
+      for (int h = 0; h < kLow; ++h) {
+        const float bit = ((m >> h) & 1) ? 1.f : 0.f;
+        cpre = cpre + bit;
+        pre.x = __builtin_fmaf(bit, w[h].x, pre.x);
+        pre.y = __builtin_fmaf(bit, w[h].y, pre.y);
+        pre.z = __builtin_fmaf(bit, w[h].z, pre.z);
+        pre.w = __builtin_fmaf(bit, w[h].w, pre.w);
       }
-      *reinterpret_cast<float4*>(sw + i * 4) = masked_mean(acc, cnt);
+#pragma unroll
+      for (int hi = 0; hi < (1 << kHigh); ++hi) {
+        float4 acc = pre;
+        float cnt = cpre;
+#pragma unroll
+        for (int h = kLow; h < H; ++h) {
+          const float bit = ((hi >> (h - kLow)) & 1) ? 1.f : 0.f;
+          cnt = cnt + bit;
+          acc.x = __builtin_fmaf(bit, w[h].x, acc.x);
+          acc.y = __builtin_fmaf(bit, w[h].y, acc.y);
+          acc.z = __builtin_fmaf(bit, w[h].z, acc.z);
+          acc.w = __builtin_fmaf(bit, w[h].w, acc.w);
+        }
+        *reinterpret_cast<float4*>(sw + (((hi << kLow) | m) * 16 + l) * 4) = masked_mean(acc, cnt);
+      }
     }
     __syncthreads();
   }
@@ -310,9 +342,11 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   };
 
   if (pa.batch >= K) return;  // (after the barriers above)
+  MI_STAMP(st1);  // weights / table ready
   if (!MI_PEARLY) load_rows(pa, ida, xa, ua);
   if (pb.batch >= K) {  // one tile only
     finish(pa, ida, xa, ua);
+    MI_STAMPS_OUT();
     return;
   }
   for (;;) {
@@ -323,6 +357,7 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
       asm volatile("" ::: "memory");
       finish(pa, ida, xa, ua);
       finish(pb, idb, xb, ub);
+      MI_STAMPS_OUT();
       return;
     }
     idn = load_ids(pn);
@@ -330,6 +365,9 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     load_rows(pb, idb, xb, ub);
     asm volatile("" ::: "memory");
     finish(pa, ida, xa, ua);
+#ifdef MI_PSTAMPS
+    if (st2 == 0) MI_STAMP(st2);  // first tile finished
+#endif
     // current tile b in (xb, ub); ids of tile n requested
     pa = advance(pn);
     if (pa.batch >= K) {  // drain: n is the last tile
@@ -337,6 +375,7 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
       asm volatile("" ::: "memory");
       finish(pb, idb, xb, ub);
       finish(pn, idn, xa, ua);
+      MI_STAMPS_OUT();
       return;
     }
     ida = load_ids(pa);

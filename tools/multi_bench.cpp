@@ -65,7 +65,7 @@ int main(int argc, char** argv) {
   int64_t* ids;
   CK(hipMalloc(&feat, (size_t)N * 256));
   CK(hipMalloc(&planes, H * 256));
-  CK(hipMalloc(&buckets, H * 256));
+  CK(hipMalloc(&buckets, H * 256 + 4096 * 4 * 8));  // + room for a stamps build's per-wave timestamps
   CK(hipMalloc(&users, (size_t)R * B * 256));
   CK(hipMalloc(&ids, (size_t)T * B * 8));
   CK(hipMalloc(&sc_m, (size_t)T * B * 4));
@@ -158,6 +158,46 @@ int main(int argc, char** argv) {
     std::sort(t.begin(), t.end());
     printf("isolated launches (idle %d us before each): per batch min %.3f  p25 %.3f  median %.3f  p75 %.3f  max %.3f us\n",
            idle_us, t[0], t[10], t[20], t[30], t[39]);
+  }
+  if (getenv("MB_STAMPS")) {  // library built with -DMI_PSTAMPS: per-wave timeline of ONE isolated launch (100 MHz clock)
+    CK(hipStreamSynchronize(st));
+    CK(hipMemset(reinterpret_cast<char*>(buckets) + H * 256, 0, 4096 * 4 * 8));
+    run_multi();
+    CK(hipStreamSynchronize(st));
+    std::vector<uint64_t> s4(4096 * 4);
+    CK(hipMemcpy(s4.data(), reinterpret_cast<char*>(buckets) + H * 256, s4.size() * 8, hipMemcpyDeviceToHost));
+    uint64_t t0 = ~0ull;
+    int nw = 0;
+    for (int w = 0; w < 4096; ++w) if (s4[w * 4 + 3]) { t0 = std::min(t0, s4[w * 4]); ++nw; }
+    std::vector<double> a, b, c, d;
+    for (int w = 0; w < 4096; ++w) if (s4[w * 4 + 3]) {
+      a.push_back((s4[w * 4] - t0) * 0.01); b.push_back((s4[w * 4 + 1] - t0) * 0.01);
+      c.push_back((s4[w * 4 + 2] - t0) * 0.01); d.push_back((s4[w * 4 + 3] - t0) * 0.01);
+    }
+    auto pr = [&](const char* nm, std::vector<double>& v) {
+      std::sort(v.begin(), v.end());
+      printf("  %-28s min %7.2f  p50 %7.2f  p90 %7.2f  max %7.2f us\n", nm, v[0], v[v.size() / 2], v[v.size() * 9 / 10], v.back());
+    };
+    printf("stamps of %d waves (us after the first wave's start):\n", nw);
+    pr("wave start", a); pr("weights + table ready", b); pr("first tile finished", c); pr("wave end", d);
+    // where do the slow waves sit?  workgroup b runs on XCD b % 8 (round-robin dispatch); 8 waves per workgroup
+    const int wpb = nw / 256 > 0 ? nw / 256 : 1;
+    double xs[8] = {0}, xm[8] = {0}; int xn[8] = {0};
+    double in_wg = 0;
+    for (int blk = 0; blk * wpb < nw; ++blk) {
+      double lo = 1e30, hi = 0;
+      for (int w = 0; w < wpb; ++w) {
+        const double e = (s4[(blk * wpb + w) * 4 + 3] - t0) * 0.01;
+        lo = std::min(lo, e); hi = std::max(hi, e);
+        xs[blk % 8] += e; xm[blk % 8] = std::max(xm[blk % 8], e); ++xn[blk % 8];
+      }
+      in_wg += hi - lo;
+    }
+    printf("  wave end by XCD (workgroup %% 8): mean");
+    for (int x = 0; x < 8; ++x) printf(" %6.1f", xs[x] / std::max(1, xn[x]));
+    printf("\n                                   max ");
+    for (int x = 0; x < 8; ++x) printf(" %6.1f", xm[x]);
+    printf("\n  mean spread of wave ends INSIDE a workgroup: %.2f us\n", in_wg / (nw / wpb));
   }
   for (int rep = 0; rep < 2; ++rep) {
     CK(hipEventRecord(e0, st));
