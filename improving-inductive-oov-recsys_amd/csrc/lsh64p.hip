@@ -43,10 +43,18 @@
 //     same hint on the gathered rows costs 0.15 us)
 //   K = 20 batches per launch 5.6 us, K = 4: 6.5 us (the launch's head and tail are paid once per launch).
 //
-// Scheduling is static (wave g of G takes tiles g, g+G, ...): uniform work per tile, no counter to contend for, and
-// the sequential rows of the other side are then swept by all waves as one moving front (DRAM page locality).
-// Every wave's loop is bounded by the tile count, so the grid always drains.
+// Scheduling: the first quarter of a launch's tiles is dealt statically (wave g of G takes tiles g, g+G, ...: no
+// counter, and the sequential rows of the other side are swept by all waves as one moving front), the rest comes
+// from a pool of tile pairs the waves draw tickets for (scalar atomics; see "schedule" in the kernel) -- with every
+// tile dealt statically the waves of a 20-batch launch ended between 86 and 110 us after its start, with the pool
+// between 98 and 106.  Per batch, same harness: K = 64: 5.39 -> 5.16 us (0.845 of peak), K = 20: 5.5 -> 5.4,
+// launches of fewer than 12 pairs per wave keep the fixed order (the pool's own costs outweigh it there).
+// Every wave's loop is bounded by the tile count (static rounds) or ends at the first ticket past the pool's last
+// pair, so the grid always drains.
 #include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
 
 #include "common.hpp"
 #include "lsh64_tile.hpp"
@@ -55,6 +63,9 @@ namespace mi_oov {
 
 // Developer knobs (tools/multi_bench.sh builds variants): MI_PW = waves per SIMD the register allocation is bounded
 // for; MI_PWPB = waves per workgroup; MI_PNT_X / MI_PNT_U = non-temporal loads for the gathered / sequential rows.
+#ifndef MI_PSTATIC
+#define MI_PSTATIC 25  // per cent of a launch's tiles dealt statically (the rest: the ticket pool)
+#endif
 #ifndef MI_PW
 #define MI_PW 2
 #endif
@@ -111,7 +122,9 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
                                                                         void* __restrict__ out_src, unsigned K, unsigned B,
                                                                         const float* __restrict__ feat, int64_t N,
                                                                         const float* __restrict__ planes,
-                                                                        const float* __restrict__ buckets) {
+                                                                        const float* __restrict__ buckets,
+                                                                        unsigned* __restrict__ sched,
+                                                                        unsigned* __restrict__ sched_busy) {
   static_assert(MODE == kModeScore || H == 8, "codes are written as one 8-byte word per lookup");
   constexpr bool kFromCodes = MODE == kModeFromCodes;  // ids = int32 slots, feat = u8[N,8] codes
   constexpr bool kScore = MODE == kModeScore || kFromCodes;
@@ -184,18 +197,100 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     }
   };
 
-  // The ids of the wave's first two tiles go out before anything else: their round trip (the first hop of the ids ->
-  // rows chain) overlaps the staging of the weights and the table build instead of following them.
-  TilePos pa, pb, pn;
-  {
-    const unsigned g = blockIdx.x * kPWpb + wv;
-    pa.batch = g / tpb;
-    pa.local = g - pa.batch * tpb;
+  // ---- schedule ------------------------------------------------------------------------------------------------------
+  // Per-wave stamps of the statically scheduled kernel (tools/multi_bench MB_STAMPS=1): with every wave given exactly
+  // the same 40 tiles, the first wave ends at 86 us and the last at 109 -- some XCDs and some waves of a CU get ~10 % less
+  // of the memory system than others, and the launch lasts as long as its slowest wave.  So only the first three
+  // quarters of the tiles are dealt statically (wave g takes tiles g, g + G, ...: no counter, and the sequential rows of
+  // the other side are swept as one front); the rest is a POOL of tile pairs that waves draw from as they get there.
+  // The pool has kPWpb ticket counters, 256 B apart; a wave uses counter (workgroup + wave slot) % kPWpb, so every
+  // counter is shared by all eight wave slots and all eight XCDs alike (waves differ in speed along both: shared by wave
+  // slot, the counters of the fast slots ran dry 20 us before the others), the fast waves take more, all counters run
+  // dry together, and a counter sees one draw per 2 tiles of 1/kPWpb of the chip (~50 per us: an address takes ~90).
+  // Ticket t of counter c is pair t * kPWpb + c, so the pairs in flight stay one front.  A draw is a SCALAR atomic
+  // (s_atomic_add ... glc, waited for on lgkmcnt in the same asm statement): the wave's vector loads stay in flight
+  // across it and their s_waitcnt vmcnt immediates are untouched (a returning vector atomic makes the compiler wait for
+  // vmcnt(0) wherever its result is read, which drains the pipeline; tools/probe/satomic.hip checks the instruction).
+  // A wave draws the ticket of its NEXT pair just before it would wait for a tile's rows anyway, so the counter's round
+  // trip is spent in the shadow of that wait; its first ticket it draws at the very start of the kernel.
+  // The last wave of a counter to leave resets it, and the last of those clears the counter set's "busy" word in host
+  // memory, which is how the host knows it may hand the set to another launch (launches need no memset, no event).
+  // sched == nullptr (a launch being captured into a graph, whose replays the host cannot see; or no free counter set):
+  // the same tickets are dealt in a fixed order instead, workgroup b taking tickets b, b + gridDim.x, ... of its counters.
+  const unsigned T = K * tpb;                               // tiles of the launch (<= 2^30)
+  const unsigned nsp = static_cast<unsigned>((static_cast<uint64_t>(T) * MI_PSTATIC / 100) / (2 * G));  // static pairs per wave
+  const unsigned Ts = 2 * G * nsp;                          // tiles dealt statically
+  const unsigned Pp = (T - Ts + 1) / 2;                     // pool pairs (the last one may repeat tile T - 1)
+  const unsigned shard = (blockIdx.x + wv) % kPWpb;
+  unsigned* ticket_ctr = sched + shard * 64;
+  unsigned* exit_ctr = ticket_ctr + 32;
+  const unsigned gwave = blockIdx.x * kPWpb + wv;
+  auto pos_of = [&](unsigned t) {
+    TilePos p;
+    p.batch = t / tpb;
+    p.local = t - p.batch * tpb;
+    return p;
+  };
+  unsigned dealt = blockIdx.x;  // (sched == nullptr)
+  auto draw = [&]() -> unsigned {
+    unsigned t = 1;
+    if (sched) {
+      asm volatile("s_atomic_add %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "+s"(t) : "s"(ticket_ctr) : "memory");
+    } else {
+      t = dealt;
+      dealt += gridDim.x;
+    }
+    return t;
+  };
+  auto pool_pair = [&](unsigned ticket, TilePos& p0, TilePos& p1) -> bool {
+    const unsigned pair = ticket * kPWpb + shard;
+    if (pair >= Pp) return false;
+    const unsigned t0 = Ts + 2 * pair;
+    p0 = pos_of(t0);
+    p1 = pos_of(t0 + 1 < T ? t0 + 1 : T - 1);  // odd T: the very last pair scores tile T - 1 twice (same values)
+    return true;
+  };
+  auto leave = [&]() {  // every wave passes here exactly once, after its last draw
+    if (sched && lane == 0) {
+      const unsigned done = __hip_atomic_fetch_add(exit_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (done == gridDim.x - 1) {  // the last wave of this counter (every workgroup has one): zero for the next launch
+        __hip_atomic_store(ticket_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(exit_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Order: the two stores are acknowledged (vmcnt) before this counter is reported finished, and the busy word is
+        // cleared by whoever sees all kPWpb reported.  No release fence: on this chip one is a write-back of the L2,
+        // which the end of the kernel is about to do anyway, and all of this sits behind the launch's LAST wave.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned* counters_done = sched + 48;  // (third quarter of counter 0's line)
+        if (__hip_atomic_fetch_add(counters_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kPWpb - 1) {
+          __hip_atomic_store(counters_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifndef MI_PNOFLAG
+          __hip_atomic_store(sched_busy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
+        }
+      }
+    }
+  };
+
+  // The ids of the wave's first two tiles go out before anything else: their round trip overlaps the staging of the
+  // weights and the table build instead of following them.
+  // (A launch with a static part draws its first ticket behind those loads; one without needs it to know its tiles.)
+  TilePos pa, pb, pn, pm;
+  unsigned tk = 0;
+  bool have = true;
+  if (nsp > 0) {
+    pa = pos_of(gwave);
+    pb = advance(pa);
+  } else {
+    have = pool_pair(draw(), pa, pb);
   }
-  pb = advance(pa);
-  int64_t ida = 0, idb = 0, idn;
-  if (pa.batch < K) ida = load_ids(pa);
-  if (pb.batch < K) idb = load_ids(pb);
+  int64_t ida = 0, idb = 0, idn, idm;
+  if (have) {
+    ida = load_ids(pa);
+    idb = load_ids(pb);
+    asm volatile("" ::: "memory");
+    tk = draw();
+  }
 
   // Weights.  Planes and bucket rows are staged global -> LDS first; then -- the ids have landed with them, vmcnt
   // retires in order -- the rows of the wave's FIRST tile are requested, and the 2^H-row table of aggregates (score
@@ -218,7 +313,7 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   }
   __syncthreads();
   float4 xa[4], ua[NU], xb[4], ub[NU];
-  if (MI_PEARLY && pa.batch < K) load_rows(pa, ida, xa, ua);
+  if (MI_PEARLY && have) load_rows(pa, ida, xa, ua);
   if constexpr (kScore) {
     // Table build (stamps: 5.5 us with one independent 8-step chain per entry).  The chain of a code runs over the planes
     // in increasing order, so all codes with the same LOW bits share its first steps: a thread takes one lane slice and one
@@ -341,52 +436,135 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     }
   };
 
-  if (pa.batch >= K) return;  // (after the barriers above)
-  MI_STAMP(st1);  // weights / table ready
-  if (!MI_PEARLY) load_rows(pa, ida, xa, ua);
-  if (pb.batch >= K) {  // one tile only
-    finish(pa, ida, xa, ua);
-    MI_STAMPS_OUT();
+  if (!have) {  // no tile for this wave (after the barriers above)
+    leave();
     return;
   }
-  for (;;) {
-    // current tile a in (xa, ua), rows requested; ids of tile b requested
-    pn = advance(pb);
-    if (pn.batch >= K) {  // drain: b is the last tile
-      load_rows(pb, idb, xb, ub);
-      asm volatile("" ::: "memory");
-      finish(pa, ida, xa, ua);
-      finish(pb, idb, xb, ub);
-      MI_STAMPS_OUT();
-      return;
-    }
+  MI_STAMP(st1);  // weights / table ready
+  if (!MI_PEARLY) load_rows(pa, ida, xa, ua);
+  // (The ids are in registers by now.  Saying so here -- an empty statement that "rewrites" them -- keeps the compiler's
+  // wait-count analysis from carrying "idb may be the youngest load in flight", which it concludes from the branches of
+  // the prologue, into the loop, where it would turn the first wait of every iteration into vmcnt(0).)
+  asm volatile("" : "+v"(ida), "+v"(idb));
+  // One iteration retires the pair (a, b) -- a's rows and b's ids are in flight -- and brings the next pair (n, m) to
+  // that state:    ids(n)  rows(b)  finish(a)      ids(m)  rows(n)  finish(b)
+  auto step_pair = [&](bool pool) {
     idn = load_ids(pn);
     asm volatile("" ::: "memory");
     load_rows(pb, idb, xb, ub);
     asm volatile("" ::: "memory");
+    if (pool) tk = draw();
     finish(pa, ida, xa, ua);
 #ifdef MI_PSTAMPS
     if (st2 == 0) MI_STAMP(st2);  // first tile finished
 #endif
-    // current tile b in (xb, ub); ids of tile n requested
-    pa = advance(pn);
-    if (pa.batch >= K) {  // drain: n is the last tile
-      load_rows(pn, idn, xa, ua);
-      asm volatile("" ::: "memory");
-      finish(pb, idb, xb, ub);
-      finish(pn, idn, xa, ua);
-      MI_STAMPS_OUT();
-      return;
-    }
-    ida = load_ids(pa);
+    idm = load_ids(pm);
     asm volatile("" ::: "memory");
     load_rows(pn, idn, xa, ua);
     asm volatile("" ::: "memory");
     finish(pb, idb, xb, ub);
-    // rotate: tile n is current (its rows are in xa, ua), the tile after it has its ids in flight
-    pb = pa; idb = ida;
     pa = pn; ida = idn;
+    pb = pm; idb = idm;
+  };
+  // ONE loop for both phases (a second copy of the body costs register moves of rows in flight at its head)
+  for (unsigned r = 1;;) {
+    const bool pool = r >= nsp;
+    if (!pool) {
+      pn = advance(pb);
+      pm = advance(pn);
+      ++r;
+    } else if (!pool_pair(tk, pn, pm)) {
+      break;
+    }
+    step_pair(pool);
   }
+  // drain: (a, b) is the wave's last pair
+  load_rows(pb, idb, xb, ub);
+  asm volatile("" ::: "memory");
+  finish(pa, ida, xa, ua);
+  finish(pb, idb, xb, ub);
+  MI_STAMPS_OUT();
+  leave();
+}
+
+// Counter sets of the tile pool (see the kernel): kSchedSlots sets of kPWpb lines of 64 words (ticket counter, exit
+// counter at +32, and in line 0 the count of finished counters at +48) per device, zero at load and left at zero by
+// every launch.  A set serves ONE launch at a time: the host marks it busy in a word of pinned host memory when it hands
+// it out, the last wave of the launch clears the word.  Nothing is handed out to a launch that is being captured (the
+// kernel then deals the tickets in a fixed order), when every set is busy, or when MI_OOV_POOL=0.
+constexpr int kSchedSlots = 32, kSchedDevices = 16;
+__device__ unsigned g_sched[kSchedSlots][kPWpb * 64];
+struct SchedSlot {
+  unsigned* counters = nullptr;  // device
+  unsigned* busy_dev = nullptr;  // device address of the busy word
+  unsigned* busy = nullptr;      // host address of the same word
+};
+struct SchedPool {
+  unsigned* counters = nullptr;
+  unsigned* busy = nullptr;
+  unsigned* busy_dev = nullptr;
+  unsigned turn = 0;
+  int state = 0;  // 0 new, 1 ready, -1 unusable
+};
+static SchedPool g_pools[kSchedDevices];
+static std::mutex g_pool_mutex;
+
+static bool pool_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("MI_OOV_POOL");  // developer knob: 0 = always deal the tickets in a fixed order
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+
+// A launch of fewer than kPoolMinPairs tile pairs per wave is over before the spread between waves has grown past what
+// the pool's own costs are (the draws, and the hand-back after the last wave: ~1.5 us per launch; K = 4 batches of
+// 65536: 6.2 us per batch dealt in fixed order, 6.6 from the pool; K = 20: 5.5 and 5.4; K = 64: 5.39 and 5.16).
+constexpr int64_t kPoolMinPairs = 12;
+
+static SchedSlot take_sched_slot(hipStream_t st, int64_t tiles, int grid) {
+  SchedSlot none;
+  if (!pool_enabled() || tiles < kPoolMinPairs * 2 * kPWpb * grid) return none;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return none;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSchedDevices) return none;
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  SchedPool& pool = g_pools[dev];
+  if (pool.state == 0) {
+    pool.state = -1;
+    void* host = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&pool.counters), HIP_SYMBOL(g_sched)) == hipSuccess &&
+        hipHostMalloc(&host, kSchedSlots * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      memset(host, 0, kSchedSlots * sizeof(unsigned));
+      pool.busy = static_cast<unsigned*>(host);
+      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&pool.busy_dev), host, 0) == hipSuccess) pool.state = 1;
+    }
+    if (pool.state != 1) (void)hipGetLastError();
+  }
+  if (pool.state != 1) return none;
+  for (int i = 0; i < kSchedSlots; ++i) {
+    const unsigned s = (pool.turn + i) % kSchedSlots;
+    if (__atomic_load_n(&pool.busy[s], __ATOMIC_ACQUIRE) == 0) {
+      __atomic_store_n(&pool.busy[s], 1u, __ATOMIC_RELAXED);
+      pool.turn = s + 1;
+      SchedSlot slot;
+      slot.counters = pool.counters + static_cast<size_t>(s) * (kPWpb * 64);
+      slot.busy_dev = pool.busy_dev + s;
+      slot.busy = pool.busy + s;
+      return slot;
+    }
+  }
+  return none;
+}
+// after a launch: a set whose kernel never started is handed back by the host
+static int check_pool_launch(const SchedSlot& slot) {
+  const int rc = check_launch();
+  if (rc != MI_OOV_OK && slot.busy) __atomic_store_n(slot.busy, 0u, __ATOMIC_RELEASE);
+  return rc;
 }
 
 // resident workgroups of a persistent kernel on the current device (occupancy x CUs), cached per instantiation
@@ -430,10 +608,11 @@ static int launch_multi(const int64_t* const* ids_tab, const float* const* other
     const int64_t nk = (K - k0 < kmax) ? K - k0 : kmax;
     const int64_t blocks_needed = (nk * tpb + kPWpb - 1) / kPWpb;
     const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
+    const SchedSlot cset = take_sched_slot(st, nk * tpb, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(ids_tab + k0),
                        static_cast<const void*>(other_tab + k0), static_cast<void*>(const_cast<float**>(score_tab + k0)),
-                       static_cast<unsigned>(nk), static_cast<unsigned>(B), feat, N, planes, buckets);
-    if (int rc = check_launch()) return rc;
+                       static_cast<unsigned>(nk), static_cast<unsigned>(B), feat, N, planes, buckets, cset.counters, cset.busy_dev);
+    if (int rc = check_pool_launch(cset)) return rc;
   }
   return MI_OOV_OK;
 }
@@ -455,10 +634,11 @@ int launch_lsh64_codes_persistent(const int64_t* ids, int64_t B, const float* fe
     const int64_t nb = (B - b0 < kMaxRows) ? B - b0 : kMaxRows;
     const int64_t blocks_needed = ((nb + 15) / 16 + kPWpb - 1) / kPWpb;
     const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
+    const SchedSlot cset = take_sched_slot(st, (nb + 15) / 16, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(ids + b0),
                        static_cast<const void*>(nullptr), static_cast<void*>(bits + b0 * 8), 1u, static_cast<unsigned>(nb),
-                       feat, N, planes, static_cast<const float*>(nullptr));
-    if (int rc = check_launch()) return rc;
+                       feat, N, planes, static_cast<const float*>(nullptr), cset.counters, cset.busy_dev);
+    if (int rc = check_pool_launch(cset)) return rc;
   }
   return MI_OOV_OK;
 }
@@ -481,11 +661,12 @@ int launch_lsh64_from_codes(const uint8_t* codes, int64_t M, const int32_t* slot
     const int64_t nb = (B - b0 < kMaxRows) ? B - b0 : kMaxRows;
     const int64_t blocks_needed = ((nb + 15) / 16 + kPWpb - 1) / kPWpb;
     const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
+    const SchedSlot cset = take_sched_slot(st, (nb + 15) / 16, grid);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(slot + b0),
                        static_cast<const void*>(other + b0 * 64), static_cast<void*>(score + b0), 1u,
                        static_cast<unsigned>(nb), reinterpret_cast<const float*>(codes), M,
-                       static_cast<const float*>(nullptr), buckets);
-    if (int rc = check_launch()) return rc;
+                       static_cast<const float*>(nullptr), buckets, cset.counters, cset.busy_dev);
+    if (int rc = check_pool_launch(cset)) return rc;
   }
   return MI_OOV_OK;
 }

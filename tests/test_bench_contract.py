@@ -66,9 +66,11 @@ def test_pmc_traffic_and_rocprof_duration_agree_with_the_line():
     timed = summary["timed"]
     assert timed["kernel"] == kernel and timed["launches"] == under["roofline"]["launches"]
     assert timed["batches_per_launch"] == line["roofline"]["batches_per_launch"]
-    # rocprof's kernel duration of the timed launch against the bench's HIP events: the plain run within 5 %, the run
-    # under the profiler (whose event records carry the tool's own overhead around a single launch) within 15 %
-    assert abs(timed["avg_us"] - line["roofline"]["avg_launch_us"]) < 0.05 * timed["avg_us"]
+    # rocprof's kernel duration of the timed launch against the bench's HIP events: the plain run within 7 % (the event
+    # pair around ONE launch of ~106 us also holds the dispatch and the two event packets, 3-6 us, and two runs on
+    # different boxes differ by ~3 %), the run under the profiler (whose event records carry the tool's own overhead
+    # around a single launch) within 15 %
+    assert abs(timed["avg_us"] - line["roofline"]["avg_launch_us"]) < 0.07 * timed["avg_us"]
     assert 0 <= under["roofline"]["avg_launch_us"] - timed["avg_us"] < 0.15 * timed["avg_us"]
     assert timed["avg_us"] * 1e-6 > 0  # and the roofline fraction it implies meets north_star's 0.70
     frac = line["roofline"]["bytes_per_lookup"] * line["roofline"]["lookups_per_launch"] / (timed["avg_us"] * 1e-6) / 8e12

@@ -575,6 +575,92 @@ def test_lsh_multi_queue_slices_and_fallback(oracle, ops, dev):
         assert bits_equal(res[k].cpu().numpy(), oracle.lsh_embed_score(ids[k], feat, planes12, buckets12, other[k])[0])
 
 
+def _multi_case(rng, K, B, N, dev):
+    ids = rng.integers(0, N, size=(K, B), dtype=np.int64)
+    other = rng.standard_normal((K, B, 64), dtype=np.float32)
+    return T(ids, dev), T(other, dev)
+
+
+def test_lsh_multi_tile_pool_concurrent_streams_and_recycling(ops, dev):
+    """The persistent kernel deals part of its tiles from a ticket pool (csrc/lsh64p.hip): a counter set serves one
+    launch at a time and is handed back by the launch's last wave.  Launches in flight on four streams at once, and 3x
+    more launches than there are counter sets, all give the per-batch kernel's scores bit for bit."""
+    rng = np.random.default_rng(77)
+    K, B, N = 6, 20000, 4000     # 7500 tiles: one static pair per wave of 2048, the rest from the pool
+    feat = T(rng.standard_normal((N, 64), dtype=np.float32), dev)
+    planes = T(rng.standard_normal((8, 64), dtype=np.float32), dev)
+    buckets = T(rng.standard_normal((8, 64), dtype=np.float32), dev)
+    scorer = ops.LshMultiScorer(feat, planes, buckets)
+    cases = [_multi_case(rng, K, B, N, dev) for _ in range(8)]
+    want = [[ops.lsh_embed_score(ids[k], feat, planes, buckets, other[k]) for k in range(K)] for ids, other in cases]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(device=dev) for _ in range(4)]
+    queues = []
+    for rnd in range(24):                      # 96 launches > 32 counter sets
+        for si, st in enumerate(streams):
+            ids, other = cases[(rnd + 2 * si) % 8]
+            with torch.cuda.stream(st):
+                q = ops.LshBatchQueue([ids[k] for k in range(K)], [other[k] for k in range(K)])
+                scorer.run(q)
+            queues.append(((rnd + 2 * si) % 8, q))
+    torch.cuda.synchronize()
+    for ci, q in queues:
+        for k in range(K):
+            assert torch.equal(torch.nan_to_num(q.scores[k]), torch.nan_to_num(want[ci][k]))
+
+
+def test_lsh_multi_captured_launch_deals_tiles_statically(ops, dev):
+    """A launch captured into a HIP graph gets no counter set (the host cannot see its replays): the kernel deals the
+    same tickets in a fixed order.  Replays with new ids in place equal the eager results."""
+    rng = np.random.default_rng(78)
+    K, B, N = 5, 30011, 6000
+    feat = T(rng.standard_normal((N, 64), dtype=np.float32), dev)
+    planes = T(rng.standard_normal((8, 64), dtype=np.float32), dev)
+    buckets = T(rng.standard_normal((8, 64), dtype=np.float32), dev)
+    scorer = ops.LshMultiScorer(feat, planes, buckets)
+    ids, other = _multi_case(rng, K, B, N, dev)
+    q = ops.LshBatchQueue([ids[k] for k in range(K)], [other[k] for k in range(K)])
+    scorer.run(q)                              # warm-up outside the capture (occupancy query, LDS attribute)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        scorer.run(q)
+    for rep in range(3):
+        new_ids, new_other = _multi_case(rng, K, B, N, dev)
+        ids.copy_(new_ids)
+        other.copy_(new_other)
+        for s in q.scores:
+            s.fill_(-1.0)
+        g.replay()
+        torch.cuda.synchronize()
+        for k in range(K):
+            eager = ops.lsh_embed_score(ids[k], feat, planes, buckets, other[k])
+            assert torch.equal(torch.nan_to_num(q.scores[k]), torch.nan_to_num(eager)), (rep, k)
+
+
+def test_lsh_multi_pool_disabled_process(dev):
+    """MI_OOV_POOL=0 (read once per process): every launch deals its tiles in the fixed order; same scores."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import numpy as np, torch, mi_oov\n"
+        "from mi_oov import ops\n"
+        "rng = np.random.default_rng(3); dev = 'cuda:0'\n"
+        "T = lambda a: torch.from_numpy(a).to(dev)\n"
+        "for K, B, N in [(7, 20000, 4000), (1, 16, 9), (40, 333, 200), (3, 65536, 50000)]:\n"
+        "    feat, planes, buckets = T(rng.standard_normal((N, 64), dtype=np.float32)), T(rng.standard_normal((8, 64), dtype=np.float32)), T(rng.standard_normal((8, 64), dtype=np.float32))\n"
+        "    ids, other = T(rng.integers(0, N, size=(K, B), dtype=np.int64)), T(rng.standard_normal((K, B, 64), dtype=np.float32))\n"
+        "    got = ops.lsh_embed_score_multi([ids[k] for k in range(K)], feat, planes, buckets, [other[k] for k in range(K)])\n"
+        "    for k in range(K):\n"
+        "        want = ops.lsh_embed_score(ids[k], feat, planes, buckets, other[k])\n"
+        "        assert torch.equal(torch.nan_to_num(got[k]), torch.nan_to_num(want)), (K, B, k)\n"
+        "print('POOL-OFF-OK')\n")
+    env = dict(os.environ, MI_OOV_POOL="0", PYTHONPATH=os.pathsep.join(sys.path))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "POOL-OFF-OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_lsh_multi_raw_cabi_errors(ops, dev):
     """Status codes of the raw entry point: unsupported shape, NULL table, misaligned table."""
     import ctypes
