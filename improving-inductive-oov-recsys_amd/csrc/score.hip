@@ -1273,6 +1273,223 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
   }
 }
 
+// ---- pass 2 without LDS operands ---------------------------------------------------------------------------------------
+// The FILTER pass again, laid out so that a wave never waits for another: the four waves of a workgroup share the 128
+// user rows and split each 128-column block into four 32-column slices.
+//   * A wave's A operand -- its 128 rows x 64 k in the matrix cores' fragment layout -- is loaded ONCE, straight from
+//     global memory (a fragment is 16 contiguous bytes of a row), and stays in 64 registers for the whole strip.
+//   * Its B operand is 32 columns x 64 k per block = four 16-byte loads per lane, also straight in fragment layout, and
+//     requested one block ahead.  No staging through LDS, no barrier inside the strip loop (bf16_tile_kernel: two per
+//     block, and 1.5 LDS operand reads per MFMA).
+//   * The row thresholds ride in the K dimension: -thr[row] = hi + mid + lo, three bf16 pieces that add up to the f32
+//     value, are three extra k of A against ones in B (one v_mfma_f32_32x32x8_bf16_1k per 32-row tile: a fifth
+//     of a full step), so the accumulators come out as score - thr without 64 seed registers or LDS reads per block.
+//     Non-finite thresholds keep one piece (inf - inf would poison the sum); a NaN threshold lets everything pass, as
+//     !(score < NaN) does.
+// Same keys as bf16_tile_kernel<EPI_FILTER> up to the rounding of the shifted sum (both inside the slack of eps), same
+// lists and overflow rules.  Measured at 4096 x 50 000, k = 20 (rocprofv3; bf16_tile_kernel<EPI_FILTER>: 56.4 us):
+//   MFMAs alone (B loaded once)   25.8 us   978 MFMAs per SIMD: ~1.5 PFLOP/s chip-wide with the threshold step counted
+//   + the block loads             34.6      (one block ahead: exposed only while nothing else fills the block)
+//   + the 22 group tests          34.0      (free: independent vector work in the MFMAs' shadow)
+//   + pushes, drain               49.1      ~9 records per wave and block in ~7 of the 22 groups, 13 instructions each
+// Tried on the way: one ballot, branch and push per passing SCORE 70 us; a drain per block 68 (three dependent LDS round
+// trips for 9 active lanes); a compare of the slot against the queue's end inside the push 54 (a vector compare feeding
+// a branch: ~100 cycles, and a wave has one partner to hide behind); E laid out in fragment order (coalesced 1 KB
+// loads) 31 instead of 35 for MFMAs + loads; warming the XCD's L2 with the strip's lines first: no change;
+// 256 / 768 / 1024 workgroups instead of 512 (two per CU): 72 / 61 / 58 us.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int kDirectQueue = 256;  // records (16 B) a wave of the direct filter kernel can hold between drains
+constexpr int kNegInfBits = static_cast<int>(0xFF800000u);
+constexpr int kRowLost = 1 << 24;  // flag in a row's LDS list counter: some of its candidates never reached a list
+
+__device__ __forceinline__ uint32_t bf16_bits_rne(float v) {  // finite v
+  const uint32_t u = __float_as_uint(v);
+  return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+
+template <bool MASKED>
+__global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
+                                                                       const __bf16* __restrict__ Eb, int64_t N,
+                                                                       const float* __restrict__ thr, TopkArgs ta, StripLists sl,
+                                                                       int nvisit) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  int* rowcnt = reinterpret_cast<int*>(smem);  // [BM] entries of the (row, strip) lists so far
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, hh = lane >> 5;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.y) * BM;
+  const int strip = blockIdx.x, nstrip = gridDim.x;
+  if (strip >= nvisit) {
+    if (tid < BM && b0 + tid < B) sl.cnt[(b0 + tid) * sl.ns + strip] = 0;
+    return;
+  }
+  const int rows_here = (B - b0 < BM) ? static_cast<int>(B - b0) : BM;
+  const uint32_t n_cols = static_cast<uint32_t>(N);
+  const uint32_t skip = ta.n_skip_low < N ? static_cast<uint32_t>(ta.n_skip_low) : n_cols;
+  if (tid < BM) rowcnt[tid] = 0;
+
+  // the wave's B slice of the strip's first block, then A
+  const int ccol = wv * 32 + i32;  // this lane's column inside a block
+  u32x4 bq[4], bn[4];
+  {
+    const int64_t n0 = static_cast<int64_t>(strip) * BN;
+    const int64_t rb = (n0 + ccol < N) ? n0 + ccol : N - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bq[ks] = *reinterpret_cast<const u32x4*>(Eb + rb * 64 + ks * 16 + hh * 8);
+  }
+  u32x4 aq[4][4];
+  s16x4 at[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int r = m * 32 + i32;
+    const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) aq[m][ks] = *reinterpret_cast<const u32x4*>(Ub + ra * 64 + ks * 16 + hh * 8);
+    float nt = (r < rows_here) ? 0.f - thr[b0 + r] : -__builtin_inff();
+    if (nt != nt) nt = __builtin_inff();
+    uint32_t p0, p1 = 0u, p2 = 0u;
+    if (__builtin_fabsf(nt) == __builtin_inff()) {
+      p0 = __float_as_uint(nt) >> 16;
+    } else {
+      p0 = bf16_bits_rne(nt);
+      const float r1 = nt - __uint_as_float(p0 << 16);  // exact
+      p1 = bf16_bits_rne(r1);
+      const float r2 = r1 - __uint_as_float(p1 << 16);  // exact
+      p2 = bf16_bits_rne(r2);
+      if ((p0 & 0x7FFFu) == 0x7F80u) p1 = p2 = 0u;      // (rounded up to inf: |nt| within half a bf16 ulp of FLT_MAX)
+    }
+    at[m] = hh == 0 ? s16x4{static_cast<short>(p0), static_cast<short>(p1), static_cast<short>(p2), 0} : s16x4{0, 0, 0, 0};
+  }
+  const s16x4 ones = hh == 0 ? s16x4{0x3F80, 0x3F80, 0x3F80, 0} : s16x4{0, 0, 0, 0};
+  __syncthreads();  // rowcnt zeroed
+
+  uint64_t* cand_wg = sl.cand + (b0 * sl.ns + strip) * sl.cap;
+  const int row_stride = sl.ns * sl.cap;
+  u32x4* queue = reinterpret_cast<u32x4*>(rowcnt + BM) + wv * (kDirectQueue + 1);  // {block, group, lane; three score images}; + a dump slot
+  int qpos = 0;  // records in the queue (wave-uniform)
+  // Drain: 64 records at a time, a lane per record: list slots for its (up to three) passing scores -- the three LDS
+  // atomics in flight together -- then keys and stores.
+  auto drain = [&]() {
+    const int nq = qpos < kDirectQueue ? qpos : kDirectQueue;
+    for (int i = lane; i < nq; i += 64) {
+      const u32x4 rec = queue[i];
+      const int v0 = static_cast<int>((rec.x >> 6) & 63u), src = static_cast<int>(rec.x & 63u);
+      const uint32_t col = (rec.x >> 12) * static_cast<uint32_t>(BN) + static_cast<uint32_t>(wv * 32 + (src & 31));
+      const bool col_ok = col < n_cols && col >= skip;
+      const uint32_t image[3] = {rec.y, rec.z, rec.w};
+      int lrow[3], p[3];
+      bool ok[3];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int v = v0 + t;
+        lrow[t] = (v >> 4) * 32 + (v & 3) + 8 * ((v & 15) >> 2) + 4 * (src >> 5);
+        ok[t] = static_cast<int>(image[t]) > kNegInfBits && col_ok && lrow[t] < rows_here;  // (v = 64, 65: image -inf)
+        if constexpr (MASKED) {
+          if (ok[t]) ok[t] = !((sl.mask[(b0 + lrow[t]) * sl.mask_words + (col >> 6)] >> (col & 63u)) & 1ull);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) p[t] = ok[t] ? atomicAdd(&rowcnt[lrow[t]], 1) : 0;
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        if (ok[t]) {
+          const uint64_t packed = (static_cast<uint64_t>(order_key(__uint_as_float(image[t]))) << 32) | (0xFFFFFFFFu - col);
+          if (p[t] < sl.cap) {
+            cand_wg[lrow[t] * row_stride + p[t]] = packed;
+          } else if (__atomic_load_n(&sl.ovf_cnt[b0 + lrow[t]], __ATOMIC_RELAXED) <= kOvfCap) {
+            // (a row that has already run over is lost to the exact fallback: no point in counting on)
+            const int p2 = atomicAdd(&sl.ovf_cnt[b0 + lrow[t]], 1);
+            if (p2 < kOvfCap) sl.ovf[(b0 + lrow[t]) * kOvfCap + p2] = packed;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    qpos = 0;
+  };
+
+  for (int j = strip; j < nvisit; j += nstrip) {
+    {
+      const int64_t n1 = static_cast<int64_t>(j + nstrip < nvisit ? j + nstrip : j) * BN;  // (the last block re-reads itself)
+      const int64_t rb = (n1 + ccol < N) ? n1 + ccol : N - 1;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bn[ks] = *reinterpret_cast<const u32x4*>(Eb + rb * 64 + ks * 16 + hh * 8);
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+      c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[m], ones, c, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[m][ks]), __builtin_bit_cast(bf16x8, bq[ks]), c, 0, 0, 0);
+      acc[m] = c;
+    }
+    // acc[m][r]: row m 32 + (r & 3) + 8 (r >> 2) + 4 hh, column n0 + ccol
+    // The scores are tested three at a time: as signed integers the float images that FAIL (x < 0) are exactly those
+    // <= 0xFF800000 (-inf) -- NaNs of either sign and everything >= +0 lie above; -0 cannot occur (a sum that cancels
+    // rounds to +0) -- so "one of my three passes" is one v_max3_i32 and one compare.  All 22 group ballots are taken
+    // first (independent VALU work, the masks stay in scalar registers); the branches that follow depend on scalar
+    // registers only.  A lane with a passing score pushes ONE record -- its three score images and where they sit --
+    // into the wave's queue (slot = rank among the pushing lanes).  The queue lives across blocks and is drained when
+    // it may not hold another block's records (a block leaves ~9): what matters in this kernel is the NUMBER of
+    // vector instructions next to the 20 MFMAs of a block (they share the SIMD's issue: knocking the epilogue out
+    // took 70 us to 34), and a drain costs ~100 of them whether 9 lanes have a record or 64.
+    if (qpos > kDirectQueue - 128) drain();
+    const uint32_t tag0 = (static_cast<uint32_t>(j) << 12) | static_cast<uint32_t>(lane);
+    auto bits = [&](int v) { return v < 64 ? static_cast<int>(__float_as_uint(acc[v >> 4][v & 15])) : kNegInfBits; };
+    uint64_t gm[22];
+    uint64_t any = 0;
+#pragma unroll
+    for (int g = 0; g < 22; ++g) {
+      const int x0 = bits(3 * g), x1 = bits(3 * g + 1), x2 = bits(3 * g + 2);
+      int mx = x0 > x1 ? x0 : x1;
+      mx = mx > x2 ? mx : x2;
+      gm[g] = __ballot(mx > kNegInfBits);
+      any |= gm[g];
+    }
+    if (any) {
+#pragma unroll
+      for (int g = 0; g < 22; ++g) {
+        if (gm[g]) {
+          const int x0 = bits(3 * g), x1 = bits(3 * g + 1), x2 = bits(3 * g + 2);
+          int mx = x0 > x1 ? x0 : x1;
+          mx = mx > x2 ? mx : x2;
+          if (mx > kNegInfBits) {  // (the lanes of gm[g])
+            // No test of the slot here (a vector compare feeding a branch is a ~100-cycle chain, seven times per
+            // block, and a wave has one other wave to hide it behind): records past the end land in a dump slot and
+            // the count tells afterwards.
+            int slot = static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(gm[g] >> 32),
+                                            __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(gm[g]), static_cast<uint32_t>(qpos))));
+            slot = slot < kDirectQueue ? slot : kDirectQueue;
+            queue[slot] = u32x4{tag0 | static_cast<uint32_t>(3 * g << 6), static_cast<uint32_t>(x0), static_cast<uint32_t>(x1),
+                                static_cast<uint32_t>(x2)};
+          }
+          qpos += __popcll(gm[g]);
+        }
+      }
+      if (qpos > kDirectQueue) {
+        // more records than the queue holds (a dozen rows of equal scores in this block): which were dropped is not
+        // known any more, so all rows of the workgroup take the exact fallback
+        atomicOr(&rowcnt[lane], kRowLost);
+        atomicOr(&rowcnt[lane + 64], kRowLost);
+        qpos = kDirectQueue;
+      }
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) bq[ks] = bn[ks];
+  }
+  drain();
+  __syncthreads();
+  if (tid < rows_here) {
+    const int n = rowcnt[tid];
+    sl.cnt[(b0 + tid) * sl.ns + strip] = n < sl.cap ? n : sl.cap;
+    if (n & kRowLost) atomicAdd(&sl.ovf_cnt[b0 + tid], kOvfCap + 1);  // candidates of this row were dropped: exact fallback
+  }
+}
+
 // finalize for the bf16 prefilter, one WAVE per row (4 rows per workgroup, no barriers on the common path): gather the
 // row's strip lists, cut by the k-th best bf16 key, exact f32 key of the survivors (the oracle's fmaf chain), rank sort.
 // (One 256-thread workgroup per row spent 48 us on 4096 rows: barriers between six short phases, and a rank-counting
@@ -1632,7 +1849,10 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
         return n > 128 ? 128 : n;
       };
       const int64_t nvisit1 = (nblk + L.stride - 1) / L.stride;
-      const int64_t ns1 = strips(nvisit1, target1), ns2 = strips(nblk, target);
+      static const bool direct_on = [] { const char* e = getenv("MI_OOV_FILTER_DIRECT"); return !(e && e[0] == '0'); }();  // developer knob: 0 = pass 2 with LDS-staged operands
+      const bool direct = direct_on && nblk < (1 << 20);  // (a queue record has 20 bits for the block)
+      static const int64_t target_d = [] { const char* e = getenv("MI_OOV_STRIP_WGS2"); return e ? atoll(e) : 512LL; }();  // direct pass 2: 2 workgroups per CU
+      const int64_t ns1 = strips(nvisit1, target1), ns2 = strips(nblk, direct ? target_d : target);
       StripLists sl{};
       sl.ns = static_cast<int>(ns2);
       {  // list capacity: a power of two >= `MI_OOV_LIST_SLACK` (2) x the expected share of ~1.3 k stride candidates per
@@ -1685,7 +1905,14 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
         hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, L.NT,
                            static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf), bb);
       if ((rc = check_launch())) return rc;
-      if (mask)
+      const size_t lds_direct = BM * sizeof(int) + 4 * (kDirectQueue + 1) * 16;
+      if (direct && mask)
+        hipLaunchKernelGGL((bf16_filter_direct_kernel<true>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_direct, st,
+                           Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
+      else if (direct)
+        hipLaunchKernelGGL((bf16_filter_direct_kernel<false>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_direct, st,
+                           Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
+      else if (mask)
         hipLaunchKernelGGL((bf16_tile_kernel<EPI_FILTER, true>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
                            Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
       else

@@ -306,6 +306,28 @@ def test_fused_topk_vs_oracle(B, N, D, k, skip, oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
+@pytest.mark.parametrize("case", ["queue_overflow", "popular_columns"])
+def test_fused_topk_direct_filter_queue(case, oracle, ops, dev):
+    """The second pass (bf16_filter_direct_kernel) keeps passing scores in a per-wave queue of 256 records that lives
+    across column blocks.  queue_overflow: 40 all-zero user rows inside one 128-row block tie everywhere, a wave finds
+    far more than 256 passing lane-groups in a block, records are dropped and every row of that workgroup -- the
+    ordinary ones too -- must come out of the exact fallback unchanged.  popular_columns: a few items score high for
+    every user, so single lanes push in most of the 22 groups of a block, block after block."""
+    rng = np.random.default_rng(11)
+    B, N, k = 300, 9000, 20
+    U = rng.standard_normal((B, 64), dtype=np.float32)
+    E = rng.standard_normal((N, 64), dtype=np.float32)
+    if case == "queue_overflow":
+        U[130:170] = 0.0
+    else:
+        E[[5, 777, 4100, 8999]] = 3.0 * np.abs(U).mean(0)   # large positive scores for most users
+        U = np.abs(U)
+    vals, idx = ops.score_topk(T(U, dev), T(E, dev), k, 1)
+    o_vals, o_idx = oracle.score_topk(U, E, k, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx)
+    assert bits_equal(vals.cpu().numpy(), o_vals)
+
+
 @pytest.mark.parametrize("case", ["cluster_small", "cluster_big", "neg_nan", "many_strips", "skip_mid_tile"])
 def test_fused_topk_bf16_lists(case, oracle, ops, dev):
     """The D = 64 fused path filters on bf16 matrix-core scores into per-(row, strip) lists and re-scores the

@@ -18,4 +18,6 @@ for r in csv.DictReader(open(f)):
 PY
   rm -rf $out/pt_$tag
 }
-run base MI_OOV_STRIP_WGS=1024
+run direct MI_OOV_FILTER_DIRECT=1
+run staged MI_OOV_FILTER_DIRECT=0
+for w in ${PT_WGS2:-}; do run direct_wgs$w MI_OOV_FILTER_DIRECT=1 MI_OOV_STRIP_WGS2=$w; done
