@@ -288,8 +288,6 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   if (have) {
     ida = load_ids(pa);
     idb = load_ids(pb);
-    asm volatile("" ::: "memory");
-    tk = draw();
   }
 
   // Weights.  Planes and bucket rows are staged global -> LDS first; then -- the ids have landed with them, vmcnt
@@ -303,13 +301,27 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   constexpr int kTabRows = kScore ? (1 << H) : 0;
   float* splanes = sw + kTabRows * 64;
   float* sbuckets = splanes + H * 64;
-  if constexpr (!kFromCodes) {
-    for (int i = threadIdx.x; i < H * 16; i += kPBlk)
-      *reinterpret_cast<float4*>(splanes + i * 4) = *reinterpret_cast<const float4*>(planes + i * 4);
-  }
-  if constexpr (kScore) {
-    for (int i = threadIdx.x; i < H * 16; i += kPBlk)
-      *reinterpret_cast<float4*>(sbuckets + i * 4) = *reinterpret_cast<const float4*>(buckets + i * 4);
+  {
+    // (H * 16 <= 128 float4 per matrix: one per thread of the first two waves.)  The wave's first ticket is drawn
+    // between the loads and the LDS stores: the draw waits for its reply, and waits while these loads are in flight.
+    static_assert(H * 16 <= kPBlk, "one staging load per thread");
+    const bool stage = threadIdx.x < H * 16;
+    float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), bv = pv;
+    if constexpr (!kFromCodes) {
+      if (stage) pv = *reinterpret_cast<const float4*>(planes + threadIdx.x * 4);
+    }
+    if constexpr (kScore) {
+      if (stage) bv = *reinterpret_cast<const float4*>(buckets + threadIdx.x * 4);
+    }
+    asm volatile("" ::: "memory");
+    if (have) tk = draw();
+    asm volatile("" ::: "memory");
+    if constexpr (!kFromCodes) {
+      if (stage) *reinterpret_cast<float4*>(splanes + threadIdx.x * 4) = pv;
+    }
+    if constexpr (kScore) {
+      if (stage) *reinterpret_cast<float4*>(sbuckets + threadIdx.x * 4) = bv;
+    }
   }
   __syncthreads();
   float4 xa[4], ua[NU], xb[4], ub[NU];
