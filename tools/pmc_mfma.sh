@@ -19,10 +19,11 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_mfma/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "full_sort_kernel" not in k:
+        if "full_sort_kernel" not in k and "bf16_" not in k:
             continue
         acc[k.split("(")[0].replace("void mi_oov::", "")][row["Counter_Name"]].append(float(row["Counter_Value"]))
-print("# full_sort_kernel<VEC, EPI>: EPI 0 = scores stored, 1-3 = Linear (+GELU / +sigmoid), 4 = tile maxima, 5 = filter")
+print("# full_sort_kernel<VEC, EPI>: EPI 0 = scores stored, 1-3 = Linear (+GELU / +sigmoid), 4 = tile maxima, 5 = filter (f32 MFMA);")
+print("# bf16_tile_kernel<4, MASKED> = first top-k pass (tile maxima), bf16_filter_direct_kernel<MASKED> = second pass (bf16 MFMA)")
 for k, d in sorted(acc.items()):
     print(k)
     for c, v in sorted(d.items()):
