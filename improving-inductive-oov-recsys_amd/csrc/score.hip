@@ -1296,7 +1296,9 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
 // trips for 9 active lanes); a compare of the slot against the queue's end inside the push 54 (a vector compare feeding
 // a branch: ~100 cycles, and a wave has one partner to hide behind); E laid out in fragment order (coalesced 1 KB
 // loads) 31 instead of 35 for MFMAs + loads; warming the XCD's L2 with the strip's lines first: no change;
-// 256 / 768 / 1024 workgroups instead of 512 (two per CU): 72 / 61 / 58 us.
+// 256 / 768 / 1024 workgroups instead of 512 (two per CU): 72 / 61 / 58 us; two B register sets refilled right behind
+// their MFMAs (loads ~2 blocks ahead, exact s_waitcnt counts): 52 -- SQ_WAIT_ANY is 41 % of the waves' cycles, but it is
+// not load latency that a deeper prefetch would hide (profiles/r02_pmc_mfma.txt: matrix cores busy 25 % of the kernel).
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 constexpr int kDirectQueue = 256;  // records (16 B) a wave of the direct filter kernel can hold between drains
 constexpr int kNegInfBits = static_cast<int>(0xFF800000u);
