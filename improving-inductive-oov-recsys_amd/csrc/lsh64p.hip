@@ -254,15 +254,17 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     if (sched && lane == 0) {
       const unsigned done = __hip_atomic_fetch_add(exit_ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (done == gridDim.x - 1) {  // the last wave of this counter (every workgroup has one): zero for the next launch
-        __hip_atomic_store(ticket_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(exit_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (zeroed with read-modify-writes, not stores: the counters are only ever touched by atomics, which all XCDs
+        //  perform at one place -- a plain store could sit in this XCD's L2 until the end of the kernel)
+        __hip_atomic_fetch_and(ticket_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_and(exit_ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // Order: the two stores are acknowledged (vmcnt) before this counter is reported finished, and the busy word is
         // cleared by whoever sees all kPWpb reported.  No release fence: on this chip one is a write-back of the L2,
         // which the end of the kernel is about to do anyway, and all of this sits behind the launch's LAST wave.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         unsigned* counters_done = sched + 48;  // (third quarter of counter 0's line)
         if (__hip_atomic_fetch_add(counters_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == kPWpb - 1) {
-          __hip_atomic_store(counters_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_and(counters_done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #ifndef MI_PNOFLAG
           __hip_atomic_store(sched_busy, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
