@@ -901,6 +901,17 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 constexpr int BLD = 72;  // bf16 elements per LDS row: 64 + 8 (144 B: staggers the banks, keeps 16-B alignment)
 
+// The bf16 copy of E is kept in FRAGMENT ORDER: rows in tiles of 32, a tile = [8 chunks of 8 k][32 rows][8 bf16] = 4 KB,
+// padded with zero rows to a multiple of 128 rows.  The matrix cores want, per k-step, 16 bytes of each of 32 rows: in
+// row-major order that is a load instruction over 32 cache lines using a quarter of each, four times over for the four
+// steps of a row (the second pass spent 41 % of its waves' cycles in s_waitcnt that a deeper prefetch did not touch: the
+// texture path's line rate, not latency); in this order the 64 lanes of a step read one contiguous KB.  The copy is
+// private to the library (workspace / prepared catalogue), so only its writer and its three readers know.
+__host__ __device__ constexpr int64_t eb_rows(int64_t N) { return (N + 127) / 128 * 128; }
+__device__ __forceinline__ int64_t eb_chunk(int64_t row, int chunk) {  // offset (bf16 elements) of 8 k of a row
+  return (row >> 5) * 2048 + (static_cast<int64_t>(chunk) * 32 + (row & 31)) * 8;
+}
+
 // bf16 copies of U and E (64-float rows) + squared row norms, one launch: workgroups [0, gu) take U (norms to u2[], the
 // rows' overflow counters zeroed), workgroups [gu, gu + ge) take E and leave the maximum squared norm of their rows in
 // e2part[workgroup] (float bits; unsigned order = float order for non-negative floats, NaN images sort above +inf; the
@@ -916,6 +927,7 @@ __global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __res
   const float* M = is_u ? U : E;
   __bf16* Mb = is_u ? Ub : Eb;
   const int64_t rows = is_u ? B : N;
+  const int64_t rows_out = is_u ? B : eb_rows(N);  // (E: zero rows up to the next multiple of 128)
   const int blk = is_u ? blockIdx.x : blockIdx.x - gu, nblk = is_u ? gu : gridDim.x - gu;
   if (threadIdx.x == 0) bmax = 0u;
   __syncthreads();
@@ -923,7 +935,7 @@ __global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __res
   const int64_t per = kBlock / 16;
   const int64_t step = static_cast<int64_t>(nblk) * per;
   uint32_t mine = 0u;
-  for (int64_t r0 = static_cast<int64_t>(blk) * per + (threadIdx.x >> 4); r0 < rows; r0 += 4 * step) {
+  for (int64_t r0 = static_cast<int64_t>(blk) * per + (threadIdx.x >> 4); r0 < rows_out; r0 += 4 * step) {
     float4 v[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -938,11 +950,13 @@ __global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __res
       s = __builtin_fmaf(v[q].z, v[q].z, s);
       s = __builtin_fmaf(v[q].w, v[q].w, s);
       s = row16_sum(s);  // (every lane takes part: no divergence around the cross-lane sum)
-      if (r < rows) {
-        uint2 pk;
+      if (r < rows_out) {
+        uint2 pk;  // (rows past N: v = 0)
         pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v[q].x), static_cast<__bf16>(v[q].y)});
         pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v[q].z), static_cast<__bf16>(v[q].w)});
-        *reinterpret_cast<uint2*>(Mb + r * 64 + l16 * 4) = pk;
+        *reinterpret_cast<uint2*>(Mb + (is_u ? r * 64 + l16 * 4 : eb_chunk(r, l16 >> 1) + (l16 & 1) * 4)) = pk;
+      }
+      if (r < rows) {
         if (l16 == 0) {
           if (is_u) {
             u2[r] = s;
@@ -1034,6 +1048,7 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
   const uint32_t n_cols = static_cast<uint32_t>(N);  // N < 2^32 (checked by the caller)
   const uint32_t skip = ta.n_skip_low < N ? static_cast<uint32_t>(ta.n_skip_low) : n_cols;
   const int erow = tid >> 3, eoff = (tid & 7) * 8;  // operand staging: 128 rows x 8 units of 8 k (16 B), 4 units per thread
+  const int brow = tid & 31, bchunk = tid >> 5;     // ... of E (fragment order, eb_chunk): thread = (row of a 32-row tile, chunk)
   u32x4 pf[4];  // the next block of E (a native vector type: an array of HIP's uint4 struct lands in scratch)
 
 #pragma unroll
@@ -1041,9 +1056,8 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
     const int r = erow + 32 * q;
     const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
     const int64_t n0 = static_cast<int64_t>(strip) * stride * BN;
-    const int64_t rb = (n0 + r < N) ? n0 + r : N - 1;
     *reinterpret_cast<u32x4*>(sA + r * BLD + eoff) = *reinterpret_cast<const u32x4*>(Ub + ra * 64 + eoff);
-    *reinterpret_cast<u32x4*>(sB + r * BLD + eoff) = *reinterpret_cast<const u32x4*>(Eb + rb * 64 + eoff);
+    *reinterpret_cast<u32x4*>(sB + (brow + 32 * q) * BLD + bchunk * 8) = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n0 + brow + 32 * q, bchunk));
   }
   if constexpr (EPI == EPI_FILTER) {
     if (tid < BM) {
@@ -1059,10 +1073,7 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
     {
       const int64_t n1 = static_cast<int64_t>(more ? j + nstrip : j) * stride * BN;  // (the last block re-reads itself)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int64_t rb = (n1 + erow + 32 * q < N) ? n1 + erow + 32 * q : N - 1;
-        pf[q] = *reinterpret_cast<const u32x4*>(Eb + rb * 64 + eoff);
-      }
+      for (int q = 0; q < 4; ++q) pf[q] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n1 + brow + 32 * q, bchunk));
     }
     // the epilogue's row / column offsets are loop invariant: made opaque here so that the compiler recomputes them per
     // block instead of carrying 64+ registers of addresses (i.e. spills) across the strip loop
@@ -1263,7 +1274,7 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
     if (more) {
       __syncthreads();  // every wave is done with sB
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(sB + (erow + 32 * q) * BLD + eoff) = pf[q];
+      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(sB + (brow + 32 * q) * BLD + bchunk * 8) = pf[q];
       __syncthreads();
     }
   }
@@ -1298,8 +1309,13 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
 // loads) 31 instead of 35 for MFMAs + loads; warming the XCD's L2 with the strip's lines first: no change;
 // 256 / 768 / 1024 workgroups instead of 512 (two per CU): 72 / 61 / 58 us; two B register sets refilled right behind
 // their MFMAs (loads ~2 blocks ahead, exact s_waitcnt counts): 52 -- SQ_WAIT_ANY is 41 % of the waves' cycles, but it is
-// not load latency that a deeper prefetch would hide (profiles/r02_pmc_mfma.txt: matrix cores busy 25 % of the kernel).
+// not load latency that a deeper prefetch would hide (profiles/r02_pmc_mfma.txt: matrix cores busy 25 % of the kernel);
+// E in fragment order (eb_chunk: contiguous 1 KB per load instruction instead of 32 quarter-used lines) 49.2 -> 48.7,
+// kept; s_setprio 1 while testing and pushing 48.4 -> 47.8, kept; s_setprio on the MFMA phase instead: no change.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+#ifndef MI_FD_PRIO
+#define MI_FD_PRIO 1  // issue priority of a wave while it tests and pushes (its partner is then mostly issuing MFMAs): 48.4 -> 47.8 us
+#endif
 constexpr int kDirectQueue = 256;  // records (16 B) a wave of the direct filter kernel can hold between drains
 constexpr int kNegInfBits = static_cast<int>(0xFF800000u);
 constexpr int kRowLost = 1 << 24;  // flag in a row's LDS list counter: some of its candidates never reached a list
@@ -1335,9 +1351,8 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
   u32x4 bq[4], bn[4];
   {
     const int64_t n0 = static_cast<int64_t>(strip) * BN;
-    const int64_t rb = (n0 + ccol < N) ? n0 + ccol : N - 1;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bq[ks] = *reinterpret_cast<const u32x4*>(Eb + rb * 64 + ks * 16 + hh * 8);
+    for (int ks = 0; ks < 4; ++ks) bq[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n0 + ccol, ks * 2 + hh));
   }
   u32x4 aq[4][4];
   s16x4 at[4];
@@ -1413,9 +1428,8 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
   for (int j = strip; j < nvisit; j += nstrip) {
     {
       const int64_t n1 = static_cast<int64_t>(j + nstrip < nvisit ? j + nstrip : j) * BN;  // (the last block re-reads itself)
-      const int64_t rb = (n1 + ccol < N) ? n1 + ccol : N - 1;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) bn[ks] = *reinterpret_cast<const u32x4*>(Eb + rb * 64 + ks * 16 + hh * 8);
+      for (int ks = 0; ks < 4; ++ks) bn[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n1 + ccol, ks * 2 + hh));
     }
     f32x16 acc[4];
 #pragma unroll
@@ -1440,6 +1454,9 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
     // vector instructions next to the 20 MFMAs of a block (they share the SIMD's issue: knocking the epilogue out
     // took 70 us to 34), and a drain costs ~100 of them whether 9 lanes have a record or 64.
     if (qpos > kDirectQueue - 128) drain();
+#if MI_FD_PRIO
+    __builtin_amdgcn_s_setprio(MI_FD_PRIO);
+#endif
     const uint32_t tag0 = (static_cast<uint32_t>(j) << 12) | static_cast<uint32_t>(lane);
     auto bits = [&](int v) { return v < 64 ? static_cast<int>(__float_as_uint(acc[v >> 4][v & 15])) : kNegInfBits; };
     uint64_t gm[22];
@@ -1480,6 +1497,9 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
         qpos = kDirectQueue;
       }
     }
+#if MI_FD_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bq[ks] = bn[ks];
   }
@@ -1770,7 +1790,7 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16) {
   L.off_e2max = align256(L.off_eps + B * 4);
   L.off_ub = align256(L.off_e2max + kNormGrid * 4);        // bf16 copies of U and E (64-column inputs only)
   L.off_eb = align256(L.off_ub + B * 128);
-  L.off_cnt = align256(L.off_eb + N * 128);
+  L.off_cnt = align256(L.off_eb + eb_rows(N) * 128);
   L.off_cand = align256(L.off_cnt + B * (128 + 1) * 4);  // f32 path: kSeg + 1 counters per row; bf16 path: <= 128 strips + 1
   L.bytes = align256(L.off_cand + B * (L.cap + kOvfCap) * 8);
   return L;
@@ -1793,7 +1813,7 @@ static bool masked_topk_supported(int64_t B, int64_t N, int64_t D, int64_t k) {
 }
 
 // `catalogue`: bf16 copy of E + partial norm maxima made by mi_oov_topk_catalogue_prepare (null: made per call).
-static int64_t catalogue_e2_offset(int64_t N) { return align256(N * 128); }
+static int64_t catalogue_e2_offset(int64_t N) { return align256(eb_rows(N) * 128); }
 static int64_t catalogue_parts(int64_t N) {
   const int64_t ge = grid_for(N, kBlock / 16);
   return ge > kNormGrid ? kNormGrid : ge;
