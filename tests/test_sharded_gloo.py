@@ -178,6 +178,81 @@ def _worker(rank, world, port, ret):
         dist.destroy_process_group()
 
 
+def _worker_odd(rank, world, port, ret):
+    """Three ranks: shards of unequal size (334 / 334 / 333 rows), a rank that is asked for nothing, ids on every
+    boundary; lsh, the pipelined steps and slsh against the unsharded oracle."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import mi_oov  # noqa: F401
+        from mi_oov import sharded
+        from oracle import oov_oracle as oracle
+        rng = np.random.default_rng(1)
+        N, F, H, D = 1001, 16, 8, 8
+        feat = rng.standard_normal((N, F), dtype=np.float32)
+        planes = rng.standard_normal((H, F), dtype=np.float32)
+        buckets = rng.standard_normal((H, D), dtype=np.float32)
+        lo, hi, per = sharded.shard_bounds(N, world, rank)
+        T = torch.from_numpy
+        fails = []
+        if (per, hi - lo) != (334, 334 if rank < 2 else 333):
+            fails.append(f"shard_bounds {per} {lo} {hi}")
+        table = sharded.ShardedLSHTable(T(feat[lo:hi]), N, prims=OraclePrims)
+        cases = {
+            "ragged": np.random.default_rng(10 + rank).integers(0, N, size=100 + 211 * rank),
+            "nothing_for_rank1": np.concatenate([np.arange(0, 334, 7), np.arange(668, N, 5)]),
+            "boundaries": np.array([0, 333, 334, 667, 668, 1000, 1001, -1, 333, 668]),
+            "empty_on_rank2": np.zeros((0,), np.int64) if rank == 2 else np.arange(300, 700),
+        }
+        for name, ids in cases.items():
+            ids = ids.astype(np.int64)
+            other = np.random.default_rng(40 + rank).standard_normal((len(ids), D), dtype=np.float32)
+            if not _same(table.embed(T(ids), T(planes), T(buckets)).numpy(), oracle.lsh_embed(ids, feat, planes, buckets)):
+                fails.append(f"embed {name}")
+            if not _same(table.embed_score(T(ids), T(planes), T(buckets), T(other)).numpy(),
+                         oracle.lsh_embed_score(ids, feat, planes, buckets, other)[0]):
+                fails.append(f"embed_score {name}")
+        # capacities agreed through max_batch; five pipelined steps
+        fixed = sharded.ShardedLSHTable(T(feat[lo:hi]), N, prims=OraclePrims, cap_factor=1.5, max_batch=400)
+        r2 = np.random.default_rng(60 + rank)
+        ids_l = [r2.integers(0, N, size=150 + 50 * rank).astype(np.int64) for _ in range(5)]
+        oth_l = [r2.standard_normal((len(i), D), dtype=np.float32) for i in ids_l]
+        sc_l = [torch.empty(len(i)) for i in ids_l]
+        sharded.LshPipeline(fixed, T(planes), T(buckets)).run([T(i) for i in ids_l], [T(o) for o in oth_l], sc_l)
+        for t in range(5):
+            if not _same(sc_l[t].numpy(), oracle.lsh_embed_score(ids_l[t], feat, planes, buckets, oth_l[t])[0]):
+                fails.append(f"pipeline step {t}")
+        if int(fixed.overflow) != 0:
+            fails.append("overflow")
+        # slsh, bucket table of 100 rows sharded 34 / 34 / 32
+        NB, n_pl = 100, 7
+        planes_s = rng.standard_normal((n_pl, F), dtype=np.float32)
+        bigt = rng.standard_normal((NB, D), dtype=np.float32)
+        blo, bhi, _ = sharded.shard_bounds(NB, world, rank)
+        window, win_lo = sharded.ShardedSLSHTable.gather_window(T(bigt[blo:bhi]), NB, n_pl)
+        st = sharded.ShardedSLSHTable(T(feat[lo:hi]), N, window, win_lo, NB, prims=OraclePrims)
+        for name, ids in cases.items():
+            ids = ids.astype(np.int64)
+            got, gidx = st.embed(T(ids), T(planes_s))
+            want, widx = oracle.slsh_embed(ids, feat, planes_s, bigt)
+            if not (np.array_equal(gidx.numpy(), widx) and _same(got.numpy(), want)):
+                fails.append(f"slsh {name}")
+        ret[rank] = fails
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_lookup_world3_uneven_shards():
+    from oracle import oov_oracle
+    oov_oracle.build()
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_odd, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: [], 1: [], 2: []}
+
+
 def test_exchange_lookup_world2():
     from oracle import oov_oracle
     oov_oracle.build()
