@@ -1325,26 +1325,27 @@ __device__ __forceinline__ uint32_t bf16_bits_rne(float v) {  // finite v
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <bool MASKED>
-__global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
+template <bool MASKED, int MT>  // MT 32-row tiles = the workgroup's user rows (every wave holds all of them)
+__global__ __launch_bounds__(kBlock, MT == 4 ? 2 : 4) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
                                                                        const __bf16* __restrict__ Eb, int64_t N,
                                                                        const float* __restrict__ thr, TopkArgs ta, StripLists sl,
                                                                        int nvisit) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  int* rowcnt = reinterpret_cast<int*>(smem);  // [BM] entries of the (row, strip) lists so far
+  constexpr int RM = MT * 32, NV = MT * 16, NG = (NV + 2) / 3;  // rows; accumulators per lane; groups of three
+  int* rowcnt = reinterpret_cast<int*>(smem);  // [RM] entries of the (row, strip) lists so far
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int i32 = lane & 31, hh = lane >> 5;
-  const int64_t b0 = static_cast<int64_t>(blockIdx.y) * BM;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.y) * RM;
   const int strip = blockIdx.x, nstrip = gridDim.x;
   if (strip >= nvisit) {
-    if (tid < BM && b0 + tid < B) sl.cnt[(b0 + tid) * sl.ns + strip] = 0;
+    if (tid < RM && b0 + tid < B) sl.cnt[(b0 + tid) * sl.ns + strip] = 0;
     return;
   }
-  const int rows_here = (B - b0 < BM) ? static_cast<int>(B - b0) : BM;
+  const int rows_here = (B - b0 < RM) ? static_cast<int>(B - b0) : RM;
   const uint32_t n_cols = static_cast<uint32_t>(N);
   const uint32_t skip = ta.n_skip_low < N ? static_cast<uint32_t>(ta.n_skip_low) : n_cols;
-  if (tid < BM) rowcnt[tid] = 0;
+  if (tid < RM) rowcnt[tid] = 0;
 
   // the wave's B slice of the strip's first block, then A
   const int ccol = wv * 32 + i32;  // this lane's column inside a block
@@ -1354,10 +1355,10 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) bq[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n0 + ccol, ks * 2 + hh));
   }
-  u32x4 aq[4][4];
-  s16x4 at[4];
+  u32x4 aq[MT][4];
+  s16x4 at[MT];
 #pragma unroll
-  for (int m = 0; m < 4; ++m) {
+  for (int m = 0; m < MT; ++m) {
     const int r = m * 32 + i32;
     const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
 #pragma unroll
@@ -1382,7 +1383,7 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
 
   uint64_t* cand_wg = sl.cand + (b0 * sl.ns + strip) * sl.cap;
   const int row_stride = sl.ns * sl.cap;
-  u32x4* queue = reinterpret_cast<u32x4*>(rowcnt + BM) + wv * (kDirectQueue + 1);  // {block, group, lane; three score images}; + a dump slot
+  u32x4* queue = reinterpret_cast<u32x4*>(rowcnt + RM) + wv * (kDirectQueue + 1);  // {block, group, lane; three score images}; + a dump slot
   int qpos = 0;  // records in the queue (wave-uniform)
   // Drain: 64 records at a time, a lane per record: list slots for its (up to three) passing scores -- the three LDS
   // atomics in flight together -- then keys and stores.
@@ -1400,7 +1401,7 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
       for (int t = 0; t < 3; ++t) {
         const int v = v0 + t;
         lrow[t] = (v >> 4) * 32 + (v & 3) + 8 * ((v & 15) >> 2) + 4 * (src >> 5);
-        ok[t] = static_cast<int>(image[t]) > kNegInfBits && col_ok && lrow[t] < rows_here;  // (v = 64, 65: image -inf)
+        ok[t] = static_cast<int>(image[t]) > kNegInfBits && col_ok && lrow[t] < rows_here;  // (v past the last accumulator: image -inf)
         if constexpr (MASKED) {
           if (ok[t]) ok[t] = !((sl.mask[(b0 + lrow[t]) * sl.mask_words + (col >> 6)] >> (col & 63u)) & 1ull);
         }
@@ -1431,9 +1432,9 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) bn[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n1 + ccol, ks * 2 + hh));
     }
-    f32x16 acc[4];
+    f32x16 acc[MT];
 #pragma unroll
-    for (int m = 0; m < 4; ++m) {
+    for (int m = 0; m < MT; ++m) {
       f32x16 c;
 #pragma unroll
       for (int r = 0; r < 16; ++r) c[r] = 0.f;
@@ -1458,11 +1459,11 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
     __builtin_amdgcn_s_setprio(MI_FD_PRIO);
 #endif
     const uint32_t tag0 = (static_cast<uint32_t>(j) << 12) | static_cast<uint32_t>(lane);
-    auto bits = [&](int v) { return v < 64 ? static_cast<int>(__float_as_uint(acc[v >> 4][v & 15])) : kNegInfBits; };
-    uint64_t gm[22];
+    auto bits = [&](int v) { return v < NV ? static_cast<int>(__float_as_uint(acc[v >> 4][v & 15])) : kNegInfBits; };
+    uint64_t gm[NG];
     uint64_t any = 0;
 #pragma unroll
-    for (int g = 0; g < 22; ++g) {
+    for (int g = 0; g < NG; ++g) {
       const int x0 = bits(3 * g), x1 = bits(3 * g + 1), x2 = bits(3 * g + 2);
       int mx = x0 > x1 ? x0 : x1;
       mx = mx > x2 ? mx : x2;
@@ -1471,7 +1472,7 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
     }
     if (any) {
 #pragma unroll
-      for (int g = 0; g < 22; ++g) {
+      for (int g = 0; g < NG; ++g) {
         if (gm[g]) {
           const int x0 = bits(3 * g), x1 = bits(3 * g + 1), x2 = bits(3 * g + 2);
           int mx = x0 > x1 ? x0 : x1;
@@ -1492,8 +1493,7 @@ __global__ __launch_bounds__(kBlock, 2) void bf16_filter_direct_kernel(const __b
       if (qpos > kDirectQueue) {
         // more records than the queue holds (a dozen rows of equal scores in this block): which were dropped is not
         // known any more, so all rows of the workgroup take the exact fallback
-        atomicOr(&rowcnt[lane], kRowLost);
-        atomicOr(&rowcnt[lane + 64], kRowLost);
+        for (int r = lane; r < RM; r += 64) atomicOr(&rowcnt[r], kRowLost);
         qpos = kDirectQueue;
       }
     }
@@ -1862,8 +1862,8 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       const int64_t rb = (B + BM - 1) / BM;
       static const int64_t target = [] { const char* e = getenv("MI_OOV_STRIP_WGS"); return e ? atoll(e) : 1024LL; }();
       static const int64_t target1 = [] { const char* e = getenv("MI_OOV_STRIP_WGS1"); return e ? atoll(e) : 768LL; }();  // pass 1: 3 workgroups per CU, one round
-      auto strips = [&](int64_t nvisit, int64_t tgt) {  // ~tgt workgroups in all, at most 128 strips, a multiple of 8 when there are 8 blocks
-        int64_t n = tgt / rb;
+      auto strips = [&](int64_t nvisit, int64_t tgt, int64_t row_blocks) {  // ~tgt workgroups in all, at most 128 strips, a multiple of 8 when there are 8 blocks
+        int64_t n = tgt / row_blocks;
         if (n > 128) n = 128;
         if (n > nvisit) n = nvisit;
         if (n < 1) n = 1;
@@ -1873,8 +1873,14 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       const int64_t nvisit1 = (nblk + L.stride - 1) / L.stride;
       static const bool direct_on = [] { const char* e = getenv("MI_OOV_FILTER_DIRECT"); return !(e && e[0] == '0'); }();  // developer knob: 0 = pass 2 with LDS-staged operands
       const bool direct = direct_on && nblk < (1 << 20);  // (a queue record has 20 bits for the block)
-      static const int64_t target_d = [] { const char* e = getenv("MI_OOV_STRIP_WGS2"); return e ? atoll(e) : 512LL; }();  // direct pass 2: 2 workgroups per CU
-      const int64_t ns1 = strips(nvisit1, target1), ns2 = strips(nblk, direct ? target_d : target);
+      // direct pass 2: workgroups of 64 user rows (2 tiles of 32: 123 registers, 4 waves per SIMD) and one round of 1024;
+      // MI_OOV_FILTER_TILES=4: 128 rows, 211 registers, 2 waves per SIMD, 512 workgroups (48 us instead of 41)
+      static const int mt_env = [] { const char* e = getenv("MI_OOV_FILTER_TILES"); return e && atoi(e) == 4 ? 4 : 2; }();
+      const int mt = (B + 63) / 64 > 65535 ? 4 : mt_env;  // (grid.y)
+      static const int64_t target_env = [] { const char* e = getenv("MI_OOV_STRIP_WGS2"); return e ? atoll(e) : 0LL; }();
+      const int64_t target_d = target_env > 0 ? target_env : (mt == 2 ? 1024 : 512);
+      const int64_t rbd = (B + mt * 32 - 1) / (mt * 32);
+      const int64_t ns1 = strips(nvisit1, target1, rb), ns2 = direct ? strips(nblk, target_d, rbd) : strips(nblk, target, rb);
       StripLists sl{};
       sl.ns = static_cast<int>(ns2);
       {  // list capacity: a power of two >= `MI_OOV_LIST_SLACK` (2) x the expected share of ~1.3 k stride candidates per
@@ -1928,12 +1934,17 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
                            static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf), bb);
       if ((rc = check_launch())) return rc;
       const size_t lds_direct = BM * sizeof(int) + 4 * (kDirectQueue + 1) * 16;
-      if (direct && mask)
-        hipLaunchKernelGGL((bf16_filter_direct_kernel<true>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_direct, st,
-                           Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
-      else if (direct)
-        hipLaunchKernelGGL((bf16_filter_direct_kernel<false>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_direct, st,
-                           Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
+      auto launch_direct = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rbd)), dim3(kBlock), lds_direct, st, Ub, B, Eb, N, thr, ta, sl,
+                           static_cast<int>(nblk));
+      };
+      if (direct && mask) {
+        if (mt == 2) launch_direct(bf16_filter_direct_kernel<true, 2>);
+        else launch_direct(bf16_filter_direct_kernel<true, 4>);
+      } else if (direct) {
+        if (mt == 2) launch_direct(bf16_filter_direct_kernel<false, 2>);
+        else launch_direct(bf16_filter_direct_kernel<false, 4>);
+      }
       else if (mask)
         hipLaunchKernelGGL((bf16_tile_kernel<EPI_FILTER, true>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
                            Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));

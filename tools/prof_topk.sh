@@ -21,3 +21,4 @@ PY
 run direct MI_OOV_FILTER_DIRECT=1
 run staged MI_OOV_FILTER_DIRECT=0
 for w in ${PT_WGS2:-}; do run direct_wgs$w MI_OOV_FILTER_DIRECT=1 MI_OOV_STRIP_WGS2=$w; done
+for t in ${PT_TILES:-}; do for w in ${PT_TILES_WGS:-512}; do run direct_tiles${t}_wgs$w MI_OOV_FILTER_DIRECT=1 MI_OOV_FILTER_TILES=$t MI_OOV_STRIP_WGS2=$w; done; done
