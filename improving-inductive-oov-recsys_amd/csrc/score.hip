@@ -81,8 +81,14 @@ constexpr int kSeg = 64, kSegCap = 16;  // 64 x 16 = the 1024 candidates the fin
 // A segment that is full spills into the row's overflow list (one more counter per row, kept behind the B x kSeg
 // segment counters; its entries behind the B x kSeg x kSegCap segment slots): with ~200 candidates per row a 17th
 // entry in one of 64 segments happens about once per few thousand rows, and the exact fallback for a row whose
-// candidates were lost re-scores the whole catalogue in one workgroup (6.5 ms at N = 50000).
-constexpr int kOvfCap = 128;
+// candidates were lost re-scores the whole catalogue in one workgroup (6.5 ms at N = 50000, 13 ms at 500 000, 0.26 s at
+// 10 M).  The count of candidates of a row is heavy-tailed when k is small -- tau is the k-th best of a SAMPLE, so the
+// count behaves like a Gamma(k) variable around its mean of ~1.3 k stride: with k = 2 one row in 10^5 has 7 times the
+// mean -- and with 128 overflow slots about one call in twenty of the 10 M-row knn search (k = 2) hit a fallback row
+// (0.39 s instead of 7 ms), as did row 1726 of the 4096 x 500 000, k = 5 sweep case (387 candidates, 13.4 ms instead
+// of 0.4).  512 slots put that at e^-36 per row.
+constexpr int kOvfCap = 512;
+constexpr int kOvfLds = 128;  // entries of an overflow list the finalize kernel keeps in LDS (longer lists: read in place)
 struct TopkArgs;
 __device__ __forceinline__ void append_candidate(const TopkArgs& ta, int64_t B, int64_t row, unsigned blk, uint64_t packed);
 
@@ -1535,12 +1541,13 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
                                                                      int64_t n_skip_low, StripLists sl,
                                                                      const float* __restrict__ eps_row,
                                                                      float* __restrict__ vals, int64_t* __restrict__ idx) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];  // kFinRows x (ns cap + kOvfCap) gathered entries
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // kFinRows x (ns cap + kOvfLds) gathered entries
   __shared__ int cnt_all[kFinRows][128], off_all[kFinRows][128];
   __shared__ int ovf_row[kFinRows];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int row = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x) * kFinRows + wv);  // wave-uniform
-  uint64_t* lc = reinterpret_cast<uint64_t*>(smem) + wv * (sl.ns * sl.cap + kOvfCap);
+  const int lds_cap = sl.ns * sl.cap + kOvfLds;  // entries of the row kept in LDS; a longer overflow list is read in place
+  uint64_t* lc = reinterpret_cast<uint64_t*>(smem) + wv * lds_cap;
   int* lcnt = cnt_all[wv];
   int* loff = off_all[wv];
   bool overflow = false;
@@ -1580,7 +1587,10 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
         for (int q = 0; q < 4; ++q)
           if (dst[q] >= 0) lc[dst[q]] = v[q];
       }
-      for (int j = lane; j < oc; j += 64) lc[t0 + t1 + j] = sl.ovf[static_cast<int64_t>(row) * kOvfCap + j];
+      const uint64_t* ovf_row_p = sl.ovf + static_cast<int64_t>(row) * kOvfCap;
+      const int n_lds = t0 + t1 + (oc < kOvfLds ? oc : kOvfLds);
+      for (int j = lane; j < n_lds - t0 - t1; j += 64) lc[t0 + t1 + j] = ovf_row_p[j];
+      auto entry = [&](int i) { return i < n_lds ? lc[i] : ovf_row_p[i - t0 - t1]; };  // i < n
       __builtin_amdgcn_wave_barrier();
       // Stage 1: v_k = the k-th best bf16 key: the largest T with at least kk keys >= T, bit by bit.  The k candidates
       // at or above it have exact scores >= v_k - eps, so a candidate whose bf16 score is below v_k - 2 eps (exact
@@ -1589,7 +1599,7 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
       const int kk = n < k ? n : k;
       uint32_t mykey[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mykey[q] = (q * 64 + lane < n) ? static_cast<uint32_t>(lc[q * 64 + lane] >> 32) : 0u;
+      for (int q = 0; q < 4; ++q) mykey[q] = (q * 64 + lane < n) ? static_cast<uint32_t>(entry(q * 64 + lane) >> 32) : 0u;
       uint32_t T = 0u;
       if (kk > 0) {
         for (int bit = 31; bit >= 0; --bit) {
@@ -1597,8 +1607,8 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
           int have = 0;
 #pragma unroll
           for (int q = 0; q < 4; ++q) have += __popcll(__ballot(mykey[q] >= c));  // (an absent slot's key 0 never counts: c > 0)
-          for (int b = 256; b < n; b += 64)  // lists longer than 256 entries (rare): from LDS
-            have += __popcll(__ballot(b + lane < n && static_cast<uint32_t>(lc[b + lane < n ? b + lane : 0] >> 32) >= c));
+          for (int b = 256; b < n; b += 64)  // lists longer than 256 entries (rare): from LDS / the overflow list
+            have += __popcll(__ballot(b + lane < n && static_cast<uint32_t>(entry(b + lane < n ? b + lane : 0) >> 32) >= c));
           if (have >= kk) T = c;
         }
       }
@@ -1611,15 +1621,20 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
       int m = 0;
       for (int base = 0; base < n; base += 64) {  // survivors to the front (a survivor's new slot is never above its old one)
         const int i = base + lane;
-        const uint64_t me = i < n ? lc[i] : 0;
+        const uint64_t me = i < n ? entry(i) : 0;
         const bool keep = i < n && !(key_to_float(static_cast<uint32_t>(me >> 32)) < cut);
         const uint64_t mask = __ballot(keep);
+        if (m + __popcll(mask) > lds_cap) {  // more survivors than LDS holds (never seen: ~45 of ~110 survive): exact fallback
+          overflow = true;
+          break;
+        }
         __builtin_amdgcn_wave_barrier();  // every lane holds its lc[i] before slots <= i are rewritten
         if (keep)
           lc[m + static_cast<int>(__builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u)))] = me;
         m += __popcll(mask);
       }
       __builtin_amdgcn_wave_barrier();
+      if (overflow) m = 0;  // (the row is redone below)
       for (int base = 0; base < m; base += 64) {  // usually one round: all the gathers of the row in flight together
         const int i = base + lane;
         if (i < m) {
@@ -1953,7 +1968,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
                            Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
       if ((rc = check_launch())) return rc;
       hipLaunchKernelGGL(topk_finalize_exact_kernel, dim3(static_cast<unsigned>((B + kFinRows - 1) / kFinRows)), dim3(kBlock),
-                         static_cast<size_t>(kFinRows) * (sl.ns * sl.cap + kOvfCap) * 8, st, U, E, B, N, D,
+                         static_cast<size_t>(kFinRows) * (sl.ns * sl.cap + kOvfLds) * 8, st, U, E, B, N, D,
                          static_cast<int>(k), n_skip_low, sl, eps, vals, idx);
       return check_launch();
     }

@@ -306,19 +306,25 @@ def test_fused_topk_vs_oracle(B, N, D, k, skip, oracle, ops, dev):
     assert bits_equal(vals.cpu().numpy(), o_vals)
 
 
-@pytest.mark.parametrize("case", ["queue_overflow", "popular_columns"])
+@pytest.mark.parametrize("case", ["queue_overflow", "popular_columns", "ties_300", "ties_450"])
 def test_fused_topk_direct_filter_queue(case, oracle, ops, dev):
     """The second pass (bf16_filter_direct_kernel) keeps passing scores in a per-wave queue of 256 records that lives
     across column blocks.  queue_overflow: 40 all-zero user rows inside one 128-row block tie everywhere, a wave finds
     far more than 256 passing lane-groups in a block, records are dropped and every row of that workgroup -- the
     ordinary ones too -- must come out of the exact fallback unchanged.  popular_columns: a few items score high for
-    every user, so single lanes push in most of the 22 groups of a block, block after block."""
+    every user, so single lanes push in most of the 22 groups of a block, block after block.  ties_300 / ties_450: that
+    many items share one row, so for the users that like it all of them are candidates inside three column blocks: the
+    (row, strip) lists run over into the row's overflow list (512 slots, of which the finalize kernel keeps 128 in LDS and
+    reads the rest in place), and with 450 of them more survive the bf16 cut than the kernel can rank in LDS: fallback."""
     rng = np.random.default_rng(11)
     B, N, k = 300, 9000, 20
     U = rng.standard_normal((B, 64), dtype=np.float32)
     E = rng.standard_normal((N, 64), dtype=np.float32)
     if case == "queue_overflow":
         U[130:170] = 0.0
+    elif case.startswith("ties_"):
+        n_ties = int(case.split("_")[1])
+        E[100:100 + n_ties] = 2.0 * U[:40].mean(0) / np.linalg.norm(U[:40].mean(0)) * 8.0
     else:
         E[[5, 777, 4100, 8999]] = 3.0 * np.abs(U).mean(0)   # large positive scores for most users
         U = np.abs(U)
