@@ -366,8 +366,9 @@ struct Dot64Keys {  // DotKeys for 64-float rows, 16-byte aligned: float4 loads,
   }
 };
 
-struct MaskedDot64Keys {  // ... with a row of exclusion bits: an excluded column gets key 0 (no real key is 0)
-  Dot64Keys dot;
+template <typename Dot>
+struct MaskedKeys {  // ... with a row of exclusion bits: an excluded column gets key 0 (no real key is 0)
+  Dot dot;
   const uint64_t* mrow;
   __device__ __forceinline__ uint32_t operator()(int64_t c) const {
     return ((mrow[c >> 6] >> (c & 63)) & 1ull) ? 0u : dot(c);
@@ -927,7 +928,8 @@ __device__ __forceinline__ int64_t eb_chunk(int64_t row, int chunk) {  // offset
 __global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __restrict__ U, int64_t B, __bf16* __restrict__ Ub,
                                                               float* __restrict__ u2, int* __restrict__ zero_rows, int gu,
                                                               const float* __restrict__ E, int64_t N, __bf16* __restrict__ Eb,
-                                                              uint32_t* __restrict__ e2part) {
+                                                              uint32_t* __restrict__ e2part, int D) {
+  // D <= 64 floats per row (any alignment when D < 64): the bf16 copies are zero-padded to 64 k
   __shared__ uint32_t bmax;
   const bool is_u = static_cast<int>(blockIdx.x) < gu;
   const float* M = is_u ? U : E;
@@ -946,7 +948,18 @@ __global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __res
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t r = r0 + q * step;
-      v[q] = r < rows ? *reinterpret_cast<const float4*>(M + r * 64 + l16 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < rows) {
+        if (D == 64) {
+          v[q] = *reinterpret_cast<const float4*>(M + r * 64 + l16 * 4);
+        } else {
+          const float* src = M + r * D + l16 * 4;
+          if (l16 * 4 + 0 < D) v[q].x = src[0];
+          if (l16 * 4 + 1 < D) v[q].y = src[1];
+          if (l16 * 4 + 2 < D) v[q].z = src[2];
+          if (l16 * 4 + 3 < D) v[q].w = src[3];
+        }
+      }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1617,7 +1630,7 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
       // Stage 2: exact f32 score of the survivors -- 16 independent float4 loads of the item row, then the oracle's chain
       // acc = fma(u[d], e[d], acc), d = 0..63 from +0 (the order the f32 MFMA kernel runs); the user row comes in
       // scalar registers
-      const float* u = U + static_cast<int64_t>(row) * 64;
+      const float* u = U + static_cast<int64_t>(row) * D;
       int m = 0;
       for (int base = 0; base < n; base += 64) {  // survivors to the front (a survivor's new slot is never above its old one)
         const int i = base + lane;
@@ -1639,17 +1652,23 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
         const int i = base + lane;
         if (i < m) {
           const uint32_t inv = static_cast<uint32_t>(lc[i]);
-          const float4* e4 = reinterpret_cast<const float4*>(E + static_cast<int64_t>(0xFFFFFFFFu - inv) * 64);
-          float4 ev[16];
-#pragma unroll
-          for (int c = 0; c < 16; ++c) ev[c] = e4[c];
           float acc = 0.f;
+          if (D == 64) {
+            const float4* e4 = reinterpret_cast<const float4*>(E + static_cast<int64_t>(0xFFFFFFFFu - inv) * 64);
+            float4 ev[16];
 #pragma unroll
-          for (int c = 0; c < 16; ++c) {
-            acc = __builtin_fmaf(u[4 * c + 0], ev[c].x, acc);
-            acc = __builtin_fmaf(u[4 * c + 1], ev[c].y, acc);
-            acc = __builtin_fmaf(u[4 * c + 2], ev[c].z, acc);
-            acc = __builtin_fmaf(u[4 * c + 3], ev[c].w, acc);
+            for (int c = 0; c < 16; ++c) ev[c] = e4[c];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) {
+              acc = __builtin_fmaf(u[4 * c + 0], ev[c].x, acc);
+              acc = __builtin_fmaf(u[4 * c + 1], ev[c].y, acc);
+              acc = __builtin_fmaf(u[4 * c + 2], ev[c].z, acc);
+              acc = __builtin_fmaf(u[4 * c + 3], ev[c].w, acc);
+            }
+          } else {  // narrower rows (D < 64): the oracle's chain for that width (DotKeys), zero-padded to the f32 kernel's K chunk
+            const float* e = E + static_cast<int64_t>(0xFFFFFFFFu - inv) * D;
+            for (int64_t d = 0; d < D; ++d) acc = __builtin_fmaf(u[d], e[d], acc);
+            if (D % KC) acc = __builtin_fmaf(0.f, 0.f, acc);
           }
           lc[i] = (static_cast<uint64_t>(order_key(acc)) << 32) | inv;
         }
@@ -1682,7 +1701,8 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
     const int64_t r = static_cast<int64_t>(blockIdx.x) * kFinRows + w;
     if (sl.mask) {  // excluded columns rank below every real key and are blanked afterwards (never returned)
       const uint64_t* mrow = sl.mask + r * sl.mask_words;
-      select_topk_row(MaskedDot64Keys{Dot64Keys{U + r * 64, E}, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
+      if (D == 64) select_topk_row(MaskedKeys<Dot64Keys>{Dot64Keys{U + r * 64, E}, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
+      else select_topk_row(MaskedKeys<DotKeys>{DotKeys{U + r * D, E, D}, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
       __syncthreads();
       for (int t = threadIdx.x; t < k; t += kBlock) {
         const int64_t c = idx[r * k + t];
@@ -1692,7 +1712,8 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
         }
       }
     } else {
-      select_topk_row(Dot64Keys{U + r * 64, E}, N, k, n_skip_low, vals + r * k, idx + r * k);
+      if (D == 64) select_topk_row(Dot64Keys{U + r * 64, E}, N, k, n_skip_low, vals + r * k, idx + r * k);
+      else select_topk_row(DotKeys{U + r * D, E, D}, N, k, n_skip_low, vals + r * k, idx + r * k);
     }
     __syncthreads();
   }
@@ -1824,7 +1845,7 @@ extern "C" int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k) 
 
 // The bf16 fused path can take per-row exclusions (a bitmap built from the CSR); `mask` is then B x ceil(N / 64) words.
 static bool masked_topk_supported(int64_t B, int64_t N, int64_t D, int64_t k) {
-  return B > 0 && N > 0 && N < (1LL << 32) && D == 64 && k > 0 && use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535;
+  return B > 0 && N > 0 && N < (1LL << 32) && D > 0 && D <= 64 && k > 0 && use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535;
 }
 
 // `catalogue`: bf16 copy of E + partial norm maxima made by mi_oov_topk_catalogue_prepare (null: made per call).
@@ -1845,7 +1866,8 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
   if (use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535) {
     const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
     static const bool bf16_path = [] { const char* e = getenv("MI_OOV_TOPK_BF16"); return !(e && e[0] == '0'); }();
-    const bool use_bf16 = (bf16_path || mask || catalogue) && D == 64 && vec;
+    // the bf16 path serves rows of up to 64 floats (narrower ones are zero-padded in the bf16 copies; 64-float rows must be 16-byte aligned)
+    const bool use_bf16 = (bf16_path || mask || catalogue) && (D < 64 || (D == 64 && vec));
     if ((mask || catalogue) && !use_bf16) return MI_OOV_ERR_ALIGN;  // (the entry points checked the shape; only alignment is left)
     const FusedLayout L = fused_layout(B, N, k, use_bf16);
     char* ws = static_cast<char*>(workspace);
@@ -1925,7 +1947,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       const int64_t ge = catalogue_parts(N);
       if (gu > kNormGrid) gu = kNormGrid;
       hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
-                         sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max);
+                         sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max, static_cast<int>(D));
       if ((rc = check_launch())) return rc;
       const size_t lds_ops = static_cast<size_t>(BM + BN) * BLD * sizeof(__bf16);
       const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
@@ -2033,19 +2055,19 @@ extern "C" int mi_oov_score_topk_masked(const float* U, int64_t B, const float* 
 // run) is converted once: the counterpart of the reference building its ScaNN searcher at construction
 // (knn_embedder.py:84-93).  The buffer holds the bf16 copy of E and the per-workgroup maxima of its squared row norms.
 extern "C" int64_t mi_oov_topk_catalogue_bytes(int64_t N, int64_t D) {
-  if (N <= 0 || N >= (1LL << 32) || D != 64) return 0;
+  if (N <= 0 || N >= (1LL << 32) || D <= 0 || D > 64) return 0;
   return catalogue_e2_offset(N) + align256(kNormGrid * 4);
 }
 
 extern "C" int mi_oov_topk_catalogue_prepare(const float* E, int64_t N, int64_t D, void* catalogue, void* stream) {
-  if (N <= 0 || N >= (1LL << 32) || D != 64) return MI_OOV_ERR_SHAPE;
+  if (N <= 0 || N >= (1LL << 32) || D <= 0 || D > 64) return MI_OOV_ERR_SHAPE;
   if (!E || !catalogue) return MI_OOV_ERR_NULL;
-  if (!aligned16(E) || (reinterpret_cast<uintptr_t>(catalogue) & 15u) != 0) return MI_OOV_ERR_ALIGN;
+  if ((D == 64 && !aligned16(E)) || (reinterpret_cast<uintptr_t>(catalogue) & 15u) != 0) return MI_OOV_ERR_ALIGN;
   __bf16* Eb = static_cast<__bf16*>(catalogue);
   uint32_t* e2part = reinterpret_cast<uint32_t*>(static_cast<char*>(catalogue) + catalogue_e2_offset(N));
   hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(catalogue_parts(N))), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                      static_cast<const float*>(nullptr), 0, static_cast<__bf16*>(nullptr), static_cast<float*>(nullptr),
-                     static_cast<int*>(nullptr), 0, E, N, Eb, e2part);
+                     static_cast<int*>(nullptr), 0, E, N, Eb, e2part, static_cast<int>(D));
   return check_launch();
 }
 

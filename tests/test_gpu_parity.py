@@ -289,7 +289,9 @@ def test_topk_edge_cases(oracle, ops, dev):
 
 
 @pytest.mark.parametrize("B,N,D,k,skip", [(70, 3000, 64, 10, 1), (9, 1300, 22, 5, 0), (130, 4159, 64, 20, 1),
-                                          (33, 20000, 32, 100, 1), (5, 40000, 64, 256, 7)])
+                                          (33, 20000, 32, 100, 1), (5, 40000, 64, 256, 7), (70, 5000, 4, 10, 1),
+                                          (40, 9000, 48, 20, 0), (12, 3000, 63, 7, 1), (20, 4000, 1, 3, 0),
+                                          (6, 2000, 96, 8, 1)])
 def test_fused_topk_vs_oracle(B, N, D, k, skip, oracle, ops, dev):
     """N >= 128 k takes the fused two-pass path (tile maxima -> tau -> filter -> rank): exact top-k with
     the [B,N] matrix never written, including ties across tiles, NaN rows and duplicated scores."""
@@ -409,11 +411,41 @@ def test_topk_prepared_catalogue(oracle, ops, dev):
     v2, i2 = ops.score_topk_excl(T(U, dev), cat, 15, T(ptr, dev), T(cols, dev), n_skip_low=1)
     ov, oi = oracle.score_topk_excl(U, E, 15, ptr, cols, 1)
     assert np.array_equal(i2.cpu().numpy(), oi) and np.array_equal(v2.cpu().numpy(), ov)
-    assert ops.TopkCatalogue.of(Eg[:, :32].contiguous()) is None          # a width the fused path does not take
+    assert ops.TopkCatalogue.of(torch.zeros((7000, 80), device=dev)) is None       # a width the fused path does not take
     Eg[5] += 1.0
     assert not cat.fresh()
     with pytest.raises(ValueError):
         ops.score_topk(T(U, dev), cat, 15, 1)
+
+
+@pytest.mark.parametrize("D", [22, 40])
+def test_topk_narrow_rows_take_the_bf16_path(D, oracle, ops, dev):
+    """Rows of fewer than 64 floats (a knn search over 22 feature columns, a 32-d model): the bf16 copies are zero-padded
+    to 64, the exact re-score runs the oracle's chain for the real width -- plain, with exclusions, and through a
+    prepared catalogue; same results as the oracle, bit for bit."""
+    rng = np.random.default_rng(D)
+    B, N, k = 200, 12000, 12
+    U = rng.standard_normal((B, D), dtype=np.float32)
+    E = rng.standard_normal((N, D), dtype=np.float32)
+    E[50:90] = E[50]                      # ties
+    U[3] = 0.0                            # a row of equal scores -> exact fallback with the narrow chain
+    Ug, Eg = T(U, dev), T(E, dev)
+    o_vals, o_idx = oracle.score_topk(U, E, k, 1)
+    vals, idx = ops.score_topk(Ug, Eg, k, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx) and bits_equal(vals.cpu().numpy(), o_vals)
+    cat = ops.TopkCatalogue.of(Eg)
+    assert cat is not None
+    vals, idx = ops.score_topk(Ug, cat, k, 1)
+    assert np.array_equal(idx.cpu().numpy(), o_idx) and bits_equal(vals.cpu().numpy(), o_vals)
+    lens = rng.integers(0, 300, B)
+    ptr = np.concatenate(([0], np.cumsum(lens))).astype(np.int64)
+    cols = rng.integers(1, N, int(ptr[-1])).astype(np.int64)
+    ov, oi = oracle.score_topk_excl(U, E, k, ptr, cols, 1)
+    for table in (Eg, cat):
+        v2, i2 = ops.score_topk_excl(Ug, table, k, T(ptr, dev), T(cols, dev), n_skip_low=1)
+        assert np.array_equal(i2.cpu().numpy(), oi) and np.array_equal(v2.cpu().numpy(), ov)
+    from mi_oov import _cabi as C
+    assert C.lib().mi_oov_score_topk_masked_workspace(B, N, D, k) > 0 and C.lib().mi_oov_score_topk_masked_workspace(B, N, 65, k) == 0
 
 
 def test_score_topk_user_chunks(oracle, ops, dev, monkeypatch):
