@@ -448,6 +448,30 @@ def test_topk_narrow_rows_take_the_bf16_path(D, oracle, ops, dev):
     assert C.lib().mi_oov_score_topk_masked_workspace(B, N, D, k) > 0 and C.lib().mi_oov_score_topk_masked_workspace(B, N, 65, k) == 0
 
 
+def test_fused_topk_random_shapes(oracle, ops, dev):
+    """Forty random shapes through the fused path -- user batches that are not multiples of the 64-row workgroups,
+    catalogues that end inside a tile, widths 1..64, k up to 64, skipped low columns, tie runs and a zero user row --
+    against the oracle, bit for bit."""
+    rng = np.random.default_rng(2026)
+    for case in range(40):
+        D = int(rng.choice([1, 3, 8, 16, 22, 31, 32, 40, 48, 63, 64]))
+        k = int(rng.choice([1, 2, 5, 10, 20, 33, 64]))
+        N = int(rng.integers(128 * k, 128 * k + 30000))
+        B = int(rng.integers(1, 200))
+        skip = int(rng.choice([0, 1, 1, 5]))
+        U = rng.standard_normal((B, D), dtype=np.float32)
+        E = rng.standard_normal((N, D), dtype=np.float32)
+        if case % 3 == 0:
+            a = int(rng.integers(0, N - 70))
+            E[a:a + int(rng.integers(2, 70))] = E[a]
+        if case % 5 == 0:
+            U[int(rng.integers(0, B))] = 0.0
+        vals, idx = ops.score_topk(T(U, dev), T(E, dev), k, skip)
+        o_vals, o_idx = oracle.score_topk(U, E, k, skip)
+        assert np.array_equal(idx.cpu().numpy(), o_idx), (case, B, N, D, k, skip)
+        assert bits_equal(vals.cpu().numpy(), o_vals), (case, B, N, D, k, skip)
+
+
 def test_score_topk_user_chunks(oracle, ops, dev, monkeypatch):
     """ops.score_topk bounds its workspace by going through big user batches in chunks (multiples of 128 rows)."""
     rng = np.random.default_rng(77)
