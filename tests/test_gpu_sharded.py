@@ -194,6 +194,16 @@ def test_world2_single_device_hip_local_compute(dev):
     assert dict(ret) == {0: [], 1: []}
 
 
+def test_world3_single_device_hip_local_compute(dev):
+    """Three ranks (shards of 666 668 / 666 668 / 666 667 rows): the exchange with the HIP kernels as local compute on a
+    world size that is not a power of two."""
+    world = 3
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rank_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
+    assert dict(ret) == {0: [], 1: [], 2: []}
+
+
 def test_bench_self_spawned_two_ranks_sharded_line(dev):
     """`python bench.py --gpus 2` from a bare shell: the parent starts the ranks itself, the N > 1 headline is the
     row-sharded mode with the replicated figure beside it.  Two ranks on the one device, gloo rendezvous (rehearsal
