@@ -42,6 +42,10 @@ _SIGNATURES = {
     "mi_oov_scatter_add_rows": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "mi_oov_lsh_embed_score": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_embed_score_multi": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "mi_oov_lsh_table_bytes": (_i64, [_i64, _i64]),
+    "mi_oov_lsh_table_prepare": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_lsh_multi": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64,
+                                        _vp, _vp]),
     "mi_oov_bucket_by_owner": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_codes_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_lookup": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),

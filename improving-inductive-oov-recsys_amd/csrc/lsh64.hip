@@ -169,9 +169,20 @@ __device__ __forceinline__ void lsh64_tile(unsigned tile, int l16, int grp, cons
     }
   }
   if (kDeferRows) {
+    // (non-temporal: the rows are written once and not read by this launch -- out of L2 / Infinity Cache they leave
+    //  those to the gathers; MI_EXP_NTROWS=0: plain stores)
+#ifndef MI_EXP_NTROWS
+#define MI_EXP_NTROWS 1
+#endif
+    typedef float v4f_ __attribute__((ext_vector_type(4)));
 #pragma unroll
     for (int r = 0; r < R; ++r)
-      if (FULL || row[r] < B) *reinterpret_cast<float4*>(reinterpret_cast<char*>(out) + (row[r] * 256u + l16 * 16u)) = emb_all[r];
+      if (FULL || row[r] < B) {
+        v4f_* dst = reinterpret_cast<v4f_*>(reinterpret_cast<char*>(out) + (row[r] * 256u + l16 * 16u));
+        const v4f_ v = {emb_all[r].x, emb_all[r].y, emb_all[r].z, emb_all[r].w};
+        if (MI_EXP_NTROWS) __builtin_nontemporal_store(v, dst);
+        else *dst = v;
+      }
   }
   if (BITS && FULL && l16 < 4)  // the tile's 16 code rows (128 contiguous bytes) in one store, like the scores
     *reinterpret_cast<uint2*>(bits + static_cast<size_t>(tile * 16u + l16 * 4u + grp) * 8u) = make_uint2(bits_lo, bits_hi);
@@ -535,7 +546,20 @@ static int launch64_h(const int64_t* ids, int64_t B, const float* feat, int64_t 
 
 int launch_lsh64_codes_persistent(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes,
                                   uint8_t* bits, hipStream_t st);  // lsh64p.hip
+int launch_lsh64_persistent_single(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable,
+                                   int64_t n_vocab, const float* planes, int H, const float* buckets, const float* other,
+                                   float* score, float* out, hipStream_t st);  // lsh64p.hip
 constexpr int64_t kCodesMinB = 262144;
+// One batch of scores or rows from this many lookups on: the persistent, software-pipelined kernel (a wave then walks
+// several tile pairs; below, the one-tile-per-wave launch of this file is faster).  MI_OOV_PERSIST_MIN_B: developer knob.
+static int64_t persist_min_b() {
+  static const int64_t v = [] {
+    const char* e = getenv("MI_OOV_PERSIST_MIN_B");
+    const int64_t x = e ? atoll(e) : 0;
+    return x > 0 ? x : int64_t(262144);
+  }();
+  return v;
+}
 static bool codes_persistent_enabled() {
   static const bool on = [] {
     const char* e = getenv("MI_OOV_CODES_PERSISTENT");  // developer A/B knob; default on
@@ -570,6 +594,7 @@ int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, co
     if (out) return launch64<8, false, true, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);
     return launch64<8, false, false, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);
   }
+  if (B >= persist_min_b() && !(score && out)) return launch_lsh64_persistent_single(ids, B, feat, N, vtable, n_vocab, planes, H, buckets, other, score, out, st);
   switch (H) {
 #define MI_CASE(HV) \
   case HV: return launch64_h<HV>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st);

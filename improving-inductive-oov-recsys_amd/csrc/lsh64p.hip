@@ -78,8 +78,14 @@ namespace mi_oov {
 #ifndef MI_PNT_U
 #define MI_PNT_U 1
 #endif
+#ifndef MI_PROWS_WG
+#define MI_PROWS_WG 1
+#endif
+#ifndef MI_PNT_O
+#define MI_PNT_O 1  // non-temporal stores for the rows of the rows mode
+#endif
 constexpr int kPWpb = MI_PWPB, kPBlk = 64 * kPWpb;
-constexpr int kModeScore = 0, kModeCodes = 1, kModeFromCodes = 2;
+constexpr int kModeScore = 0, kModeCodes = 1, kModeFromCodes = 2, kModeRows = 3;
 
 typedef const int64_t __attribute__((address_space(1))) * gptr_i64;
 typedef float __attribute__((address_space(1))) * gptr_f32;
@@ -88,6 +94,7 @@ typedef v2u __attribute__((address_space(1))) * gptr_u2;
 typedef const int32_t __attribute__((address_space(1))) * gptr_i32;
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef const v4f __attribute__((address_space(1))) * gptr_cv4;
+typedef v4f __attribute__((address_space(1))) * gptr_v4;
 // 16-byte load through a pointer KNOWN to be global: a pointer read from a table in memory is generic to the
 // compiler, and a flat_load counts against lgkmcnt as well as vmcnt, which would serialise the pipeline below
 template <bool NT = false>
@@ -114,9 +121,70 @@ __device__ __forceinline__ void round_ids(int64_t idv, int64_t (&id)[4]) {
   id[3] = bcast_id<3>(idv);
 }
 
+// The 2^H-row table of aggregates as a function of the bucket rows alone (sbuckets: [H][64] floats in LDS).  Stage 1 of
+// every table-using launch, or -- mi_oov_lsh_table_prepare -- made once per bucket table and then LOADED by the launches
+// (64 KiB out of L2 instead of ~4 us of dependent fmaf chains at the head of every launch).  The chain of a code runs
+// over the planes in increasing order, so all codes with the same LOW bits share its first steps: a thread takes one lane
+// slice and one pattern of the low kLow planes, runs that prefix once, and finishes the 2^(H - kLow) codes above it --
+// every fmaf(bit, w, acc) of the per-lookup chain is still executed (zero bits included: a non-finite bucket weight must
+// poison the row exactly as it does there), in the same order, so the entries are the bits the per-lookup code produces
+// (stamps: 5.5 us with one independent 8-step chain per entry, 3.7 with the shared prefix).
+template <int H, typename Dst>
+__device__ __forceinline__ void build_code_table(const float* sbuckets, Dst dst, int tid, int nthreads) {
+  constexpr int kLow = H < 5 ? H : 5, kHigh = H - kLow;
+  for (int i = tid; i < (16 << kLow); i += nthreads) {
+    const int m = i >> 4, l = i & 15;
+    float4 w[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) w[h] = *reinterpret_cast<const float4*>(sbuckets + (h * 16 + l) * 4);
+    float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cpre = 0.f;
+#pragma unroll
+    for (int h = 0; h < kLow; ++h) {
+      const float bit = ((m >> h) & 1) ? 1.f : 0.f;
+      cpre = cpre + bit;
+      pre.x = __builtin_fmaf(bit, w[h].x, pre.x);
+      pre.y = __builtin_fmaf(bit, w[h].y, pre.y);
+      pre.z = __builtin_fmaf(bit, w[h].z, pre.z);
+      pre.w = __builtin_fmaf(bit, w[h].w, pre.w);
+    }
+#pragma unroll
+    for (int hi = 0; hi < (1 << kHigh); ++hi) {
+      float4 acc = pre;
+      float cnt = cpre;
+#pragma unroll
+      for (int h = kLow; h < H; ++h) {
+        const float bit = ((hi >> (h - kLow)) & 1) ? 1.f : 0.f;
+        cnt = cnt + bit;
+        acc.x = __builtin_fmaf(bit, w[h].x, acc.x);
+        acc.y = __builtin_fmaf(bit, w[h].y, acc.y);
+        acc.z = __builtin_fmaf(bit, w[h].z, acc.z);
+        acc.w = __builtin_fmaf(bit, w[h].w, acc.w);
+      }
+      const float4 e = masked_mean(acc, cnt);
+      dst[((hi << kLow) | m) * 16 + l] = v4f{e.x, e.y, e.z, e.w};
+    }
+  }
+}
+
+// mi_oov_lsh_table_prepare: table f32[2^H][64] in global memory, one workgroup
+template <int H>
+__global__ __launch_bounds__(kPBlk) void lsh64_table_kernel(const float* __restrict__ buckets, float* __restrict__ table) {
+  __shared__ __attribute__((aligned(16))) float sb[H * 64];
+  if (threadIdx.x < H * 16)
+    *reinterpret_cast<float4*>(sb + threadIdx.x * 4) = *reinterpret_cast<const float4*>(buckets + threadIdx.x * 4);
+  __syncthreads();
+  build_code_table<H>(sb, (gptr_v4)table, threadIdx.x, kPBlk);
+}
+
 // TAB: ids_src / other_src / out_src are device arrays of K pointers (one per batch); otherwise they ARE the
-// pointers of the single batch (K = 1).  MODE_SCORE writes f32[B] scores; MODE_CODES writes u8[B,8] codes (H == 8).
-template <int H, int MODE, bool TAB>
+// pointers of the single batch (K = 1).  MODE_SCORE writes f32[B] scores; MODE_CODES writes u8[B,8] codes (H == 8);
+// MODE_ROWS writes the f32[B,64] embedding rows themselves -- what LSHInductiveEmbedder.embed_*_ids returns
+// (lsh_embedder.py:161-179).  LOOKUP (score / rows): BPR.get_*_embedding (bpr.py:48-125) -- ids below n_vocab address
+// `vtable` f32[n_vocab,64] and return that row, the others take the lsh path on feat[id]; F == D, so ONE gather per
+// lookup serves both cases with the base pointer selected per row (as lsh64_kernel<.., LOOKUP> does per batch).
+// tab_prep: the table of aggregates made by lsh64_table_kernel for this bucket table, or null (built here).
+template <int H, int MODE, bool TAB, bool LOOKUP = false>
 __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const void* __restrict__ ids_src,
                                                                         const void* __restrict__ other_src,
                                                                         void* __restrict__ out_src, unsigned K, unsigned B,
@@ -124,10 +192,15 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
                                                                         const float* __restrict__ planes,
                                                                         const float* __restrict__ buckets,
                                                                         unsigned* __restrict__ sched,
-                                                                        unsigned* __restrict__ sched_busy) {
-  static_assert(MODE == kModeScore || H == 8, "codes are written as one 8-byte word per lookup");
+                                                                        unsigned* __restrict__ sched_busy,
+                                                                        const float* __restrict__ vtable, int64_t n_vocab,
+                                                                        const float* __restrict__ tab_prep) {
+  static_assert(MODE == kModeScore || MODE == kModeRows || H == 8, "codes are written as one 8-byte word per lookup");
+  static_assert(!LOOKUP || MODE == kModeScore || MODE == kModeRows, "the in-vocabulary splice exists for scores and rows");
   constexpr bool kFromCodes = MODE == kModeFromCodes;  // ids = int32 slots, feat = u8[N,8] codes
   constexpr bool kScore = MODE == kModeScore || kFromCodes;
+  constexpr bool kRows = MODE == kModeRows;
+  constexpr bool kTable = kScore || kRows;  // the 2^H-row table of aggregates is needed
   constexpr int NU = kScore ? 4 : 1;
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
   const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -176,12 +249,17 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     round_ids(idv, id);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const bool valid = static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N);
       if constexpr (kFromCodes) {
+        const bool valid = static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N);
         const v2u c = ((gptr_u2)feat)[valid ? id[r] : 0];  // one address per 16-lane row
         x[r].x = __uint_as_float(c.x);
         x[r].y = __uint_as_float(c.y);
+      } else if constexpr (LOOKUP) {
+        const bool oov = id[r] >= n_vocab;
+        const bool valid = oov ? static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N) : id[r] >= 0;
+        x[r] = gload4<MI_PNT_X != 0>((oov ? feat : vtable) + (valid ? id[r] : 0) * 64 + l16 * 4);
       } else {
+        const bool valid = static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N);
         x[r] = gload4<MI_PNT_X != 0>(feat + (valid ? id[r] : 0) * 64 + l16 * 4);
       }
     }
@@ -293,27 +371,48 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   }
 
   // Weights.  Planes and bucket rows are staged global -> LDS first; then -- the ids have landed with them, vmcnt
-  // retires in order -- the rows of the wave's FIRST tile are requested, and the 2^H-row table of aggregates (score
-  // modes) is built out of LDS while they are in flight: the build issues no vector-memory instruction, so nothing
+  // retires in order -- the rows of the wave's FIRST tile are requested, and the 2^H-row table of aggregates (score /
+  // rows modes) is built out of LDS while they are in flight: the build issues no vector-memory instruction, so nothing
   // it waits for has the row gathers queued in front of it (MI_PEARLY=0: rows requested after the build, +~2 us per launch).
+  // With a PREPARED table (tab_prep) there is nothing to build: its 2^H x 256 bytes are requested right behind the ids
+  // (L2 hits after the first workgroups), the first tile's rows behind them, and the LDS copy is written while those
+  // rows are in flight -- one barrier instead of two and no fmaf chains at the head of the launch.
 #ifndef MI_PEARLY
 #define MI_PEARLY 1
 #endif
-  extern __shared__ __attribute__((aligned(16))) float sw[];  // [kScore ? 2^H : 0][64] table, [H][64] planes, [H][64] buckets
-  constexpr int kTabRows = kScore ? (1 << H) : 0;
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [kTable ? 2^H : 0][64] table, [H][64] planes, [H][64] buckets
+  constexpr int kTabRows = kTable ? (1 << H) : 0;
   float* splanes = sw + kTabRows * 64;
   float* sbuckets = splanes + H * 64;
+  const bool prep = kTable && tab_prep != nullptr;  // (uniform)
+  float4 xa[4], ua[NU], xb[4], ub[NU];
   {
     // (H * 16 <= 128 float4 per matrix: one per thread of the first two waves.)  The wave's first ticket is drawn
     // between the loads and the LDS stores: the draw waits for its reply, and waits while these loads are in flight.
     static_assert(H * 16 <= kPBlk, "one staging load per thread");
+    constexpr int kTabPer = kTable ? ((16 << H) + kPBlk - 1) / kPBlk : 1;  // float4 of a prepared table per thread
     const bool stage = threadIdx.x < H * 16;
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), bv = pv;
+    float4 tv[kTabPer];
     if constexpr (!kFromCodes) {
       if (stage) pv = *reinterpret_cast<const float4*>(planes + threadIdx.x * 4);
     }
-    if constexpr (kScore) {
-      if (stage) bv = *reinterpret_cast<const float4*>(buckets + threadIdx.x * 4);
+    if constexpr (kTable) {
+      if (prep) {
+#pragma unroll
+        for (int q = 0; q < kTabPer; ++q) {
+          const int i = q * kPBlk + static_cast<int>(threadIdx.x);
+          tv[q] = ((16 << H) % kPBlk == 0 || i < (16 << H)) ? gload4(tab_prep + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      } else if (stage) {
+        bv = *reinterpret_cast<const float4*>(buckets + threadIdx.x * 4);
+      }
+    }
+    asm volatile("" ::: "memory");
+    if constexpr (kTable) {
+      // (prepared table: the ids are older than the table's loads, so they are here before those are -- the first tile's
+      //  rows go out now, ahead of the ticket draw, and the LDS copy below is written in their shadow)
+      if (prep && MI_PEARLY && have) load_rows(pa, ida, xa, ua);
     }
     asm volatile("" ::: "memory");
     if (have) tk = draw();
@@ -321,53 +420,25 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     if constexpr (!kFromCodes) {
       if (stage) *reinterpret_cast<float4*>(splanes + threadIdx.x * 4) = pv;
     }
-    if constexpr (kScore) {
-      if (stage) *reinterpret_cast<float4*>(sbuckets + threadIdx.x * 4) = bv;
+    if constexpr (kTable) {
+      if (prep) {
+#pragma unroll
+        for (int q = 0; q < kTabPer; ++q) {
+          const int i = q * kPBlk + static_cast<int>(threadIdx.x);
+          if ((16 << H) % kPBlk == 0 || i < (16 << H)) *reinterpret_cast<float4*>(sw + i * 4) = tv[q];
+        }
+      } else if (stage) {
+        *reinterpret_cast<float4*>(sbuckets + threadIdx.x * 4) = bv;
+      }
     }
   }
   __syncthreads();
-  float4 xa[4], ua[NU], xb[4], ub[NU];
-  if (MI_PEARLY && have) load_rows(pa, ida, xa, ua);
-  if constexpr (kScore) {
-    // Table build (stamps: 5.5 us with one independent 8-step chain per entry).  The chain of a code runs over the planes
-    // in increasing order, so all codes with the same LOW bits share its first steps: a thread takes one lane slice and one
-    // pattern of the low kLow planes, runs that prefix once, and finishes the 2^(H - kLow) codes above it -- every
-    // fmaf(bit, w, acc) of the per-lookup chain is still executed (zero bits included: a non-finite bucket weight must
-    // poison the row exactly as it does there), in the same order, so the entries are the same bits as before.
-    constexpr int kLow = H < 5 ? H : 5, kHigh = H - kLow;
-    for (int i = threadIdx.x; i < (16 << kLow); i += kPBlk) {
-      const int m = i >> 4, l = i & 15;
-      float4 w[H];
-#pragma unroll
-      for (int h = 0; h < H; ++h) w[h] = *reinterpret_cast<const float4*>(sbuckets + (h * 16 + l) * 4);
-      float4 pre = make_float4(0.f, 0.f, 0.f, 0.f);
-      float cpre = 0.f;
-#pragma unroll
-      for (int h = 0; h < kLow; ++h) {
-        const float bit = ((m >> h) & 1) ? 1.f : 0.f;
-        cpre = cpre + bit;
-        pre.x = __builtin_fmaf(bit, w[h].x, pre.x);
-        pre.y = __builtin_fmaf(bit, w[h].y, pre.y);
-        pre.z = __builtin_fmaf(bit, w[h].z, pre.z);
-        pre.w = __builtin_fmaf(bit, w[h].w, pre.w);
-      }
-#pragma unroll
-      for (int hi = 0; hi < (1 << kHigh); ++hi) {
-        float4 acc = pre;
-        float cnt = cpre;
-#pragma unroll
-        for (int h = kLow; h < H; ++h) {
-          const float bit = ((hi >> (h - kLow)) & 1) ? 1.f : 0.f;
-          cnt = cnt + bit;
-          acc.x = __builtin_fmaf(bit, w[h].x, acc.x);
-          acc.y = __builtin_fmaf(bit, w[h].y, acc.y);
-          acc.z = __builtin_fmaf(bit, w[h].z, acc.z);
-          acc.w = __builtin_fmaf(bit, w[h].w, acc.w);
-        }
-        *reinterpret_cast<float4*>(sw + (((hi << kLow) | m) * 16 + l) * 4) = masked_mean(acc, cnt);
-      }
+  if (MI_PEARLY && have && !prep) load_rows(pa, ida, xa, ua);
+  if constexpr (kTable) {
+    if (!prep) {  // table build: see build_code_table
+      build_code_table<H>(sbuckets, reinterpret_cast<v4f*>(sw), static_cast<int>(threadIdx.x), kPBlk);
+      __syncthreads();
     }
-    __syncthreads();
   }
   float4 pw[kFromCodes ? 1 : H];
   if constexpr (!kFromCodes) {
@@ -408,28 +479,58 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     return code;
   };
 
-  // stage C: reduce and store one tile whose rows were requested a whole iteration ago
-  auto finish = [&](TilePos p, int64_t idv, const float4 (&x)[4], const float4 (&u)[NU]) {
+  // stage C: reduce one tile whose rows were requested a whole iteration ago (`reduce`), and store its result
+  // (`commit`).  The two are separate because of WHERE the store may sit in the wave's instruction stream: stores count
+  // against vmcnt like loads and vmcnt retires in order, so a wait for a load that was issued behind a store also waits
+  // for that store's acknowledgement from memory.  MI_PDEFER: a tile's result is kept in registers and stored right
+  // behind the NEXT request of gathered rows -- every load the loop waits for was then issued before the youngest store
+  // in flight, and no wait ever covers a store (rows mode: 4 x 16-byte stores per lane and tile).
+  struct Res {
+    float4 e[kRows ? 4 : 1];
+    float sc;
+    uint32_t lo, hi;
+    void* op;        // the batch's output (wave-uniform)
+    unsigned first;  // first row of the tile
+    bool full;       // all 16 rows exist (wave-uniform); otherwise rows < B are stored
+    unsigned lim;    // B; 0 in the empty result the pipeline starts with
+  };
+  auto reduce = [&](TilePos p, int64_t idv, const float4 (&x)[4], const float4 (&u)[NU]) -> Res {
+    Res res;
+    res.op = out_of(p.batch);
+    res.first = p.local * 16u;
+    res.full = p.local < nfull;
+    res.lim = B;
+    res.sc = 0.f;
+    res.lo = res.hi = 0u;
     int64_t id[4];
     round_ids(idv, id);
-    const bool full = p.local < nfull;
-    const unsigned row = p.local * 16u + l16 * 4u + grp;  // lane r of group grp keeps round r's result
+    // the embedding of round r's lookup: the table row at its code; with LOOKUP the gathered row itself when the id is
+    // in the vocabulary; NaN for an id that addresses no row
+    auto emb_of = [&](int r) -> float4 {
+      float4 emb = *reinterpret_cast<const float4*>(sw + (code_of(x[r]) * 16u + l16) * 4u);
+      bool bad;
+      if constexpr (LOOKUP) {
+        const bool oov = id[r] >= n_vocab;
+        if (!oov) emb = x[r];
+        bad = oov ? !(static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N)) : id[r] < 0;
+      } else {
+        bad = !(static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N));
+      }
+      if constexpr (kFromCodes)  // a byte above 1 (0xFF): the owner saw an id outside its shard
+        bad = bad || ((__float_as_uint(x[r].x) | __float_as_uint(x[r].y)) & 0xFEFEFEFEu) != 0;
+      if (bad) emb = make_float4(qnan(), qnan(), qnan(), qnan());
+      return emb;
+    };
     if constexpr (kScore) {
-      float sc_all = 0.f;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float4 emb = *reinterpret_cast<const float4*>(sw + (code_of(x[r]) * 16u + l16) * 4u);
-        bool bad = !(static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N));
-        if constexpr (kFromCodes)  // a byte above 1 (0xFF): the owner saw an id outside its shard
-          bad = bad || ((__float_as_uint(x[r].x) | __float_as_uint(x[r].y)) & 0xFEFEFEFEu) != 0;
-        if (bad) emb = make_float4(qnan(), qnan(), qnan(), qnan());
-        const float s = row16_sum(dot4_muladd(u[r], emb, 0.f));
-        if (l16 == r) sc_all = s;
+        const float s = row16_sum(dot4_muladd(u[r], emb_of(r), 0.f));
+        if (l16 == r) res.sc = s;  // lane r of group grp keeps round r's result
       }
-      // the tile's 16 contiguous scores in one store
-      if (l16 < 4 && (full || row < B)) ((gptr_f32)out_of(p.batch))[row] = sc_all;
+    } else if constexpr (kRows) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) res.e[r] = emb_of(r);
     } else {
-      uint32_t lo_all = 0, hi_all = 0;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const unsigned c = code_of(x[r]);
@@ -438,14 +539,40 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
         uint32_t hi = ((c >> 4) & 1u) | ((c & 32u) << 3) | ((c & 64u) << 10) | ((c & 128u) << 17);
         if (!(static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N))) lo = hi = 0xFFFFFFFFu;
         if (l16 == r) {
-          lo_all = lo;
-          hi_all = hi;
+          res.lo = lo;
+          res.hi = hi;
         }
       }
+    }
+    return res;
+  };
+  auto commit = [&](const Res& res) {
+    const unsigned row = res.first + l16 * 4u + grp;
+    if constexpr (kScore) {
+      // the tile's 16 contiguous scores in one store
+      if (l16 < 4 && (res.full || row < res.lim)) ((gptr_f32)res.op)[row] = res.sc;
+    } else if constexpr (kRows) {
+      // four 256-byte rows per 16-lane group, all four stores together (a store between the rounds of `reduce` would sit
+      // in front of the waits that follow it).  Non-temporal: the rows are written once and not read by this launch,
+      // and kept out of L2 / Infinity Cache they leave those to the gathers (K = 64: 6.37 -> 5.67 us per batch).
+      gptr_v4 op = (gptr_v4)res.op;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned orow = res.first + r * 4u + grp;
+        const v4f v = {res.e[r].x, res.e[r].y, res.e[r].z, res.e[r].w};
+        if (res.full || orow < res.lim) {
+#if MI_PNT_O
+          __builtin_nontemporal_store(v, op + (orow * 16u + l16));
+#else
+          op[orow * 16u + l16] = v;
+#endif
+        }
+      }
+    } else {
       // the tile's 16 code rows (128 contiguous bytes) in one store
-      if (l16 < 4 && (full || row < B)) {
-        v2u v = {lo_all, hi_all};
-        ((gptr_u2)out_of(p.batch))[row] = v;
+      if (l16 < 4 && (res.full || row < res.lim)) {
+        v2u v = {res.lo, res.hi};
+        ((gptr_u2)res.op)[row] = v;
       }
     }
   };
@@ -461,14 +588,30 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   // the prologue, into the loop, where it would turn the first wait of every iteration into vmcnt(0).)
   asm volatile("" : "+v"(ida), "+v"(idb));
   // One iteration retires the pair (a, b) -- a's rows and b's ids are in flight -- and brings the next pair (n, m) to
-  // that state:    ids(n)  rows(b)  finish(a)      ids(m)  rows(n)  finish(b)
+  // that state:    ids(n)  rows(b)  reduce(a)      ids(m)  rows(n)  reduce(b)
+  // with each result committed behind the rows request that follows its reduction (MI_PDEFER; the pipeline starts with an
+  // empty result whose store no lane executes: the steady-state loop holds no conditional memory instruction).
+#ifndef MI_PDEFER
+#define MI_PDEFER 1
+#endif
+  Res pend;
+  pend.op = out_src;
+  pend.first = 0u;
+  pend.full = false;
+  pend.lim = 0u;
+  pend.sc = 0.f;
+  pend.lo = pend.hi = 0u;
+#pragma unroll
+  for (int r = 0; r < (kRows ? 4 : 1); ++r) pend.e[r] = make_float4(0.f, 0.f, 0.f, 0.f);
   auto step_pair = [&](bool pool) {
     idn = load_ids(pn);
     asm volatile("" ::: "memory");
     load_rows(pb, idb, xb, ub);
     asm volatile("" ::: "memory");
+    if (MI_PDEFER) commit(pend);
     if (pool) tk = draw();
-    finish(pa, ida, xa, ua);
+    const Res ra = reduce(pa, ida, xa, ua);
+    if (!MI_PDEFER) commit(ra);
 #ifdef MI_PSTAMPS
     if (st2 == 0) MI_STAMP(st2);  // first tile finished
 #endif
@@ -476,7 +619,9 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     asm volatile("" ::: "memory");
     load_rows(pn, idn, xa, ua);
     asm volatile("" ::: "memory");
-    finish(pb, idb, xb, ub);
+    if (MI_PDEFER) commit(ra);
+    pend = reduce(pb, idb, xb, ub);
+    if (!MI_PDEFER) commit(pend);
     pa = pn; ida = idn;
     pb = pm; idb = idm;
   };
@@ -495,8 +640,9 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
   // drain: (a, b) is the wave's last pair
   load_rows(pb, idb, xb, ub);
   asm volatile("" ::: "memory");
-  finish(pa, ida, xa, ua);
-  finish(pb, idb, xb, ub);
+  if (MI_PDEFER) commit(pend);
+  commit(reduce(pa, ida, xa, ua));
+  commit(reduce(pb, idb, xb, ub));
   MI_STAMPS_OUT();
   leave();
 }
@@ -583,13 +729,14 @@ static int check_pool_launch(const SchedSlot& slot) {
 
 // resident workgroups of a persistent kernel on the current device (occupancy x CUs), cached per instantiation
 template <typename Kern>
-static int resident_blocks(Kern kernel, size_t lds, int& cached) {
+static int resident_blocks(Kern kernel, size_t lds, int& cached, int max_per_cu = 0) {
   if (cached > 0) return cached;
   int dev = 0, per_cu = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess) return 0;
   if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, kPBlk, lds) != hipSuccess) return 0;
   if (per_cu < 1 || cus < 1) return 0;
+  if (max_per_cu > 0 && per_cu > max_per_cu) per_cu = max_per_cu;
   cached = per_cu * cus;
   return cached;
 }
@@ -602,110 +749,168 @@ static int grid_override() {
   return v;
 }
 
-template <int H>
-static int launch_multi(const int64_t* const* ids_tab, const float* const* other_tab, float* const* score_tab, int64_t K,
-                        int64_t B, const float* feat, int64_t N, const float* planes, const float* buckets,
-                        hipStream_t st) {
-  const size_t lds = ((size_t(1) << H) + 2 * H) * 64 * sizeof(float);
-  auto kern = lsh64_persistent_kernel<H, kModeScore, true>;
+// One host launcher for every instantiation.  TAB: a.ids / a.other / a.out are device arrays of K pointers and every
+// batch has B lookups; otherwise they are the single batch's own pointers (K = 1), cut into launches of <= 2^23 rows
+// (32-bit byte offsets into the batch inside the kernel).
+struct PersistArgs {
+  const void* ids;    // int64 ids (FROM_CODES: int32 slots)
+  const void* other;  // f32[B,64] rows of the other side (score modes)
+  void* out;          // f32[B] scores / u8[B,8] codes / f32[B,64] rows
+  int64_t K, B;
+  const float* feat;  // f32[N,64] (FROM_CODES: u8[N,8] codes)
+  int64_t N;
+  const float* vtable;  // LOOKUP: f32[n_vocab,64]
+  int64_t n_vocab;
+  const float *planes, *buckets, *tab;
+};
+
+template <int H, int MODE, bool TAB, bool LOOKUP>
+static int launch_persistent(const PersistArgs& a, hipStream_t st) {
+  constexpr bool kTable = MODE != kModeCodes;
+  constexpr size_t lds = ((kTable ? (size_t(1) << H) : 0) + (kTable ? 2 * H : H)) * 64 * sizeof(float);
+  auto kern = lsh64_persistent_kernel<H, MODE, TAB, LOOKUP>;
   if (int rc = set_lds(kern, lds)) return rc;
   static int cached = 0;
-  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached);
+  // MI_PROWS_WG workgroups per CU in rows mode (its 97 registers would admit two: measured in DESIGN.md section 5)
+  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached, MODE == kModeRows ? MI_PROWS_WG : 0);
   if (resident <= 0) {
     g_last_hip_error = static_cast<int>(hipGetLastError());
     return MI_OOV_ERR_LAUNCH;
   }
-  const int64_t tpb = (B + 15) / 16;
-  // 32-bit tile cursor inside the kernel: at most 2^30 tiles per launch
-  const int64_t kmax = ((int64_t(1) << 30) / tpb) < 1 ? 1 : (int64_t(1) << 30) / tpb;
-  for (int64_t k0 = 0; k0 < K; k0 += kmax) {
-    const int64_t nk = (K - k0 < kmax) ? K - k0 : kmax;
-    const int64_t blocks_needed = (nk * tpb + kPWpb - 1) / kPWpb;
+  auto launch = [&](const void* ids, const void* other, void* out, int64_t k, int64_t b) -> int {
+    const int64_t tiles = k * ((b + 15) / 16);
+    const int64_t blocks_needed = (tiles + kPWpb - 1) / kPWpb;
     const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
-    const SchedSlot cset = take_sched_slot(st, nk * tpb, grid);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(ids_tab + k0),
-                       static_cast<const void*>(other_tab + k0), static_cast<void*>(const_cast<float**>(score_tab + k0)),
-                       static_cast<unsigned>(nk), static_cast<unsigned>(B), feat, N, planes, buckets, cset.counters, cset.busy_dev);
-    if (int rc = check_pool_launch(cset)) return rc;
+    const SchedSlot cset = take_sched_slot(st, tiles, grid);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, ids, other, out, static_cast<unsigned>(k), static_cast<unsigned>(b),
+                       a.feat, a.N, a.planes, a.buckets, cset.counters, cset.busy_dev, a.vtable, a.n_vocab, a.tab);
+    return check_pool_launch(cset);
+  };
+  if constexpr (TAB) {
+    const int64_t tpb = (a.B + 15) / 16;
+    // 32-bit tile cursor inside the kernel: at most 2^30 tiles per launch
+    const int64_t kmax = ((int64_t(1) << 30) / tpb) < 1 ? 1 : (int64_t(1) << 30) / tpb;
+    for (int64_t k0 = 0; k0 < a.K; k0 += kmax) {
+      const int64_t nk = (a.K - k0 < kmax) ? a.K - k0 : kmax;
+      if (int rc = launch(static_cast<const char*>(a.ids) + k0 * 8, a.other ? static_cast<const char*>(a.other) + k0 * 8 : nullptr,
+                          static_cast<char*>(a.out) + k0 * 8, nk, a.B))
+        return rc;
+    }
+  } else {
+    constexpr int64_t kMaxRows = int64_t(1) << 23;
+    constexpr int64_t id_bytes = MODE == kModeFromCodes ? 4 : 8;
+    constexpr int64_t out_bytes = MODE == kModeRows ? 256 : (MODE == kModeCodes ? 8 : 4);
+    for (int64_t b0 = 0; b0 < a.B; b0 += kMaxRows) {
+      const int64_t nb = (a.B - b0 < kMaxRows) ? a.B - b0 : kMaxRows;
+      if (int rc = launch(static_cast<const char*>(a.ids) + b0 * id_bytes,
+                          a.other ? static_cast<const char*>(a.other) + b0 * 256 : nullptr,
+                          static_cast<char*>(a.out) + b0 * out_bytes, 1, nb))
+        return rc;
+    }
   }
   return MI_OOV_OK;
+}
+
+template <int MODE, bool TAB, bool LOOKUP>
+static int launch_persistent_h(int H, const PersistArgs& a, hipStream_t st) {
+  switch (H) {
+#define MI_CASE(HV) \
+  case HV: return launch_persistent<HV, MODE, TAB, LOOKUP>(a, st);
+    MI_CASE(1) MI_CASE(2) MI_CASE(3) MI_CASE(4) MI_CASE(5) MI_CASE(6) MI_CASE(7) MI_CASE(8)
+#undef MI_CASE
+    default: return MI_OOV_ERR_SHAPE;
+  }
+}
+
+// scores (`score` given; rows of the other side in `other`) or rows (`out` given), with or without the in-vocabulary
+// table, K batches behind pointer tables (tab = true) or one batch
+static int launch_persistent_any(bool tab, int H, const PersistArgs& a, bool score, hipStream_t st) {
+#define MI_GO(M, T, L) return launch_persistent_h<M, T, L>(H, a, st)
+  if (tab) {
+    if (score) { if (a.vtable) MI_GO(kModeScore, true, true); MI_GO(kModeScore, true, false); }
+    if (a.vtable) MI_GO(kModeRows, true, true);
+    MI_GO(kModeRows, true, false);
+  }
+  if (score) { if (a.vtable) MI_GO(kModeScore, false, true); MI_GO(kModeScore, false, false); }
+  if (a.vtable) MI_GO(kModeRows, false, true);
+  MI_GO(kModeRows, false, false);
+#undef MI_GO
+}
+
+// One LARGE batch of scores or rows (F = D = 64, H <= 8): host entry used by launch_lsh64 (lsh64.hip) from
+// kPersistMinB lookups on -- below that a wave of this kernel has a tile or two and nothing to pipeline, and the
+// per-batch kernel's one-tile-per-wave launch is the faster one (crossover measured in DESIGN.md section 5).
+int launch_lsh64_persistent_single(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* vtable,
+                                   int64_t n_vocab, const float* planes, int H, const float* buckets, const float* other,
+                                   float* score, float* out, hipStream_t st) {
+  if ((score && out) || (!score && !out)) return MI_OOV_ERR_SHAPE;  // one output per launch
+  PersistArgs a{ids, other, score ? static_cast<void*>(score) : static_cast<void*>(out), 1, B, feat, N, vtable, n_vocab,
+                planes, buckets, nullptr};
+  return launch_persistent_any(false, H, a, score != nullptr, st);
 }
 
 // Codes of one large batch (H = 8, F = 64): host entry used by launch_lsh64 (lsh64.hip) for codes-only calls of at
 // least kCodesMinB lookups.  Below that a wave of the per-batch kernel has a single tile and nothing to pipeline.
 int launch_lsh64_codes_persistent(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes,
                                   uint8_t* bits, hipStream_t st) {
-  const size_t lds = 8 * 64 * sizeof(float);
-  auto kern = lsh64_persistent_kernel<8, kModeCodes, false>;
-  static int cached = 0;
-  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached);
-  if (resident <= 0) {
-    g_last_hip_error = static_cast<int>(hipGetLastError());
-    return MI_OOV_ERR_LAUNCH;
-  }
-  constexpr int64_t kMaxRows = int64_t(1) << 23;  // 32-bit byte offsets into the batch
-  for (int64_t b0 = 0; b0 < B; b0 += kMaxRows) {
-    const int64_t nb = (B - b0 < kMaxRows) ? B - b0 : kMaxRows;
-    const int64_t blocks_needed = ((nb + 15) / 16 + kPWpb - 1) / kPWpb;
-    const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
-    const SchedSlot cset = take_sched_slot(st, (nb + 15) / 16, grid);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(ids + b0),
-                       static_cast<const void*>(nullptr), static_cast<void*>(bits + b0 * 8), 1u, static_cast<unsigned>(nb),
-                       feat, N, planes, static_cast<const float*>(nullptr), cset.counters, cset.busy_dev);
-    if (int rc = check_pool_launch(cset)) return rc;
-  }
-  return MI_OOV_OK;
+  PersistArgs a{ids, nullptr, bits, 1, B, feat, N, nullptr, 0, planes, nullptr, nullptr};
+  return launch_persistent<8, kModeCodes, false, false>(a, st);
 }
 
 // Requester side of a sharded lookup, D = 64, H = 8, score only: host entry used by mi_oov_lsh_codes_embed
 // (exchange.hip).  codes u8[M,8] (8-byte aligned), slot i32[B], other f32[B,64], score f32[B].
 int launch_lsh64_from_codes(const uint8_t* codes, int64_t M, const int32_t* slot, int64_t B, const float* buckets,
                             const float* other, float* score, hipStream_t st) {
-  const size_t lds = (256 + 2 * 8) * 64 * sizeof(float);
-  auto kern = lsh64_persistent_kernel<8, kModeFromCodes, false>;
-  if (int rc = set_lds(kern, lds)) return rc;
-  static int cached = 0;
-  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached);
-  if (resident <= 0) {
-    g_last_hip_error = static_cast<int>(hipGetLastError());
-    return MI_OOV_ERR_LAUNCH;
-  }
-  constexpr int64_t kMaxRows = int64_t(1) << 23;  // 32-bit byte offsets into the batch
-  for (int64_t b0 = 0; b0 < B; b0 += kMaxRows) {
-    const int64_t nb = (B - b0 < kMaxRows) ? B - b0 : kMaxRows;
-    const int64_t blocks_needed = ((nb + 15) / 16 + kPWpb - 1) / kPWpb;
-    const int grid = static_cast<int>(blocks_needed < resident ? blocks_needed : resident);
-    const SchedSlot cset = take_sched_slot(st, (nb + 15) / 16, grid);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kPBlk), lds, st, static_cast<const void*>(slot + b0),
-                       static_cast<const void*>(other + b0 * 64), static_cast<void*>(score + b0), 1u,
-                       static_cast<unsigned>(nb), reinterpret_cast<const float*>(codes), M,
-                       static_cast<const float*>(nullptr), buckets, cset.counters, cset.busy_dev);
-    if (int rc = check_pool_launch(cset)) return rc;
-  }
-  return MI_OOV_OK;
+  PersistArgs a{slot, other, score, 1, B, reinterpret_cast<const float*>(codes), M, nullptr, 0, nullptr, buckets, nullptr};
+  return launch_persistent<8, kModeFromCodes, false, false>(a, st);
 }
 
 }  // namespace mi_oov
+
+using namespace mi_oov;
+
+extern "C" int64_t mi_oov_lsh_table_bytes(int64_t H, int64_t D) {
+  if (H < 1 || H > 8 || D != 64) return 0;
+  return (int64_t(1) << H) * D * static_cast<int64_t>(sizeof(float));
+}
+
+extern "C" int mi_oov_lsh_table_prepare(const float* buckets, int64_t H, int64_t D, float* table, void* stream) {
+  if (H < 1 || H > 8 || D != 64) return MI_OOV_ERR_SHAPE;
+  if (!buckets || !table) return MI_OOV_ERR_NULL;
+  if (!aligned16(buckets) || !aligned16(table)) return MI_OOV_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (H) {
+#define MI_CASE(HV) \
+  case HV: hipLaunchKernelGGL(lsh64_table_kernel<HV>, dim3(1), dim3(kPBlk), 0, st, buckets, table); break;
+    MI_CASE(1) MI_CASE(2) MI_CASE(3) MI_CASE(4) MI_CASE(5) MI_CASE(6) MI_CASE(7) MI_CASE(8)
+#undef MI_CASE
+  }
+  return check_launch();
+}
+
+extern "C" int mi_oov_lsh_multi(int mode, const int64_t* const* ids_tab, const float* const* other_tab, void* const* out_tab,
+                                int64_t K, int64_t B, const float* vtable, int64_t n_vocab, const float* feat, int64_t N,
+                                int64_t F, const float* planes, int64_t H, const float* buckets, int64_t D,
+                                const float* table, void* stream) {
+  if (mode != MI_OOV_LSH_SCORE && mode != MI_OOV_LSH_ROWS) return MI_OOV_ERR_KIND;
+  if (K < 0 || B < 0 || N <= 0 || (vtable && n_vocab < 0)) return MI_OOV_ERR_SHAPE;
+  if (K == 0 || B == 0) return MI_OOV_OK;
+  if (!ids_tab || !out_tab || !feat || !planes || (!buckets && !table)) return MI_OOV_ERR_NULL;
+  if (mode == MI_OOV_LSH_SCORE && !other_tab) return MI_OOV_ERR_NULL;
+  // the persistent kernel exists for the register-resident shape only (callers fall back to K single launches)
+  if (F != 64 || D != 64 || H < 1 || H > 8 || B > (int64_t(1) << 23)) return MI_OOV_ERR_SHAPE;
+  if (!aligned16(feat) || !aligned16(planes) || (buckets && !aligned16(buckets)) || (table && !aligned16(table)) ||
+      (vtable && !aligned16(vtable)) || (reinterpret_cast<uintptr_t>(ids_tab) & 7u) ||
+      (reinterpret_cast<uintptr_t>(other_tab) & 7u) || (reinterpret_cast<uintptr_t>(out_tab) & 7u))
+    return MI_OOV_ERR_ALIGN;
+  PersistArgs a{ids_tab, other_tab, const_cast<void**>(out_tab), K, B, feat, N, vtable, n_vocab, planes, buckets, table};
+  return launch_persistent_any(true, static_cast<int>(H), a, mode == MI_OOV_LSH_SCORE, static_cast<hipStream_t>(stream));
+}
 
 extern "C" int mi_oov_lsh_embed_score_multi(const int64_t* const* ids_tab, const float* const* other_tab,
                                             float* const* score_tab, int64_t K, int64_t B, const float* feat, int64_t N,
                                             int64_t F, const float* planes, int64_t H, const float* buckets, int64_t D,
                                             void* stream) {
-  using namespace mi_oov;
-  if (K < 0 || B < 0 || N <= 0) return MI_OOV_ERR_SHAPE;
-  if (K == 0 || B == 0) return MI_OOV_OK;
-  if (!ids_tab || !other_tab || !score_tab || !feat || !planes || !buckets) return MI_OOV_ERR_NULL;
-  // the persistent kernel exists for the register-resident shape only (callers fall back to K single launches)
-  if (F != 64 || D != 64 || H < 1 || H > 8 || B > (int64_t(1) << 23)) return MI_OOV_ERR_SHAPE;
-  if (!aligned16(feat) || !aligned16(planes) || !aligned16(buckets) || (reinterpret_cast<uintptr_t>(ids_tab) & 7u) ||
-      (reinterpret_cast<uintptr_t>(other_tab) & 7u) || (reinterpret_cast<uintptr_t>(score_tab) & 7u))
-    return MI_OOV_ERR_ALIGN;
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (H) {
-#define MI_CASE(HV) \
-  case HV: return launch_multi<HV>(ids_tab, other_tab, score_tab, K, B, feat, N, planes, buckets, st);
-    MI_CASE(1) MI_CASE(2) MI_CASE(3) MI_CASE(4) MI_CASE(5) MI_CASE(6) MI_CASE(7) MI_CASE(8)
-#undef MI_CASE
-    default: return MI_OOV_ERR_SHAPE;
-  }
+  return mi_oov_lsh_multi(MI_OOV_LSH_SCORE, ids_tab, other_tab, reinterpret_cast<void* const*>(score_tab), K, B, nullptr, 0,
+                          feat, N, F, planes, H, buckets, D, nullptr, stream);
 }

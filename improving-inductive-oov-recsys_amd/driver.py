@@ -285,7 +285,16 @@ def evaluate(model, users, items, tot_items, cfg, n_users, n_items, device, gen)
     """Batches shaped like NegSampleEvalDataLoader's (general_dataloader.py:157-190: per user the positives first,
     then `eval_negatives` sampled items per positive; users packed until eval_batch_size rows), scored through
     model.predict and ranked by the sampled-ranking evaluator (evaluator.py: segment top-k + hits kernels, the
-    reference's metric arithmetic).  NaN scores (all-zero lsh codes) are ranked as torch.topk ranks them: first."""
+    reference's metric arithmetic).  NaN scores (all-zero lsh codes) are ranked as torch.topk ranks them: first.
+
+    The reference scores one such batch per model.predict call.  Scores and rankings of a user do not depend on what
+    else is in its batch, so here the batches are QUEUED: the plan (which users form which batch) is made on the host
+    from ONE device -> host copy of the per-user counts -- the reference's dataloader plans on the host as well --,
+    every batch is then assembled with device operations only (negatives drawn batch by batch, in the reference's
+    order, so the sampled items do not depend on the queueing), and up to `eval_rows_per_launch` rows of consecutive
+    batches go through model.predict and the evaluator as ONE call: with BPR + lsh that is one user-row launch and one
+    fused lookup + score launch (the persistent kernel of csrc/lsh64p.hip from 524288 rows on) instead of two launches
+    and half a dozen host synchronisations per 1e5-row batch."""
     from .evaluator import SampledRankingEvaluator
     ukey, ikey, nneg = cfg["USER_ID_FIELD"], cfg["ITEM_ID_FIELD"], int(cfg["eval_negatives"])
     ev = SampledRankingEvaluator(cfg["topk"], cfg["metrics"] or ("recall", "mrr", "ndcg", "hit", "precision"),
@@ -293,30 +302,53 @@ def evaluate(model, users, items, tot_items, cfg, n_users, n_items, device, gen)
     order = torch.argsort(users, stable=True)
     su, si = users[order], items[order]
     uniq, counts = torch.unique_consecutive(su, return_counts=True)
-    starts = torch.cumsum(counts, 0) - counts
-    rows_per_user = (counts * (1 + nneg)).tolist()
-    lo_u, budget = 0, int(cfg["eval_batch_size"])
+    counts_h = counts.tolist()  # the run's one device -> host copy: the batch plan is made on the host
+    budget = int(cfg["eval_batch_size"])
+    group_rows = max(budget, int(cfg["eval_rows_per_launch"] or (1 << 22)))
+    # plan: batches of whole users with at most `budget` rows (a user with more rows is a batch of its own) ...
+    batches, lo_u, pos_lo = [], 0, 0
+    while lo_u < len(counts_h):
+        hi_u, npos = lo_u + 1, counts_h[lo_u]
+        while hi_u < len(counts_h) and (npos + counts_h[hi_u]) * (1 + nneg) <= budget:
+            npos += counts_h[hi_u]
+            hi_u += 1
+        batches.append((lo_u, hi_u, pos_lo, npos))
+        lo_u, pos_lo = hi_u, pos_lo + npos
+    # ... and groups of consecutive batches of at most `group_rows` rows, each ONE model.predict / evaluator call
+    groups, cur, cur_rows = [], [], 0
+    for bt in batches:
+        rows = bt[3] * (1 + nneg)
+        if cur and cur_rows + rows > group_rows:
+            groups.append(cur)
+            cur, cur_rows = [], 0
+        cur.append(bt)
+        cur_rows += rows
+    if cur:
+        groups.append(cur)
     with torch.no_grad():
-        while lo_u < len(rows_per_user):
-            hi_u, rows = lo_u + 1, rows_per_user[lo_u]
-            while hi_u < len(rows_per_user) and rows + rows_per_user[hi_u] <= budget:
-                rows += rows_per_user[hi_u]
-                hi_u += 1
-            cnt = counts[lo_u:hi_u]
-            nu = hi_u - lo_u
-            local = torch.arange(nu, device=device)
-            pos_u = torch.repeat_interleave(local, cnt)
-            pos_i = si[int(starts[lo_u]):int(starts[lo_u]) + int(cnt.sum())]
-            neg_u = torch.repeat_interleave(local, cnt * nneg)
-            neg_i = torch.randint(1, tot_items, (neg_u.numel(),), generator=gen, device=device)
-            # rows of one user are contiguous: its positives, then its negatives (stable sort by user)
-            row_idx = torch.cat((pos_u, neg_u))
-            col_idx = torch.cat((pos_i, neg_i))
-            perm = torch.sort(row_idx, stable=True).indices
-            row_idx, col_idx = row_idx[perm], col_idx[perm]
-            scores = model.predict({ukey: uniq[lo_u:hi_u][row_idx], ikey: col_idx.clone()})
-            ev.eval_batch(scores, uniq[lo_u:hi_u], row_idx, col_idx, pos_u, pos_i)
-            lo_u = hi_u
+        for grp in groups:
+            g_lo = grp[0][0]
+            row_parts, col_parts, pos_u_parts, pos_i_parts = [], [], [], []
+            for lo_u, hi_u, pos_lo, npos in grp:
+                cnt = counts[lo_u:hi_u]
+                local = torch.arange(lo_u - g_lo, hi_u - g_lo, device=device)  # index of the user inside the group
+                pos_u = torch.repeat_interleave(local, cnt, output_size=npos)
+                pos_i = si[pos_lo:pos_lo + npos]
+                neg_u = torch.repeat_interleave(local, cnt * nneg, output_size=npos * nneg)
+                neg_i = torch.randint(1, tot_items, (npos * nneg,), generator=gen, device=device)
+                # rows of one user are contiguous: its positives, then its negatives (stable sort by user)
+                row_idx = torch.cat((pos_u, neg_u))
+                col_idx = torch.cat((pos_i, neg_i))
+                perm = torch.sort(row_idx, stable=True).indices
+                row_parts.append(row_idx[perm])
+                col_parts.append(col_idx[perm])
+                pos_u_parts.append(pos_u)
+                pos_i_parts.append(pos_i)
+            row_idx, col_idx = torch.cat(row_parts), torch.cat(col_parts)
+            pos_u, pos_i = torch.cat(pos_u_parts), torch.cat(pos_i_parts)
+            g_users = uniq[g_lo:grp[-1][1]]
+            scores = model.predict({ukey: g_users[row_idx], ikey: col_idx.clone()})
+            ev.eval_batch(scores, g_users, row_idx, col_idx, pos_u, pos_i)
     return ev.evaluate()
 
 

@@ -238,6 +238,49 @@ class LSHInductiveEmbedder(_FeatureEmbedder):
         return ops.lsh_embed(item_ids, self.item_feature_mat, self.item_lsh.uniform_planes[0].data,
                              model.item_oov_buckets.weight)
 
+    # ---- K queued batches in one persistent launch (csrc/lsh64p.hip; not part of the reference surface) ----------
+    def lsh_table(self, side, model):
+        """The prepared 2^H-row table of aggregates of one side's bucket table (ops.LshTable: made once, re-made when the
+        bucket Parameter has been written to), or None for shapes the persistent kernel does not take."""
+        buckets = (model.user_oov_buckets if side == "user" else model.item_oov_buckets).weight
+        cache = self.__dict__.setdefault("_lsh_tables", {})
+        ent = cache.get(side)
+        if ent is None or ent.buckets is not buckets:
+            ent = cache[side] = ops.LshTable(buckets)
+        return ent
+
+    def _embed_ids_multi(self, side, ids_list, model, out=None):
+        user = side == "user"
+        if self.training:
+            for ids in ids_list:
+                _strip_prime_pad_(ids, self.prime_pad)
+        feat = self.user_feature_mat if user else self.item_feature_mat
+        planes = (self.user_lsh if user else self.item_lsh).uniform_planes[0].data
+        buckets = (model.user_oov_buckets if user else model.item_oov_buckets).weight
+        if torch.is_grad_enabled() and buckets.requires_grad:  # training: the per-batch autograd path
+            return [ops.lsh_embed(ids, feat, planes, buckets) for ids in ids_list]
+        return ops.lsh_embed_multi(ids_list, feat, planes, buckets, out=out, table=self.lsh_table(side, model))
+
+    def embed_user_ids_multi(self, user_ids_list, model, out=None):
+        """[embed_user_ids(ids, model) for ids in user_ids_list] (lsh_embedder.py:141-159), equal-sized batches, one launch."""
+        return self._embed_ids_multi("user", user_ids_list, model, out)
+
+    def embed_item_ids_multi(self, item_ids_list, model, out=None):
+        """[embed_item_ids(ids, model) for ids in item_ids_list] (lsh_embedder.py:161-179), equal-sized batches, one launch."""
+        return self._embed_ids_multi("item", item_ids_list, model, out)
+
+    def __deepcopy__(self, memo):
+        # prepared tables are derived state (get_flops deep-copies the model): re-made on first use by the copy
+        import copy
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k == "_lsh_tables":
+                continue
+            setattr(new, k, copy.deepcopy(v, memo))
+        return new
+
     # fused entry points used by this package's BPR (not part of the reference surface)
     def score_item_ids(self, item_ids, model, user_e):
         if self.training:

@@ -197,6 +197,29 @@ class BPR(InductiveGeneralRecommender):
         user_e, item_e = self.forward(user, item)
         return ops.rowdot(user_e, item_e)
 
+    def predict_multi(self, interactions):
+        """[predict(i) for i in interactions] for K queued batches OF THE SAME SIZE (a serving / evaluation loop with
+        its batches queued).  With the lsh plugin in inference: TWO persistent launches for all K batches -- the user
+        rows (in-vocabulary row or lsh row per id), then the item lookups fused with the row dot -- instead of 2 K
+        launches (bpr.py:145-149 over :48-125, K times).  Anything else: the per-batch path, K times."""
+        if not interactions:
+            return []
+        sizes = {int(i[self.USER_ID].numel()) for i in interactions}
+        if not self._fused_lsh_inference() or len(sizes) != 1 or len(interactions) == 1:
+            return [self.predict(i) for i in interactions]
+        emb = self.inductive_embedder
+        users = [i[self.USER_ID] for i in interactions]
+        items = [i[self.ITEM_ID] for i in interactions]
+        if self.inductive_mapper is not None:
+            users = [self.inductive_mapper.map_user_ids(u) for u in users]
+            items = [self.inductive_mapper.map_item_ids(t) for t in items]
+        user_rows = ops.lsh_lookup_multi(users, self.user_embedding.weight, emb.user_feature_mat,
+                                         emb.user_lsh.uniform_planes[0].data, self.user_oov_buckets.weight,
+                                         lsh_table=emb.lsh_table("user", self))
+        return ops.lsh_lookup_multi(items, self.item_embedding.weight, emb.item_feature_mat,
+                                    emb.item_lsh.uniform_planes[0].data, self.item_oov_buckets.weight,
+                                    other_list=user_rows, lsh_table=emb.lsh_table("item", self))
+
     def ind_full_sort_predict(self, interaction, item_ids):
         user_e = self.get_user_embedding(interaction[self.USER_ID])
         all_item_e = self.get_item_embedding(item_ids)

@@ -182,66 +182,125 @@ class LshScorer:
                            score_out.data_ptr(), None)
 
 
+class LshTable:
+    """The 2^H-row table of aggregates `(bits @ buckets) / popcount` for ONE bucket tensor, prepared once
+    (`mi_oov_lsh_table_prepare`) and handed to the persistent launches, which then load it instead of rebuilding it at
+    their head.  `get()` returns the device table, re-prepared whenever the bucket tensor was written to since (torch's
+    version counter: an optimizer step, `load_state_dict` and every other in-place operation on the tensor bump it;
+    a write through `.data` does NOT -- call `invalidate()` after one), or None for shapes the persistent kernel does
+    not take (D != 64 or more than 8 buckets): callers pass that on and the launch builds the table itself."""
+
+    __slots__ = ("buckets", "table", "version")
+
+    def __init__(self, buckets):
+        self.buckets = buckets  # the caller's tensor (a Parameter keeps its identity across optimizer steps)
+        self.table, self.version = None, None
+
+    def invalidate(self):
+        self.version = None
+
+    def get(self):
+        b = self.buckets
+        H, D = b.shape
+        nbytes = int(C.lib().mi_oov_lsh_table_bytes(H, D))
+        if nbytes <= 0 or not b.is_cuda or b.data_ptr() % 16 or not b.is_contiguous():
+            return None
+        if self.table is None or self.version != b._version or self.table.device != b.device:
+            if self.table is None or self.table.device != b.device:
+                self.table = torch.empty((1 << H, D), dtype=torch.float32, device=b.device)
+            src = _f32(b, "buckets")
+            with C.on_device(src):
+                rc = C.lib().mi_oov_lsh_table_prepare(C.ptr(src), H, D, C.ptr(self.table), C.stream_of(src))
+            C.check(rc, "mi_oov_lsh_table_prepare")
+            self.version = b._version
+        return self.table
+
+
 class LshBatchQueue:
-    """K queued batches for the persistent multi-batch launch (mi_oov_lsh_embed_score_multi, csrc/lsh64p.hip).
+    """K queued batches for the persistent multi-batch launch (mi_oov_lsh_multi, csrc/lsh64p.hip).
 
-    The kernel reads three device arrays of K pointers (ids, rows of the other side, scores).  This object validates
-    the K tensors of each kind ONCE, builds those arrays, and keeps every tensor alive until it is dropped:
+    The kernel reads device arrays of K pointers (ids, rows of the other side, outputs).  This object validates the K
+    tensors of each kind ONCE, builds those arrays, and keeps every tensor alive until it is dropped:
 
-        q = ops.LshBatchQueue(ids_list, other_list)            # scores allocated here ...
-        q = ops.LshBatchQueue(ids_list, other_list, score_list)  # ... or caller-owned f32[B] buffers
+        q = ops.LshBatchQueue(ids_list, other_list)              # SCORES: f32[B] per batch, allocated here ...
+        q = ops.LshBatchQueue(ids_list, other_list, score_list)  # ... or caller-owned buffers
+        q = ops.LshBatchQueue(ids_list, rows=True)               # ROWS: f32[B,D] per batch (what embed_*_ids returns)
+        q = ops.LshBatchQueue(ids_list, out_list=bufs, rows=True)
         scorer.run(q)              # all K batches, one launch
         scorer.run(q, 5, 20)       # batches 5 .. 24 of the queue (a slice costs nothing: pointer arithmetic)
 
     Every batch of a queue has the same B; D is the embedder's width."""
 
-    __slots__ = ("ids", "other", "scores", "K", "B", "D", "device", "tab")
+    __slots__ = ("ids", "other", "scores", "K", "B", "D", "device", "tab", "rows")
 
-    def __init__(self, ids_list, other_list, score_list=None):
+    def __init__(self, ids_list, other_list=None, score_list=None, rows=False, out_list=None, D=64):
+        if out_list is not None:
+            score_list = out_list
         K = len(ids_list)
-        if K == 0 or len(other_list) != K or (score_list is not None and len(score_list) != K):
-            raise ValueError("LshBatchQueue needs K >= 1 id tensors and as many row (and score) tensors")
+        if K == 0 or (not rows and (other_list is None or len(other_list) != K)) or \
+                (score_list is not None and len(score_list) != K):
+            raise ValueError("LshBatchQueue needs K >= 1 id tensors and as many row (and output) tensors")
         dev, B = ids_list[0].device, ids_list[0].numel()
-        D = other_list[0].shape[-1]
+        if not rows:
+            D = other_list[0].shape[-1]
         if score_list is None:
-            block = torch.empty((K, B), dtype=torch.float32, device=dev)
+            block = torch.empty((K, B, D) if rows else (K, B), dtype=torch.float32, device=dev)
             score_list = [block[k] for k in range(K)]
         for k in range(K):
-            i, o, s = ids_list[k], other_list[k], score_list[k]
-            for t, dt, nm in ((i, torch.int64, "ids"), (o, torch.float32, "other"), (s, torch.float32, "score")):
+            i, s = ids_list[k], score_list[k]
+            o = None if rows else other_list[k]
+            for t, dt, nm in ((i, torch.int64, "ids"), (o, torch.float32, "other"), (s, torch.float32, "out")):
+                if t is None:
+                    continue
                 C.dev_tensor(t, dt, f"{nm}[{k}]")
                 if not t.is_contiguous() or t.device != dev:
                     raise ValueError(f"{nm}[{k}] must be contiguous and on {dev}")
-            if i.numel() != B or o.shape != (B, D) or s.shape != (B,):
-                raise ValueError(f"batch {k}: need int64[{B}] ids, f32[{B},{D}] rows, f32[{B}] scores")
-            if o.data_ptr() % 16:
-                raise ValueError(f"other[{k}] is not 16-byte aligned")
-        self.ids, self.other, self.scores = list(ids_list), list(other_list), list(score_list)
-        self.K, self.B, self.D, self.device = K, B, D, dev
-        ptrs = [[t.data_ptr() for t in lst] for lst in (self.ids, self.other, self.scores)]
+            if i.numel() != B or (o is not None and o.shape != (B, D)) or s.shape != ((B, D) if rows else (B,)):
+                raise ValueError(f"batch {k}: need int64[{B}] ids" + ("" if rows else f", f32[{B},{D}] rows") +
+                                 (f", f32[{B},{D}] output rows" if rows else f", f32[{B}] scores"))
+            if (o is not None and o.data_ptr() % 16) or (rows and s.data_ptr() % 16):
+                raise ValueError(f"rows of batch {k} are not 16-byte aligned")
+        self.ids, self.other, self.scores = list(ids_list), (None if rows else list(other_list)), list(score_list)
+        self.K, self.B, self.D, self.device, self.rows = K, B, D, dev, bool(rows)
+        ptrs = [[t.data_ptr() for t in self.ids], [0] * K if rows else [t.data_ptr() for t in self.other],
+                [t.data_ptr() for t in self.scores]]
         self.tab = torch.tensor(ptrs, dtype=torch.int64).to(dev)  # [3, K] device pointers
+
+    @property
+    def outputs(self):
+        return self.scores
 
 
 class LshMultiScorer:
-    """lsh_embed_score for K batches in ONE persistent launch.  Static operands validated once (as LshScorer).
-    Shapes the persistent kernel does not serve (F or D != 64, H > 8) run as K single launches: same results."""
+    """The four lsh per-batch calls for K batches in ONE persistent launch (mi_oov_lsh_multi): scores or rows, with or
+    without the in-vocabulary table of BPR's lookups.  Static operands validated once (as LshScorer); the table of
+    aggregates is prepared once per bucket-table version (LshTable) unless `prepared=False`.
+    Shapes the persistent kernel does not serve (F or D != 64, H > 8) run as K single launches: same results.
 
-    __slots__ = ("feat", "planes", "buckets", "N", "F", "H", "D", "device", "_idx", "_fn", "persistent")
+        ops.LshMultiScorer(feat, planes, buckets).run(q)                  # K x lsh_embed_score  (q: scores queue)
+        ops.LshMultiScorer(feat, planes, buckets).run(q_rows)             # K x lsh_embed        (q: rows queue)
+        ops.LshMultiScorer(feat, planes, buckets, vtable=item_table).run(q)    # K x lsh_lookup_score / lsh_lookup"""
 
-    def __init__(self, feat, planes, buckets):
+    __slots__ = ("feat", "planes", "buckets", "vtable", "N", "F", "H", "D", "device", "_idx", "_fn", "persistent", "_table")
+
+    def __init__(self, feat, planes, buckets, vtable=None, prepared=True):
         self.feat, self.planes, self.buckets = _f32(feat, "feat"), _f32(planes, "planes"), _f32(buckets, "buckets")
         (self.N, self.F), self.H, self.D = self.feat.shape, self.planes.shape[0], self.buckets.shape[1]
         if self.planes.shape[1] != self.F:
             raise ValueError(f"planes have {self.planes.shape[1]} columns, features have {self.F}")
         if self.buckets.shape[0] != self.H:
             raise ValueError(f"lsh needs one bucket row per plane: {self.buckets.shape[0]} vs {self.H}")
+        self.vtable = None if vtable is None else _f32(vtable, "vtable")
+        if self.vtable is not None and self.vtable.shape[1] != self.D:
+            raise ValueError(f"the in-vocabulary table has {self.vtable.shape[1]} columns, the bucket table {self.D}")
         self.device = self.feat.device
         self._idx = self.device.index
-        self._fn = C.lib().mi_oov_lsh_embed_score_multi
+        self._fn = C.lib().mi_oov_lsh_multi
         self.persistent = self.F == 64 and self.D == 64 and 1 <= self.H <= 8
+        self._table = LshTable(buckets) if (prepared and self.persistent) else None
 
     def run(self, q, k0=0, k=None):
-        """Score batches [k0, k0 + k) of the queue (default: all).  Returns the list of score tensors."""
+        """Batches [k0, k0 + k) of the queue (default: all).  Returns the list of output tensors (scores or rows)."""
         k = q.K - k0 if k is None else k
         if k0 < 0 or k < 0 or k0 + k > q.K:
             raise ValueError(f"batches [{k0}, {k0 + k}) are not inside a queue of {q.K}")
@@ -251,23 +310,46 @@ class LshMultiScorer:
             return []
         if not self.persistent or q.B > (1 << 23):
             for j in range(k0, k0 + k):
-                lsh_embed_score(q.ids[j], self.feat, self.planes, self.buckets, q.other[j], score_out=q.scores[j])
+                self._single(q, j)
             return q.scores[k0:k0 + k]
+        table = self._table.get() if self._table is not None else None
         base = q.tab.data_ptr()
         step = q.K * 8
         if C.current_device() != self._idx:
             with C.on_device(self.feat):
-                rc = self._launch(base, step, k0, k, q.B)
+                rc = self._launch(q.rows, base, step, k0, k, q.B, table)
         else:
-            rc = self._launch(base, step, k0, k, q.B)
+            rc = self._launch(q.rows, base, step, k0, k, q.B, table)
         if rc:
-            C.check(rc, "mi_oov_lsh_embed_score_multi")
+            C.check(rc, "mi_oov_lsh_multi")
         return q.scores[k0:k0 + k]
 
-    def _launch(self, base, step, k0, k, B):
+    def _single(self, q, j):
+        lib, ids, out = C.lib(), q.ids[j], q.scores[j]
+        vt, nv = (self.vtable.data_ptr(), self.vtable.shape[0]) if self.vtable is not None else (None, 0)
+        with C.on_device(ids):
+            st = C.stream_of(ids)
+            if q.rows and vt is None:
+                rc = lib.mi_oov_lsh_embed(ids.data_ptr(), q.B, self.feat.data_ptr(), self.N, self.F, self.planes.data_ptr(), self.H,
+                                          self.buckets.data_ptr(), self.D, out.data_ptr(), None, st)
+            elif q.rows:
+                rc = lib.mi_oov_lsh_lookup(ids.data_ptr(), q.B, vt, nv, self.feat.data_ptr(), self.N, self.F, self.planes.data_ptr(),
+                                           self.H, self.buckets.data_ptr(), self.D, out.data_ptr(), st)
+            elif vt is None:
+                rc = lib.mi_oov_lsh_embed_score(ids.data_ptr(), q.B, self.feat.data_ptr(), self.N, self.F, self.planes.data_ptr(),
+                                                self.H, self.buckets.data_ptr(), self.D, q.other[j].data_ptr(), out.data_ptr(), None, st)
+            else:
+                rc = lib.mi_oov_lsh_lookup_score(ids.data_ptr(), q.B, vt, nv, self.feat.data_ptr(), self.N, self.F,
+                                                 self.planes.data_ptr(), self.H, self.buckets.data_ptr(), self.D,
+                                                 q.other[j].data_ptr(), out.data_ptr(), None, st)
+        C.check(rc, "single-batch launch of a queue the persistent kernel does not serve")
+
+    def _launch(self, rows, base, step, k0, k, B, table):
         off = k0 * 8
-        return self._fn(base + off, base + step + off, base + 2 * step + off, k, B, self.feat.data_ptr(), self.N, self.F,
-                        self.planes.data_ptr(), self.H, self.buckets.data_ptr(), self.D, C.raw_stream(self._idx))
+        vt, nv = (self.vtable.data_ptr(), self.vtable.shape[0]) if self.vtable is not None else (None, 0)
+        return self._fn(1 if rows else 0, base + off, None if rows else base + step + off, base + 2 * step + off, k, B, vt, nv,
+                        self.feat.data_ptr(), self.N, self.F, self.planes.data_ptr(), self.H, self.buckets.data_ptr(), self.D,
+                        None if table is None else table.data_ptr(), C.raw_stream(self._idx))
 
 
 def lsh_embed_score_multi(ids_list, feat, planes, buckets, other_list, score_out=None):
@@ -276,7 +358,26 @@ def lsh_embed_score_multi(ids_list, feat, planes, buckets, other_list, score_out
     q = LshBatchQueue(ids_list, other_list, score_out)
     # (the pointer table may be released as soon as the launch is enqueued: torch's caching allocator hands a freed
     # block only to work that is ordered behind the launch on the same stream)
-    return LshMultiScorer(feat, planes, buckets).run(q)
+    return LshMultiScorer(feat, planes, buckets, prepared=False).run(q)
+
+
+def lsh_embed_multi(ids_list, feat, planes, buckets, out=None, table=None):
+    """[lsh_embed(ids, feat, planes, buckets) for ids in ids_list] in one persistent launch: the [B, D] rows
+    LSHInductiveEmbedder.embed_*_ids returns (lsh_embedder.py:141-179), K batches of the same size.  Inference only."""
+    q = LshBatchQueue(ids_list, rows=True, out_list=out, D=buckets.shape[1])
+    sc = LshMultiScorer(feat, planes, buckets, prepared=False)
+    sc._table = table
+    return sc.run(q)
+
+
+def lsh_lookup_multi(ids_list, table, feat, planes, buckets, other_list=None, out=None, lsh_table=None):
+    """K batches of lsh_lookup (other_list None: the [B, D] rows of BPR.get_*_embedding, bpr.py:48-125) or of
+    lsh_lookup_score (other_list given: BPR.predict's scores, bpr.py:145-149) in one persistent launch."""
+    rows = other_list is None
+    q = LshBatchQueue(ids_list, other_list, out, rows=rows, D=buckets.shape[1])
+    sc = LshMultiScorer(feat, planes, buckets, vtable=table, prepared=False)
+    sc._table = lsh_table
+    return sc.run(q)
 
 
 def bucket_by_owner(ids, n_rows, rows_per_rank, world, cap, overflow=None):

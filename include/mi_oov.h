@@ -149,6 +149,36 @@ int mi_oov_lsh_embed_score_multi(const int64_t* const* ids_tab, const float* con
                                  const float* planes, int64_t H,
                                  const float* buckets, int64_t D, void* stream);
 
+/* The aggregate (bits @ buckets) / popcount takes only 2^H values: mi_oov_lsh_table_prepare writes them once --
+ * table f32[2^H, D], row c = the embedding of code c (bit h of c = plane h), made with exactly the per-lookup arithmetic
+ * (fmaf chain over the bucket rows in plane order from +0, one correctly rounded division; row 0 = 0/0 = NaN,
+ * lsh_embedder.py:178) -- and the persistent launches below load it instead of rebuilding it at their head.  The table
+ * is valid for the bucket values it was made from (the Python mirror re-prepares when the bucket tensor's version
+ * counter moves).  mi_oov_lsh_table_bytes: size of `table` in bytes, 0 for shapes the persistent kernel does not take
+ * (it takes D == 64, 1 <= H <= 8).  buckets, table 16-byte aligned.                                               */
+int64_t mi_oov_lsh_table_bytes(int64_t H, int64_t D);
+int mi_oov_lsh_table_prepare(const float* buckets, int64_t H, int64_t D, float* table, void* stream);
+
+/* K queued batches of ANY of the four lsh per-batch calls in ONE persistent launch (csrc/lsh64p.hip):
+ *   mode MI_OOV_LSH_SCORE, vtable NULL   K x mi_oov_lsh_embed_score   (= mi_oov_lsh_embed_score_multi)
+ *   mode MI_OOV_LSH_SCORE, vtable given  K x mi_oov_lsh_lookup_score  (BPR.predict, bpr.py:145-149 over :94-125)
+ *   mode MI_OOV_LSH_ROWS,  vtable NULL   K x mi_oov_lsh_embed         (LSHInductiveEmbedder.embed_*_ids,
+ *                                                                      lsh_embedder.py:141-179: the [B,D] rows)
+ *   mode MI_OOV_LSH_ROWS,  vtable given  K x mi_oov_lsh_lookup        (BPR.get_*_embedding, bpr.py:48-125)
+ * batch k gives exactly what the per-batch call gives for (ids_tab[k], other_tab[k]): same arithmetic, same order.
+ *   ids_tab    DEVICE array of K device pointers, each int64[B]
+ *   other_tab  DEVICE array of K device pointers, each f32[B,D] (score mode; NULL in rows mode)
+ *   out_tab    DEVICE array of K device pointers, each f32[B] (scores) or f32[B,D] (rows; 16-byte aligned), written
+ *   vtable     f32[n_vocab,D] or NULL;  table: mi_oov_lsh_table_prepare's output for `buckets`, or NULL (built per launch;
+ *              `buckets` may be NULL when a table is given)
+ * Shapes and pointer-table lifetime as for mi_oov_lsh_embed_score_multi.                                          */
+enum { MI_OOV_LSH_SCORE = 0, MI_OOV_LSH_ROWS = 1 };
+int mi_oov_lsh_multi(int mode, const int64_t* const* ids_tab, const float* const* other_tab, void* const* out_tab,
+                     int64_t K, int64_t B, const float* vtable, int64_t n_vocab,
+                     const float* feat, int64_t N, int64_t F,
+                     const float* planes, int64_t H,
+                     const float* buckets, int64_t D, const float* table, void* stream);
+
 /* BPR.get_user_embedding / get_item_embedding with an lsh plugin, one launch
  * (R/model/general_recommender/bpr.py:48-125): rows with id < n_vocab are copied from
  * `table`, the others take the lsh path above on feat[id].

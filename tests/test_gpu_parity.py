@@ -781,3 +781,124 @@ def test_lsh_bits_large_batch_persistent_codes_kernel(B, oracle, ops, dev):
     _, o_bits = oracle.lsh_embed(ids, feat, planes, np.zeros((8, 1), np.float32), want_bits=True)
     assert bits.shape == (B, 8) and np.array_equal(bits, o_bits)
     assert (bits[7] == 0xFF).all() and (bits[B - 1] == 0xFF).all() and (bits[0] == 1).all()
+
+
+# ---- round 3: rows / lookup modes of the persistent launch, prepared table of aggregates (mi_oov_lsh_multi) ------------
+@pytest.mark.parametrize("K,B,N,H", [(1, 1, 7, 8), (3, 63, 100, 8), (2, 4097, 3000, 8), (40, 333, 200, 8), (5, 65, 50, 1),
+                                     (4, 130, 90, 3), (3, 257, 60, 5), (2, 48, 33, 7), (300, 17, 40, 8), (2, 70001, 5000, 8)])
+@pytest.mark.parametrize("prepared", [False, True])
+def test_lsh_multi_rows_and_lookup_modes_vs_oracle(K, B, N, H, prepared, oracle, ops, dev):
+    """The four per-batch calls queued K times in one persistent launch, with the table of aggregates built inside the
+    launch or prepared once: rows (embed_*_ids' [B, 64] output), lookup rows (BPR.get_*_embedding: in-vocabulary rows
+    verbatim), scores and lookup scores -- every batch bit-identical to the oracle; ids outside the tables give NaN."""
+    rng = np.random.default_rng(K * 1000 + B + H)
+    n_vocab = max(1, N // 3)
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    feat[0] = 0
+    vtab = rng.standard_normal((n_vocab, 64), dtype=np.float32)
+    planes = rng.standard_normal((H, 64), dtype=np.float32)
+    buckets = rng.standard_normal((H, 64), dtype=np.float32)
+    ids = rng.integers(0, N, size=(K, B), dtype=np.int64)
+    ids[0, 0] = 0
+    if B > 5:
+        ids[K - 1, 3], ids[0, 4] = N + 5, -1
+    other = rng.standard_normal((K, B, 64), dtype=np.float32)
+    feat_d, planes_d, buckets_d, vtab_d = T(feat, dev), T(planes, dev), T(buckets, dev), T(vtab, dev)
+    ids_d, other_d = T(ids, dev), T(other, dev)
+    il, ol = [ids_d[k] for k in range(K)], [other_d[k] for k in range(K)]
+    tab = ops.LshTable(buckets_d) if prepared else None
+    if prepared:
+        assert tab.get() is not None and tab.get().shape == (1 << H, 64)
+    rows = ops.lsh_embed_multi(il, feat_d, planes_d, buckets_d, table=tab)
+    lrows = ops.lsh_lookup_multi(il, vtab_d, feat_d, planes_d, buckets_d, lsh_table=tab)
+    lscore = ops.lsh_lookup_multi(il, vtab_d, feat_d, planes_d, buckets_d, other_list=ol, lsh_table=tab)
+    sc = ops.LshMultiScorer(feat_d, planes_d, buckets_d, prepared=prepared).run(ops.LshBatchQueue(il, ol))
+    for k in range(K):
+        o_rows = oracle.lsh_embed(ids[k], feat, planes, buckets)
+        assert bits_equal(rows[k].cpu().numpy(), o_rows), f"rows, batch {k}"
+        o_lrows = oracle.lsh_lookup(ids[k], vtab, feat, planes, buckets)
+        got = lrows[k].cpu().numpy()
+        assert bits_equal(got, o_lrows), f"lookup rows, batch {k}"
+        iv = (ids[k] >= 0) & (ids[k] < n_vocab)
+        assert bits_equal(got[iv], vtab[ids[k][iv]])
+        assert bits_equal(lscore[k].cpu().numpy(), oracle.rowdot(other[k], o_lrows)), f"lookup score, batch {k}"
+        assert bits_equal(sc[k].cpu().numpy(), oracle.lsh_embed_score(ids[k], feat, planes, buckets, other[k])[0]), f"score, batch {k}"
+    if B > 5:
+        assert np.isnan(rows[K - 1][3].cpu().numpy()).all() and np.isnan(lrows[0][4].cpu().numpy()).all()
+
+
+def test_lsh_table_prepared_equals_per_lookup_arithmetic_and_tracks_updates(oracle, ops, dev):
+    """mi_oov_lsh_table_prepare: row c of the table is the embedding of code c -- the oracle's lsh_embed of a feature row
+    whose projections have exactly those signs -- for every H the persistent kernel takes; row 0 is the reference's NaN
+    row; a non-finite bucket weight poisons exactly the rows the per-lookup chain poisons; and ops.LshTable re-prepares
+    after an in-place update of the bucket tensor (an optimizer step)."""
+    rng = np.random.default_rng(11)
+    for H in range(1, 9):
+        buckets = rng.standard_normal((H, 64), dtype=np.float32)
+        if H == 5:
+            buckets[2, 7] = np.inf
+        if H == 6:
+            buckets[0, :] *= 1e-38  # subnormal quotients take the IEEE division branch
+        b_d = T(buckets, dev)
+        tab = ops.LshTable(b_d)
+        got = tab.get().cpu().numpy()
+        # a 64-wide feature row e_h projects onto plane h alone: planes = +-identity rows give every code
+        planes = np.zeros((H, 64), np.float32)
+        planes[np.arange(H), np.arange(H)] = 1.0
+        codes = np.arange(1 << H)
+        feat = np.full((1 << H, 64), 0.0, np.float32)
+        feat[:, :H] = np.where((codes[:, None] >> np.arange(H)) & 1, 1.0, -1.0)
+        want = oracle.lsh_embed(codes.astype(np.int64), feat, planes, buckets)
+        assert bits_equal(got, want), f"H = {H}"
+        assert np.isnan(got[0]).all()
+        b_d.mul_(2.0)  # in place: the version counter moves
+        got2 = tab.get().cpu().numpy()
+        want2 = oracle.lsh_embed(codes.astype(np.int64), feat, planes, (buckets * np.float32(2.0)).astype(np.float32))
+        assert bits_equal(got2, want2), f"H = {H} after an in-place update"
+    assert ops.LshTable(torch.zeros((9, 64), device=dev)).get() is None
+    assert ops.LshTable(torch.zeros((8, 32), device=dev)).get() is None
+
+
+@pytest.mark.parametrize("B", [524288 + 37, 600000])
+def test_lsh_large_single_batch_takes_the_persistent_kernel(B, oracle, ops, dev):
+    """One call of >= 524288 scored lookups (F = D = 64, H <= 8) runs on the persistent kernel with a single batch
+    (TAB = false): lsh_embed_score and lsh_lookup_score, bit-identical to the oracle, partial last tile, invalid ids."""
+    rng = np.random.default_rng(B)
+    N, n_vocab, H = 40_000, 15_000, 8
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    vtab = rng.standard_normal((n_vocab, 64), dtype=np.float32)
+    planes = rng.standard_normal((H, 64), dtype=np.float32)
+    buckets = rng.standard_normal((H, 64), dtype=np.float32)
+    ids = rng.integers(0, N, size=B, dtype=np.int64)
+    ids[0], ids[7], ids[B - 1] = 0, -1, N
+    other = rng.standard_normal((B, 64), dtype=np.float32)
+    f, p, w, v, o, i = T(feat, dev), T(planes, dev), T(buckets, dev), T(vtab, dev), T(other, dev), T(ids, dev)
+    want, _ = oracle.lsh_embed_score(ids, feat, planes, buckets, other)
+    assert bits_equal(ops.lsh_embed_score(i, f, p, w, o).cpu().numpy(), want)
+    lrows = oracle.lsh_lookup(ids, vtab, feat, planes, buckets)
+    assert bits_equal(ops.lsh_lookup_score(i, v, f, p, w, o).cpu().numpy(), oracle.rowdot(other, lrows))
+
+
+def test_lsh_multi_generic_entry_raw_cabi_errors(ops, dev):
+    """Status codes of mi_oov_lsh_multi / mi_oov_lsh_table_prepare: unknown mode, missing tables, shapes, alignment."""
+    from mi_oov import _cabi as C
+    lib = C.lib()
+    feat = torch.zeros((10, 64), device=dev)
+    planes = torch.zeros((8, 64), device=dev)
+    buckets = torch.zeros((8, 64), device=dev)
+    table = torch.zeros((256, 64), device=dev)
+    tab = torch.zeros((3, 4), dtype=torch.int64, device=dev)
+    st = C.stream_of(feat)
+    fn, base = lib.mi_oov_lsh_multi, tab.data_ptr()
+    common = (feat.data_ptr(), 10, 64, planes.data_ptr(), 8)
+    assert fn(7, base, base, base, 1, 16, None, 0, *common, buckets.data_ptr(), 64, None, st) == -3       # MI_OOV_ERR_KIND
+    assert fn(0, base, None, base, 1, 16, None, 0, *common, buckets.data_ptr(), 64, None, st) == -1       # score mode needs rows
+    assert fn(1, base, None, base, 1, 16, None, 0, *common, None, 64, None, st) == -1                     # neither buckets nor table
+    assert fn(1, base, None, base, 1, 16, None, 0, *common, None, 64, table.data_ptr() + 4, st) == -5     # misaligned table
+    assert fn(1, base, None, base, 1, 16, None, 0, feat.data_ptr(), 10, 32, planes.data_ptr(), 8, buckets.data_ptr(), 64, None, st) == -2
+    assert fn(1, base, None, base, 0, 16, None, 0, *common, buckets.data_ptr(), 64, None, st) == 0        # K = 0
+    assert lib.mi_oov_lsh_table_bytes(8, 64) == 65536 and lib.mi_oov_lsh_table_bytes(9, 64) == 0 and lib.mi_oov_lsh_table_bytes(8, 128) == 0
+    assert lib.mi_oov_lsh_table_prepare(buckets.data_ptr(), 9, 64, table.data_ptr(), st) == -2
+    assert lib.mi_oov_lsh_table_prepare(None, 8, 64, table.data_ptr(), st) == -1
+    assert lib.mi_oov_lsh_table_prepare(buckets.data_ptr(), 8, 64, table.data_ptr() + 8, st) == -5
+    torch.cuda.synchronize()

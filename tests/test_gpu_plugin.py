@@ -585,3 +585,81 @@ def test_torch_ops_dispatch_and_autograd(mi, dev):
         (op_t(ids[keep], feat, planes, w1) * other[keep][:, :table.shape[1]]).sum().backward()
         (op_o(ids[keep], feat, planes, w2) * other[keep][:, :table.shape[1]]).sum().backward()
         assert w1.grad is not None and torch.equal(w1.grad, w2.grad)
+
+
+# ---- round 3: the plugin's K-batch entry points and the queued evaluation loop -------------------------------------------
+def _synthetic_bpr(mi, dev, n_users=900, n_items=1500, new_users=400, new_items=700, H=8, seed=3):
+    """BPR + lsh on 64-wide synthetic features (the persistent kernel's shape): ids below n_* are in the vocabulary,
+    the rest of the feature tables' rows are out of it."""
+    g = torch.Generator().manual_seed(seed)
+    fu = torch.randn((n_users + new_users, 64), generator=g)
+    fi = torch.randn((n_items + new_items, 64), generator=g)
+    ft_u = mi.FeatureTable({"id": torch.arange(fu.shape[0]), "f": fu})
+    ft_i = mi.FeatureTable({"id": torch.arange(fi.shape[0]), "f": fi})
+    cfg = Cfg(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device=dev, embedding_size=64,
+              add_oov_buckets=True, user_oov_buckets=H, item_oov_buckets=H, oov_freeze_embedding=False)
+    lsh = mi.LSHInductiveEmbedder(ft_u, ft_i, n_users, n_items, H, H, 64, dev, PRIME_PAD, "none", mi.InductiveFeatureCache())
+    model = mi.BPR(cfg, DS(n_users, n_items), None, lsh).to(dev)
+    model.eval()
+    return model, lsh, fu.shape[0], fi.shape[0]
+
+
+def test_embedder_and_bpr_multi_batch_entry_points(mi, dev):
+    """LSHInductiveEmbedder.embed_*_ids_multi and BPR.predict_multi (K queued batches, one persistent launch each) give
+    exactly what K calls of embed_*_ids / predict give; the prepared table follows an in-place update of the buckets."""
+    model, lsh, tot_u, tot_i = _synthetic_bpr(mi, dev)
+    g = torch.Generator(device=dev).manual_seed(1)
+    K, B = 7, 333
+    items = [torch.randint(0, tot_i, (B,), generator=g, device=dev) for _ in range(K)]
+    users = [torch.randint(0, tot_u, (B,), generator=g, device=dev) for _ in range(K)]
+    with torch.no_grad():
+        for _ in range(2):
+            rows = lsh.embed_item_ids_multi([t.clone() for t in items], model)
+            urows = lsh.embed_user_ids_multi([t.clone() for t in users], model)
+            for k in range(K):
+                assert bits_equal(rows[k].cpu().numpy(), lsh.embed_item_ids(items[k].clone(), model).cpu().numpy())
+                assert bits_equal(urows[k].cpu().numpy(), lsh.embed_user_ids(users[k].clone(), model).cpu().numpy())
+            inters = [{"user_id": users[k], "item_id": items[k]} for k in range(K)]
+            multi = model.predict_multi(inters)
+            for k in range(K):
+                assert bits_equal(multi[k].cpu().numpy(), model.predict(inters[k]).cpu().numpy()), f"batch {k}"
+            model.item_oov_buckets.weight.mul_(1.5)  # an optimizer step (in place, under no_grad): the prepared table
+            model.user_oov_buckets.weight.add_(0.25)  # must be re-made -- torch's version counter tells
+        # batches of different sizes (or a single one) take the per-batch path
+        odd = [{"user_id": users[0][:100], "item_id": items[0][:100]}, inters[1]]
+        got = model.predict_multi(odd)
+        assert bits_equal(got[0].cpu().numpy(), model.predict(odd[0]).cpu().numpy())
+    import copy
+    twin = copy.deepcopy(model)  # get_flops deep-copies the model: prepared tables are not carried over
+    assert "_lsh_tables" not in twin.inductive_embedder.__dict__
+    with torch.no_grad():
+        assert bits_equal(twin.predict(inters[0]).cpu().numpy(), model.predict(inters[0]).cpu().numpy())
+
+
+def test_driver_evaluate_queues_its_batches(mi, dev):
+    """driver.evaluate scores consecutive eval batches as one model.predict call (up to eval_rows_per_launch rows): the
+    metrics equal those of one call per 'eval_batch_size' batch (the reference's loop), the sampled negatives are the
+    same, and a whole evaluation makes ONE device -> host copy before its first launch."""
+    from mi_oov import driver
+    model, lsh, tot_u, tot_i = _synthetic_bpr(mi, dev, H=8)
+    g = torch.Generator(device=dev).manual_seed(5)
+    n_inter = 3000
+    users = torch.randint(1, tot_u, (n_inter,), generator=g, device=dev)
+    items = torch.randint(1, tot_i, (n_inter,), generator=g, device=dev)
+    base = dict(driver.DEFAULTS, eval_batch_size=5000, eval_negatives=20, metrics=None)
+    res = {}
+    for name, rows_per_launch in (("per_batch", 1), ("queued", 1 << 22), ("pairs", 10000)):
+        cfg = driver.Config(dict(base, eval_rows_per_launch=rows_per_launch))
+        calls = []
+        orig = model.predict
+        model.predict = lambda inter, _o=orig: (calls.append(int(inter["user_id"].numel())), _o(inter))[1]
+        try:
+            res[name] = (driver.evaluate(model, users, items, tot_i, cfg, model.n_users, model.n_items, dev,
+                                         torch.Generator(device=dev).manual_seed(9)), calls)
+        finally:
+            model.predict = orig
+    assert res["per_batch"][0] == res["queued"][0] == res["pairs"][0]
+    assert len(res["queued"][1]) == 1 and sum(res["queued"][1]) == n_inter * 21
+    assert len(res["per_batch"][1]) > 5 and max(res["per_batch"][1]) <= 5000
+    assert len(res["pairs"][1]) < len(res["per_batch"][1])
+    assert "overall" in res["queued"][0] and "new_users" in res["queued"][0]

@@ -5,6 +5,10 @@
 // `distinct` id batches exist in all (>= K); launch i takes batches [i*K, i*K+K) modulo that, so that a row of the
 // table gathered by one launch is not found in the Infinity Cache by a later one (512 batches = 8.6 GB of rows).
 // The library is dlopen'ed so that variants built with different knobs can be compared in one GPU session.
+// Environment: MB_MODE = score (default) | rows | lookup_score | lookup_rows selects which of the four per-batch calls is
+// queued (mi_oov_lsh_multi; the single launches it is compared with are mi_oov_lsh_embed_score / _embed / _lookup_score /
+// _lookup; lookups take the first half of the table as the in-vocabulary table); MB_PREP=1 hands the launches a
+// prepared table of aggregates (mi_oov_lsh_table_prepare).
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -29,6 +33,15 @@ typedef int (*multi_fn)(const int64_t* const*, const float* const*, float* const
                         int64_t, const float*, int64_t, const float*, int64_t, void*);
 typedef int (*single_fn)(const int64_t*, int64_t, const float*, int64_t, int64_t, const float*, int64_t, const float*,
                          int64_t, const float*, float*, float*, void*);
+typedef int (*multi2_fn)(int, const int64_t* const*, const float* const*, void* const*, int64_t, int64_t, const float*, int64_t,
+                         const float*, int64_t, int64_t, const float*, int64_t, const float*, int64_t, const float*, void*);
+typedef int (*embed_fn)(const int64_t*, int64_t, const float*, int64_t, int64_t, const float*, int64_t, const float*, int64_t,
+                        float*, uint8_t*, void*);
+typedef int (*lookup_fn)(const int64_t*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, const float*, int64_t,
+                         const float*, int64_t, float*, void*);
+typedef int (*lookup_score_fn)(const int64_t*, int64_t, const float*, int64_t, const float*, int64_t, int64_t, const float*,
+                               int64_t, const float*, int64_t, const float*, float*, float*, void*);
+typedef int (*prep_fn)(const float*, int64_t, int64_t, float*, void*);
 
 __device__ inline uint64_t mix(uint64_t x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
@@ -59,6 +72,16 @@ int main(int argc, char** argv) {
   multi_fn multi = (multi_fn)dlsym(lib, "mi_oov_lsh_embed_score_multi");
   single_fn single = (single_fn)dlsym(lib, "mi_oov_lsh_embed_score");
   if (!multi || !single) { printf("missing symbol\n"); return 2; }
+  multi2_fn multi2 = (multi2_fn)dlsym(lib, "mi_oov_lsh_multi");
+  embed_fn embed1 = (embed_fn)dlsym(lib, "mi_oov_lsh_embed");
+  lookup_fn lookup1 = (lookup_fn)dlsym(lib, "mi_oov_lsh_lookup");
+  lookup_score_fn lookup_score1 = (lookup_score_fn)dlsym(lib, "mi_oov_lsh_lookup_score");
+  prep_fn prep = (prep_fn)dlsym(lib, "mi_oov_lsh_table_prepare");
+  const char* mode_s = getenv("MB_MODE") ? getenv("MB_MODE") : "score";
+  const bool rows = !strcmp(mode_s, "rows") || !strcmp(mode_s, "lookup_rows");
+  const bool lookup = !strncmp(mode_s, "lookup", 6);
+  const bool want_prep = getenv("MB_PREP") && atoi(getenv("MB_PREP"));
+  if ((rows || lookup || want_prep) && (!multi2 || !prep)) { printf("library has no mi_oov_lsh_multi\n"); return 2; }
 
   const int64_t R = std::max<int64_t>(1, (ring_mib << 20) / (B * 256));
   float *feat, *planes, *buckets, *users, *sc_m, *sc_s;
@@ -68,22 +91,26 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&buckets, H * 256 + 4096 * 4 * 8));  // + room for a stamps build's per-wave timestamps
   CK(hipMalloc(&users, (size_t)R * B * 256));
   CK(hipMalloc(&ids, (size_t)T * B * 8));
-  CK(hipMalloc(&sc_m, (size_t)T * B * 4));
-  CK(hipMalloc(&sc_s, (size_t)K * B * 4));
+  const size_t osz = rows ? 256 : 4;  // bytes of output per lookup
+  const int64_t OR = rows ? std::max<int64_t>(K, R) : T;  // output buffers of the queued launches (rows: a ring)
+  CK(hipMalloc(&sc_m, (size_t)OR * B * osz));
+  CK(hipMalloc(&sc_s, (size_t)K * B * osz));
+  float* tabp = nullptr;
+  CK(hipMalloc(&tabp, 256 * 256));
   fill_f32<<<4096, 256>>>(feat, (size_t)N * 64, 1);
   fill_f32<<<64, 256>>>(planes, H * 64, 2);
   fill_f32<<<64, 256>>>(buckets, H * 64, 3);
   fill_f32<<<4096, 256>>>(users, (size_t)R * B * 64, 4);
   fill_ids<<<4096, 256>>>(ids, (size_t)T * B, 5, N);
-  CK(hipMemset(sc_m, 0xFF, (size_t)T * B * 4));
-  CK(hipMemset(sc_s, 0xEE, (size_t)K * B * 4));
+  CK(hipMemset(sc_m, 0xFF, (size_t)OR * B * osz));
+  CK(hipMemset(sc_s, 0xEE, (size_t)K * B * osz));
   std::vector<const int64_t*> h_ids(T);
   std::vector<const float*> h_oth(T);
   std::vector<float*> h_sc(T);
   for (int64_t k = 0; k < T; ++k) {
     h_ids[k] = ids + k * B;
     h_oth[k] = users + (k % R) * B * 64;
-    h_sc[k] = sc_m + k * B;
+    h_sc[k] = reinterpret_cast<float*>(reinterpret_cast<char*>(sc_m) + (size_t)(k % OR) * B * osz);
   }
   const int64_t** d_ids; const float** d_oth; float** d_sc;
   CK(hipMalloc(&d_ids, T * 8)); CK(hipMalloc(&d_oth, T * 8)); CK(hipMalloc(&d_sc, T * 8));
@@ -96,15 +123,28 @@ int main(int argc, char** argv) {
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   CK(hipDeviceSynchronize());
 
+  const float* vtab = lookup ? feat : nullptr;
+  const int64_t nvoc = lookup ? N / 2 : 0;
+  if (want_prep) {
+    int rc = prep(buckets, H, 64, tabp, st);
+    if (rc) { printf("prepare rc=%d\n", rc); return 1; }
+  }
+  printf("mode %s%s\n", mode_s, want_prep ? ", prepared table" : "");
   int64_t cursor = 0;
   auto run_multi = [&]() {
-    int rc = multi(d_ids + cursor, d_oth + cursor, d_sc + cursor, K, B, feat, N, 64, planes, H, buckets, 64, st);
+    int rc = multi2 ? multi2(rows ? 1 : 0, d_ids + cursor, rows ? nullptr : d_oth + cursor, (void* const*)(d_sc + cursor), K, B, vtab, nvoc,
+                             feat, N, 64, planes, H, buckets, 64, want_prep ? tabp : nullptr, st)
+                    : multi(d_ids + cursor, d_oth + cursor, d_sc + cursor, K, B, feat, N, 64, planes, H, buckets, 64, st);
     cursor = (cursor + K) % T;
     if (rc) { printf("multi rc=%d\n", rc); exit(1); }
   };
   auto run_single = [&]() {
     for (int64_t k = 0; k < K; ++k) {
-      int rc = single(h_ids[k], B, feat, N, 64, planes, H, buckets, 64, h_oth[k], sc_s + k * B, nullptr, st);
+      float* o = reinterpret_cast<float*>(reinterpret_cast<char*>(sc_s) + (size_t)k * B * osz);
+      int rc = rows ? (lookup ? lookup1(h_ids[k], B, vtab, nvoc, feat, N, 64, planes, H, buckets, 64, o, st)
+                              : embed1(h_ids[k], B, feat, N, 64, planes, H, buckets, 64, o, nullptr, st))
+                    : (lookup ? lookup_score1(h_ids[k], B, vtab, nvoc, feat, N, 64, planes, H, buckets, 64, h_oth[k], o, nullptr, st)
+                              : single(h_ids[k], B, feat, N, 64, planes, H, buckets, 64, h_oth[k], o, nullptr, st));
       if (rc) { printf("single rc=%d\n", rc); exit(1); }
     }
   };
@@ -113,7 +153,7 @@ int main(int argc, char** argv) {
   run_single();
   CK(hipStreamSynchronize(st));
   {
-    std::vector<uint32_t> a((size_t)K * B), b((size_t)K * B);
+    std::vector<uint32_t> a((size_t)K * B * (osz / 4)), b((size_t)K * B * (osz / 4));
     CK(hipMemcpy(a.data(), sc_m, a.size() * 4, hipMemcpyDeviceToHost));
     CK(hipMemcpy(b.data(), sc_s, b.size() * 4, hipMemcpyDeviceToHost));
     size_t bad = 0, nan = 0;
@@ -123,13 +163,13 @@ int main(int argc, char** argv) {
       if (na && nb) continue;
       if (a[i] != b[i]) { if (bad < 5) printf("  mismatch at %zu: %08x vs %08x\n", i, a[i], b[i]); ++bad; }
     }
-    printf("check: %zu scores, %zu NaN (all-zero codes), %zu mismatches vs single-batch launches\n", a.size(), nan, bad);
+    printf("check: %zu values, %zu NaN (all-zero codes), %zu mismatches vs single-batch launches\n", a.size(), nan, bad);
     if (bad) return 1;
   }
   // clock ramp
   for (int i = 0; i < 30; ++i) run_multi();
   CK(hipStreamSynchronize(st));
-  const double bytes = 532.0 * B;
+  const double bytes = (rows ? 520.0 : 532.0) * B;
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipEventRecord(e0, st));
     for (int i = 0; i < L; ++i) run_multi();
@@ -138,8 +178,8 @@ int main(int argc, char** argv) {
     float ms;
     CK(hipEventElapsedTime(&ms, e0, e1));
     const double us = ms * 1e3 / (L * K);
-    printf("multi : K=%lld x %d launches: %.3f us per batch, %.2f TB/s (532 B/lookup), frac %.3f\n", (long long)K, L, us,
-           bytes / us * 1e-6, bytes / us * 1e-6 / 8.0);
+    printf("multi : K=%lld x %d launches: %.3f us per batch, %.2f TB/s (%d B/lookup), frac %.3f\n", (long long)K, L, us,
+           bytes / us * 1e-6, rows ? 520 : 532, bytes / us * 1e-6 / 8.0);
   }
   if (getenv("MB_ISOLATED")) {  // every launch on its own, the stream drained (and the host asleep) before it
     std::vector<float> t;
