@@ -46,6 +46,9 @@ _SIGNATURES = {
     "mi_oov_lsh_table_prepare": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "mi_oov_lsh_multi": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64,
                                         _vp, _vp]),
+    "mi_oov_gather_rows_multi": (ctypes.c_int, [_vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "mi_oov_gather_mean_multi": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "mi_oov_slsh_embed_multi": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "mi_oov_bucket_by_owner": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_codes_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_lookup": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),

@@ -5,23 +5,45 @@
 //   col_mean       MeanEmbedder cached mean                 mean_embedder.py:54-56,76-78
 //   broadcast_rows mean.repeat(B,1) / zeros(D).repeat(B,1)  mean_embedder.py:56,78; zero_embedder.py:36-60
 //   rowdot         BPR.predict                              bpr.py:145-149
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace mi_oov {
 
+// Rows written once and not read by the launch that writes them leave with NON-TEMPORAL stores: kept out of L2 /
+// Infinity Cache they leave those to the gathers (lsh rows, same shape of traffic: 9.8 -> 8.2 us per 65536 lookups;
+// a consumer that reads the rows right away pays ~1 us of that back: tools/pair_time.py).
+typedef float v4f_nt __attribute__((ext_vector_type(4)));
+template <bool VEC>
+__device__ __forceinline__ void store4_stream(float* row, int64_t e, int64_t L, float4 v) {
+  if constexpr (VEC) {
+    if (e < L) __builtin_nontemporal_store(v4f_nt{v.x, v.y, v.z, v.w}, reinterpret_cast<v4f_nt*>(row + e));
+  } else {
+    store4_guard(row, e, L, v);
+  }
+}
+
 // One 16-lane group per output row, R rows in flight per group.
-template <bool VEC, int MODE>  // MODE 0: gather_rows, 1: splice_rows
-__global__ __launch_bounds__(kBlock) void row_copy_kernel(const int64_t* __restrict__ ids,
+// TAB (gather only): ids_src / out_src are DEVICE arrays of K pointers, one per queued batch of B rows each
+// (mi_oov_gather_rows_multi); tile t of the launch belongs to batch t / tiles_per_batch.
+template <bool VEC, int MODE, bool TAB = false>  // MODE 0: gather_rows, 1: splice_rows
+__global__ __launch_bounds__(kBlock) void row_copy_kernel(const void* __restrict__ ids_src,
                                                           const int64_t* __restrict__ rank, int64_t B,
                                                           const float* __restrict__ W, int64_t N,
                                                           const float* __restrict__ oov_rows, int64_t n_oov,
-                                                          int64_t D, float* __restrict__ out) {
+                                                          int64_t D, void* __restrict__ out_src, int64_t K) {
   constexpr int R = 4;
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
-  const int64_t ntiles = (B + 4 * R - 1) / (4 * R);
+  const int64_t tpb = (B + 4 * R - 1) / (4 * R);
+  const int64_t ntiles = tpb * (TAB ? K : 1);
   const int dchunks = static_cast<int>((D + 63) / 64);
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
-       tile += static_cast<int64_t>(gridDim.x) * 4) {
+  for (int64_t gtile = static_cast<int64_t>(blockIdx.x) * 4 + wv; gtile < ntiles;
+       gtile += static_cast<int64_t>(gridDim.x) * 4) {
+    const int64_t batch = TAB ? gtile / tpb : 0;
+    const int64_t tile = TAB ? gtile - batch * tpb : gtile;
+    const int64_t* ids = TAB ? reinterpret_cast<const int64_t* const*>(ids_src)[batch] : static_cast<const int64_t*>(ids_src);
+    float* out = TAB ? reinterpret_cast<float* const*>(out_src)[batch] : static_cast<float*>(out_src);
     const float* src[R];
     int64_t row[R];
     bool live[R];
@@ -48,41 +70,87 @@ __global__ __launch_bounds__(kBlock) void row_copy_kernel(const int64_t* __restr
         v[r] = src[r] ? load4<VEC>(src[r], e, D) : make_float4(qnan(), qnan(), qnan(), qnan());
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        if (live[r]) store4<VEC>(out + row[r] * D, e, D, v[r]);
+        if (live[r]) store4_stream<VEC>(out + row[r] * D, e, D, v[r]);
     }
   }
 }
 
 // out[o,:] = mean_{t in [o*g, min(M,(o+1)*g))} W[idx[t],:], summed in increasing t.
-template <bool VEC>
-__global__ __launch_bounds__(kBlock) void gather_mean_kernel(const int64_t* __restrict__ idx, int64_t M, int64_t g,
+// G2: the reference's g = 2 (knn_embedder.py:126,147) with both rows of an output, and the pairs of FOUR outputs per
+// 16-lane group, requested together (8 gathers in flight per lane instead of one at a time) -- same sums, same order.
+// TAB: idx_src / out_src are DEVICE arrays of K pointers, one per queued batch of M indices (mi_oov_gather_mean_multi).
+template <bool VEC, bool G2, bool TAB = false>
+__global__ __launch_bounds__(kBlock) void gather_mean_kernel(const void* __restrict__ idx_src, int64_t M, int64_t g,
                                                              const float* __restrict__ W, int64_t N, int64_t D,
-                                                             float* __restrict__ out) {
+                                                             void* __restrict__ out_src, int64_t K) {
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
   const int64_t nout = (M + g - 1) / g;
-  const int64_t ntiles = (nout + 3) / 4;
+  constexpr int R = G2 ? 4 : 1;  // outputs per 16-lane group and tile
+  const int64_t tpb = (nout + 4 * R - 1) / (4 * R);
+  const int64_t ntiles = tpb * (TAB ? K : 1);
   const int dchunks = static_cast<int>((D + 63) / 64);
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
-       tile += static_cast<int64_t>(gridDim.x) * 4) {
-    const int64_t o = tile * 4 + grp;
-    if (o >= nout) continue;
-    const int64_t t0 = o * g;
-    const int64_t t1 = (t0 + g < M) ? t0 + g : M;
-    const float inv_n = static_cast<float>(t1 - t0);
-    for (int c = 0; c < dchunks; ++c) {
-      const int e = (c * 16 + l16) * 4;
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-      bool ok = true;
-      for (int64_t t = t0; t < t1; ++t) {
-        const int64_t id = idx[t];
-        const bool in = static_cast<uint64_t>(id) < static_cast<uint64_t>(N);
-        ok = ok && in;
-        const float4 v = in ? load4<VEC>(W + id * D, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
-        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  for (int64_t gtile = static_cast<int64_t>(blockIdx.x) * 4 + wv; gtile < ntiles;
+       gtile += static_cast<int64_t>(gridDim.x) * 4) {
+    const int64_t batch = TAB ? gtile / tpb : 0;
+    const int64_t tile = TAB ? gtile - batch * tpb : gtile;
+    const int64_t* idx = TAB ? reinterpret_cast<const int64_t* const*>(idx_src)[batch] : static_cast<const int64_t*>(idx_src);
+    float* out = TAB ? reinterpret_cast<float* const*>(out_src)[batch] : static_cast<float*>(out_src);
+    if constexpr (G2) {
+      int64_t o[R], ia[R], ib[R];
+      bool live[R], two[R];
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        o[r] = tile * (4 * R) + r * 4 + grp;
+        live[r] = o[r] < nout;
+        two[r] = live[r] && 2 * o[r] + 1 < M;  // (the last group of an odd M holds one row: averaged over its own length)
+        ia[r] = live[r] ? idx[2 * o[r]] : 0;
+        ib[r] = two[r] ? idx[2 * o[r] + 1] : 0;
       }
-      acc.x /= inv_n; acc.y /= inv_n; acc.z /= inv_n; acc.w /= inv_n;
-      if (!ok) acc = make_float4(qnan(), qnan(), qnan(), qnan());
-      store4<VEC>(out + o * D, e, D, acc);
+      for (int c = 0; c < dchunks; ++c) {
+        const int e = (c * 16 + l16) * 4;
+        float4 va[R], vb[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const bool ina = static_cast<uint64_t>(ia[r]) < static_cast<uint64_t>(N);
+          const bool inb = static_cast<uint64_t>(ib[r]) < static_cast<uint64_t>(N);
+          va[r] = (live[r] && ina) ? load4<VEC>(W + ia[r] * D, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
+          vb[r] = (two[r] && inb) ? load4<VEC>(W + ib[r] * D, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if (!live[r]) continue;
+          const bool ok = static_cast<uint64_t>(ia[r]) < static_cast<uint64_t>(N) &&
+                          (!two[r] || static_cast<uint64_t>(ib[r]) < static_cast<uint64_t>(N));
+          float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+          acc.x += va[r].x; acc.y += va[r].y; acc.z += va[r].z; acc.w += va[r].w;
+          if (two[r]) { acc.x += vb[r].x; acc.y += vb[r].y; acc.z += vb[r].z; acc.w += vb[r].w; }
+          const float n = two[r] ? 2.f : 1.f;
+          acc.x /= n; acc.y /= n; acc.z /= n; acc.w /= n;
+          if (!ok) acc = make_float4(qnan(), qnan(), qnan(), qnan());
+          store4_stream<VEC>(out + o[r] * D, e, D, acc);
+        }
+      }
+    } else {
+      const int64_t o = tile * 4 + grp;
+      if (o >= nout) continue;
+      const int64_t t0 = o * g;
+      const int64_t t1 = (t0 + g < M) ? t0 + g : M;
+      const float inv_n = static_cast<float>(t1 - t0);
+      for (int c = 0; c < dchunks; ++c) {
+        const int e = (c * 16 + l16) * 4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        bool ok = true;
+        for (int64_t t = t0; t < t1; ++t) {
+          const int64_t id = idx[t];
+          const bool in = static_cast<uint64_t>(id) < static_cast<uint64_t>(N);
+          ok = ok && in;
+          const float4 v = in ? load4<VEC>(W + id * D, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
+          acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        acc.x /= inv_n; acc.y /= inv_n; acc.z /= inv_n; acc.w /= inv_n;
+        if (!ok) acc = make_float4(qnan(), qnan(), qnan(), qnan());
+        store4_stream<VEC>(out + o * D, e, D, acc);
+      }
     }
   }
 }
@@ -156,7 +224,7 @@ __global__ __launch_bounds__(kBlock) void broadcast_kernel(const float* __restri
     for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
          tile += static_cast<int64_t>(gridDim.x) * 4) {
       const int64_t row = tile * 4 + grp;
-      if (row < B) store4<VEC>(out + row * D, e, D, v);
+      if (row < B) store4_stream<VEC>(out + row * D, e, D, v);
     }
   }
 }
@@ -395,7 +463,7 @@ __global__ __launch_bounds__(kBlock) void token_fields_kernel(TokenArgs a) {
         v[r] = src[r] ? load4<VEC>(src[r], e, a.D) : make_float4(qnan(), qnan(), qnan(), qnan());
 #pragma unroll
       for (int r = 0; r < R; ++r)
-        if (row[r] < rows) store4<VEC>(a.out + row[r] * a.D, e, a.D, v[r]);
+        if (row[r] < rows) store4_stream<VEC>(a.out + row[r] * a.D, e, a.D, v[r]);
     }
   }
 }
@@ -554,6 +622,18 @@ extern "C" int mi_oov_token_fields_embed(const int64_t* tokens, int64_t B, int64
   return check_launch();
 }
 
+namespace mi_oov {
+int launch_gather_mean64_persistent(const int64_t* const* idx_tab, float* const* out_tab, int64_t K, int64_t M,
+                                    const float* W, int64_t N, hipStream_t st);  // lsh64p.hip
+static bool persist_movers() {
+  static const bool on = [] {
+    const char* e = getenv("MI_OOV_PERSIST_MOVERS");  // developer A/B knob: 0 = the grid-stride kernels for every width
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+}  // namespace mi_oov
+
 extern "C" int mi_oov_gather_rows(const int64_t* ids, int64_t B, const float* W, int64_t N, int64_t D, float* out,
                                   void* stream) {
   if (B < 0 || N <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
@@ -563,9 +643,25 @@ extern "C" int mi_oov_gather_rows(const int64_t* ids, int64_t B, const float* W,
   const bool vec = (D % 4 == 0) && aligned16(W) && aligned16(out);
   const int grid = grid_for(B, 64);
   if (vec)
-    hipLaunchKernelGGL((row_copy_kernel<true, 0>), dim3(grid), dim3(kBlock), 0, st, ids, nullptr, B, W, N, nullptr, 0, D, out);
+    hipLaunchKernelGGL((row_copy_kernel<true, 0>), dim3(grid), dim3(kBlock), 0, st, ids, nullptr, B, W, N, nullptr, 0, D, out, 1);
   else
-    hipLaunchKernelGGL((row_copy_kernel<false, 0>), dim3(grid), dim3(kBlock), 0, st, ids, nullptr, B, W, N, nullptr, 0, D, out);
+    hipLaunchKernelGGL((row_copy_kernel<false, 0>), dim3(grid), dim3(kBlock), 0, st, ids, nullptr, B, W, N, nullptr, 0, D, out, 1);
+  return check_launch();
+}
+
+// K queued batches of mi_oov_gather_rows in one launch (grid-stride over the tiles of all batches): ids_tab / out_tab are
+// DEVICE arrays of K device pointers (int64[B] / f32[B,D], 16-byte aligned rows), every batch B rows.
+extern "C" int mi_oov_gather_rows_multi(const int64_t* const* ids_tab, float* const* out_tab, int64_t K, int64_t B,
+                                        const float* W, int64_t N, int64_t D, void* stream) {
+  if (K < 0 || B < 0 || N <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (K == 0 || B == 0) return MI_OOV_OK;
+  if (!ids_tab || !out_tab || !W) return MI_OOV_ERR_NULL;
+  if (D % 4 != 0) return MI_OOV_ERR_SHAPE;  // rows of whole float4 (callers fall back to K single launches)
+  if (!aligned16(W) || (reinterpret_cast<uintptr_t>(ids_tab) & 7u) || (reinterpret_cast<uintptr_t>(out_tab) & 7u)) return MI_OOV_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = grid_for(K * ((B + 15) / 16) * 16, 64);
+  hipLaunchKernelGGL((row_copy_kernel<true, 0, true>), dim3(grid), dim3(kBlock), 0, st, static_cast<const void*>(ids_tab), nullptr, B, W, N,
+                     nullptr, 0, D, static_cast<void*>(const_cast<float**>(out_tab)), K);
   return check_launch();
 }
 
@@ -579,9 +675,9 @@ extern "C" int mi_oov_splice_rows(const int64_t* ids, const int64_t* oov_rank, i
   const bool vec = (D % 4 == 0) && (!table || aligned16(table)) && (!oov_rows || aligned16(oov_rows)) && aligned16(out);
   const int grid = grid_for(B, 64);
   if (vec)
-    hipLaunchKernelGGL((row_copy_kernel<true, 1>), dim3(grid), dim3(kBlock), 0, st, ids, oov_rank, B, table, n_vocab, oov_rows, n_oov, D, out);
+    hipLaunchKernelGGL((row_copy_kernel<true, 1>), dim3(grid), dim3(kBlock), 0, st, ids, oov_rank, B, table, n_vocab, oov_rows, n_oov, D, out, 1);
   else
-    hipLaunchKernelGGL((row_copy_kernel<false, 1>), dim3(grid), dim3(kBlock), 0, st, ids, oov_rank, B, table, n_vocab, oov_rows, n_oov, D, out);
+    hipLaunchKernelGGL((row_copy_kernel<false, 1>), dim3(grid), dim3(kBlock), 0, st, ids, oov_rank, B, table, n_vocab, oov_rows, n_oov, D, out, 1);
   return check_launch();
 }
 
@@ -592,11 +688,45 @@ extern "C" int mi_oov_gather_mean(const int64_t* idx, int64_t M, int64_t g, cons
   if (!idx || !W || !out) return MI_OOV_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = (D % 4 == 0) && aligned16(W) && aligned16(out);
-  const int grid = grid_for((M + g - 1) / g, 16);
+  const int64_t nout = (M + g - 1) / g;
+  if (g == 2) {  // the reference's group size: four outputs per 16-lane group, their 8 gathers in flight together
+    const int grid = grid_for(nout, 64);
+    if (vec)
+      hipLaunchKernelGGL((gather_mean_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out, 1);
+    else
+      hipLaunchKernelGGL((gather_mean_kernel<false, true>), dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out, 1);
+    return check_launch();
+  }
+  const int grid = grid_for(nout, 16);
   if (vec)
-    hipLaunchKernelGGL(gather_mean_kernel<true>, dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out);
+    hipLaunchKernelGGL((gather_mean_kernel<true, false>), dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out, 1);
   else
-    hipLaunchKernelGGL(gather_mean_kernel<false>, dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out);
+    hipLaunchKernelGGL((gather_mean_kernel<false, false>), dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out, 1);
+  return check_launch();
+}
+
+// K queued batches of mi_oov_gather_mean (every batch M indices, group size g) in one launch.
+extern "C" int mi_oov_gather_mean_multi(const int64_t* const* idx_tab, float* const* out_tab, int64_t K, int64_t M, int64_t g,
+                                        const float* W, int64_t N, int64_t D, void* stream) {
+  if (K < 0 || M < 0 || g <= 0 || N <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (K == 0 || M == 0) return MI_OOV_OK;
+  if (!idx_tab || !out_tab || !W) return MI_OOV_ERR_NULL;
+  if (D % 4 != 0) return MI_OOV_ERR_SHAPE;
+  if (!aligned16(W) || (reinterpret_cast<uintptr_t>(idx_tab) & 7u) || (reinterpret_cast<uintptr_t>(out_tab) & 7u)) return MI_OOV_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t nout = (M + g - 1) / g;
+  // 64-float rows, pairs: the software-pipelined persistent kernel of lsh64p.hip (indices two tiles ahead, rows one
+  // tile ahead: 9.0 us per 65536 outputs against 10.8 for the grid-stride kernel below)
+  if (g == 2 && D == 64 && M < (int64_t(1) << 24) && persist_movers()) return launch_gather_mean64_persistent(idx_tab, out_tab, K, M, W, N, st);
+  if (g == 2) {
+    const int grid = grid_for(K * ((nout + 15) / 16) * 16, 64);
+    hipLaunchKernelGGL((gather_mean_kernel<true, true, true>), dim3(grid), dim3(kBlock), 0, st, static_cast<const void*>(idx_tab), M, g, W, N, D,
+                       static_cast<void*>(const_cast<float**>(out_tab)), K);
+  } else {
+    const int grid = grid_for(K * ((nout + 3) / 4) * 4, 16);
+    hipLaunchKernelGGL((gather_mean_kernel<true, false, true>), dim3(grid), dim3(kBlock), 0, st, static_cast<const void*>(idx_tab), M, g, W, N, D,
+                       static_cast<void*>(const_cast<float**>(out_tab)), K);
+  }
   return check_launch();
 }
 

@@ -455,8 +455,8 @@ int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, co
                  const float* planes, int H, const float* buckets, const float* other, float* score, float* out,
                  hipStream_t st, uint8_t* bits);
 
-int launch_slsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes, int H,
-                  const float* buckets, int64_t n_buckets, int64_t D, float* out, int64_t* idx, hipStream_t st);
+int launch_slsh64(const void* ids, int64_t B, int64_t K, bool tab, const float* feat, int64_t N, const float* planes, int H,
+                  const float* buckets, int64_t n_buckets, int64_t D, void* out, void* idx, hipStream_t st);
 
 static bool lsh64_enabled() {
   static const bool on = [] {
@@ -554,7 +554,7 @@ extern "C" int mi_oov_slsh_embed(const int64_t* ids, int64_t B, const float* fea
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = (F % 4 == 0) && aligned16(feat) && (!out || (p.D % 4 == 0 && aligned16(out) && aligned16(buckets)));
   if (vec && F == 64 && H <= 32 && (!out || D == 64 || D == 128) && aligned16(planes) && lsh64_enabled())
-    return launch_slsh64(ids, B, feat, N, planes, static_cast<int>(H), buckets, n_buckets, D, out, idx, st);
+    return launch_slsh64(ids, B, 1, false, feat, N, planes, static_cast<int>(H), buckets, n_buckets, D, out, idx, st);
   const int grid = grid_for(B, 64);
   if (vec) {
     auto k = slsh_kernel<true>;
@@ -566,4 +566,22 @@ extern "C" int mi_oov_slsh_embed(const int64_t* ids, int64_t B, const float* fea
     hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p, FP);
   }
   return check_launch();
+}
+
+// K queued batches of mi_oov_slsh_embed in ONE launch (hot tile only: F == 64, H <= 32, D 64 or 128 -- other shapes
+// return MI_OOV_ERR_SHAPE and the caller issues K single launches).  ids_tab / out_tab / idx_tab: DEVICE arrays of K
+// device pointers (out_tab or idx_tab may be NULL).
+extern "C" int mi_oov_slsh_embed_multi(const int64_t* const* ids_tab, float* const* out_tab, int64_t* const* idx_tab, int64_t K,
+                                       int64_t B, const float* feat, int64_t N, int64_t F, const float* planes, int64_t H,
+                                       const float* buckets, int64_t n_buckets, int64_t D, void* stream) {
+  using namespace mi_oov;
+  if (K < 0 || B < 0 || N <= 0 || F <= 0 || H <= 0 || n_buckets <= 0) return MI_OOV_ERR_SHAPE;
+  if (K == 0 || B == 0) return MI_OOV_OK;
+  if (!ids_tab || !feat || !planes || (!out_tab && !idx_tab) || (out_tab && !buckets)) return MI_OOV_ERR_NULL;
+  if (F != 64 || H > 32 || (out_tab && D != 64 && D != 128)) return MI_OOV_ERR_SHAPE;
+  if (!aligned16(feat) || !aligned16(planes) || (out_tab && !aligned16(buckets)) || (reinterpret_cast<uintptr_t>(ids_tab) & 7u) ||
+      (reinterpret_cast<uintptr_t>(out_tab) & 7u) || (reinterpret_cast<uintptr_t>(idx_tab) & 7u))
+    return MI_OOV_ERR_ALIGN;
+  return launch_slsh64(ids_tab, B, K, true, feat, N, planes, static_cast<int>(H), buckets, n_buckets, D > 0 ? D : 64,
+                       const_cast<float**>(out_tab), const_cast<int64_t**>(idx_tab), static_cast<hipStream_t>(stream));
 }

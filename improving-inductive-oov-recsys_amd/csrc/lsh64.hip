@@ -390,34 +390,78 @@ static int launch64g(const int64_t* ids, int64_t B, const float* feat, int64_t N
 // ---- slsh on the hot tile: F = 64, up to 32 planes, D = 64 or 128 -------------------------------------------------
 // single_lsh_embedder.py:82-109: idx = (bits_req + popcount) % n_buckets, out = buckets[idx].  Same tile, same
 // bank-masked reduce as above with the planes taken eight at a time from LDS; only the per-bank bit counts are
-// kept.  Three dependent hops (ids -> feature rows -> bucket rows); the R bucket-row gathers of a tile are issued
-// together and the tile's 16 bucket ids leave in one store.
-template <int DCH>
-__global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const int64_t* __restrict__ ids, unsigned B,
+// kept.  The reference's arithmetic reaches only the H + 1 bucket rows (H + c) % n_buckets, c = 0..H, however large the
+// bucket table is (n_buckets = 8 only ever yields ids 3..6): the workgroup copies those rows into
+// LDS once (<= 33 rows, 17 KiB at D = 128) and a lookup's bucket row is a conflict-free ds_read_b128 at its count -- a
+// row is a multiple of 256 B = all 64 banks, so the bank of a read depends on the lane only -- instead of a third
+// dependent hop ids -> feature row -> bucket row through HBM (n_buckets = N: 12.95 -> see DESIGN.md section 5; the
+// rows are copies, so the output is the same bits).  The tile's 16 bucket ids leave in one store, the output rows with
+// non-temporal stores.  TAB: ids_src / out_src / idx_src are DEVICE arrays of K pointers (mi_oov_slsh_embed_multi).
+template <int DCH, bool TAB>
+__global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const void* __restrict__ ids_src, unsigned B, unsigned K,
                                                         const float* __restrict__ feat, int64_t N,
                                                         const float* __restrict__ planes, int H,
                                                         const float* __restrict__ buckets, int64_t n_buckets,
-                                                        float* __restrict__ out, int64_t* __restrict__ idx) {
+                                                        void* __restrict__ out_src, void* __restrict__ idx_src) {
   constexpr int R = 4;
+  typedef float v4f_ __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
-  const unsigned ntiles = (B + 15) / 16;
+  const unsigned tpb = (B + 15) / 16;
+  const unsigned ntiles = tpb * (TAB ? K : 1u);
   const unsigned tstep = gridDim.x * kWpb;
   const int G = (H + 7) / 8, HP = G * 8;
-  unsigned tile = blockIdx.x * kWpb + wv;
+  unsigned gtile = blockIdx.x * kWpb + wv;
+  auto ids_of = [&](unsigned t) -> const int64_t* {
+    return TAB ? reinterpret_cast<const int64_t* const*>(ids_src)[t / tpb] : static_cast<const int64_t*>(ids_src);
+  };
   int64_t idc[4];
-  load_tile_ids(ids, tile, B, l16, grp, idc);
+  if (gtile < ntiles) load_tile_ids(ids_of(gtile), TAB ? gtile % tpb : gtile, B, l16, grp, idc);
 
-  extern __shared__ __attribute__((aligned(16))) float sw[];  // [HP][64], rows >= H zero
-  for (int i = threadIdx.x; i < HP * 16; i += kBlk)
-    *reinterpret_cast<float4*>(sw + i * 4) = (i / 16 < H) ? *reinterpret_cast<const float4*>(planes + i * 4)
-                                                          : make_float4(0.f, 0.f, 0.f, 0.f);
+  extern __shared__ __attribute__((aligned(16))) float sw[];  // [HP][64] planes (rows >= H zero), [H + 1][64 DCH] reachable bucket rows
+  float* srows = sw + HP * 64;
+  const bool want_rows = out_src != nullptr;
+  {
+    // every staging load first, then the LDS stores: one memory round trip in front of the barrier, not two
+    constexpr int kPl = (32 * 16 + kBlk - 1) / kBlk, kRw = (33 * 16 * DCH + kBlk - 1) / kBlk;
+    float4 pv[kPl], rv[kRw];
+#pragma unroll
+    for (int q = 0; q < kPl; ++q) {
+      const int i = q * kBlk + static_cast<int>(threadIdx.x);
+      pv[q] = (i < H * 16) ? *reinterpret_cast<const float4*>(planes + i * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < kRw; ++q) {
+      const int i = q * kBlk + static_cast<int>(threadIdx.x);
+      rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (want_rows && i < (H + 1) * 16 * DCH) {
+        const int c = i / (16 * DCH), e = i - c * (16 * DCH);
+        const int64_t v = H + c;
+        const int64_t b = v < n_buckets ? v : static_cast<int64_t>(static_cast<uint32_t>(v) % static_cast<uint32_t>(n_buckets));
+        rv[q] = *reinterpret_cast<const float4*>(buckets + b * (64 * DCH) + e * 4);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < kPl; ++q) {
+      const int i = q * kBlk + static_cast<int>(threadIdx.x);
+      if (i < HP * 16) *reinterpret_cast<float4*>(sw + i * 4) = pv[q];
+    }
+#pragma unroll
+    for (int q = 0; q < kRw; ++q) {
+      const int i = q * kBlk + static_cast<int>(threadIdx.x);
+      if (want_rows && i < (H + 1) * 16 * DCH) *reinterpret_cast<float4*>(srows + i * 4) = rv[q];
+    }
+  }
   __syncthreads();
   const int bank = l16 >> 2;
   const int pl = ((bank & 1) << 1) | (bank >> 1);
   const int hl = H - (G - 1) * 8;
   const float last0 = (pl < hl) ? 1.f : 0.f, last1 = (4 + pl < hl) ? 1.f : 0.f;
 
-  while (tile < ntiles) {
+  while (gtile < ntiles) {
+    const unsigned batch = TAB ? gtile / tpb : 0u;
+    const unsigned tile = TAB ? gtile - batch * tpb : gtile;
+    float* out = want_rows ? (TAB ? reinterpret_cast<float* const*>(out_src)[batch] : static_cast<float*>(out_src)) : nullptr;
+    int64_t* idx = idx_src ? (TAB ? reinterpret_cast<int64_t* const*>(idx_src)[batch] : static_cast<int64_t*>(idx_src)) : nullptr;
     unsigned row[R];
     bool valid[R];
     float4 x[R];
@@ -429,6 +473,10 @@ __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const int64_t* __restri
       x[r] = *reinterpret_cast<const float4*>(feat + (valid[r] ? idc[r] : 0) * 64 + l16 * 4);
       cnt[r] = 0.f;
     }
+    // the ids of the wave's next tile go out behind this tile's gathers (they are needed one tile from now)
+    const unsigned gnext = gtile + tstep;
+    int64_t idn[4] = {0, 0, 0, 0};
+    if (gnext < ntiles) load_tile_ids(ids_of(gnext), TAB ? gnext % tpb : gnext, B, l16, grp, idn);
     for (int g = 0; g < G; ++g) {
       float4 pw[8];
 #pragma unroll
@@ -446,30 +494,28 @@ __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const int64_t* __restri
     }
     // (2 ** bits).sum(1) = one or two per plane = H + popcount (single_lsh_embedder.py:86)
     int64_t bkt[R];
+    int pc[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       float c = cnt[r];
       c = c + dpp_f32<0x124>(c);
       c = c + dpp_f32<0x128>(c);
-      const int64_t v = H + static_cast<int>(c);  // <= 64
+      pc[r] = static_cast<int>(c);  // 0..H
+      const int64_t v = H + pc[r];  // <= 64
       bkt[r] = valid[r] ? (v < n_buckets ? v : static_cast<int64_t>(static_cast<uint32_t>(v) % static_cast<uint32_t>(n_buckets)))
                         : -1;
     }
     const bool full = tile * 16 + 16 <= B;
     if (out) {
-      float4 v[R][DCH];
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-#pragma unroll
-        for (int c = 0; c < DCH; ++c)
-          v[r][c] = *reinterpret_cast<const float4*>(buckets + (valid[r] ? bkt[r] : 0) * (64 * DCH) + c * 64 + l16 * 4);
 #pragma unroll
       for (int r = 0; r < R; ++r)
 #pragma unroll
         for (int c = 0; c < DCH; ++c) {
-          if (!valid[r]) v[r][c] = make_float4(qnan(), qnan(), qnan(), qnan());
+          float4 v = *reinterpret_cast<const float4*>(srows + ((pc[r] * DCH + c) * 16 + l16) * 4);
+          if (!valid[r]) v = make_float4(qnan(), qnan(), qnan(), qnan());
           if (row[r] < B)
-            *reinterpret_cast<float4*>(out + static_cast<size_t>(row[r]) * (64 * DCH) + c * 64 + l16 * 4) = v[r][c];
+            __builtin_nontemporal_store(v4f_{v.x, v.y, v.z, v.w},
+                                        reinterpret_cast<v4f_*>(out + static_cast<size_t>(row[r]) * (64 * DCH) + c * 64 + l16 * 4));
         }
     }
     if (idx) {
@@ -485,26 +531,43 @@ __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const int64_t* __restri
           if (l16 == 0 && row[r] < B) idx[row[r]] = bkt[r];
       }
     }
-    tile += tstep;
-    if (tile < ntiles) load_tile_ids(ids, tile, B, l16, grp, idc);
+    gtile = gnext;
+#pragma unroll
+    for (int r = 0; r < R; ++r) idc[r] = idn[r];
   }
 }
 
-// Host entry used by mi_oov_slsh_embed (lsh.hip) when F = 64, H <= 32 and D is 64 or 128 (or no rows are wanted).
-int launch_slsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, const float* planes, int H,
-                  const float* buckets, int64_t n_buckets, int64_t D, float* out, int64_t* idx, hipStream_t st) {
+// Host entry used by mi_oov_slsh_embed / mi_oov_slsh_embed_multi (lsh.hip) when F = 64, H <= 32 and D is 64 or 128 (or no
+// rows are wanted).  tab: ids / out / idx are device arrays of K pointers.
+int launch_slsh64(const void* ids, int64_t B, int64_t K, bool tab, const float* feat, int64_t N, const float* planes, int H,
+                  const float* buckets, int64_t n_buckets, int64_t D, void* out, void* idx, hipStream_t st) {
   constexpr int64_t kMaxRows = int64_t(1) << 22;  // 32-bit row arithmetic inside the kernel
   const int HP = (H + 7) / 8 * 8;
+  const int dch = (out && D == 128) ? 2 : 1;
+  const size_t lds = (static_cast<size_t>(HP) * 64 + (out ? static_cast<size_t>(H + 1) * 64 * dch : 0)) * sizeof(float);
+  if (tab) {
+    if (B > kMaxRows || K * ((B + 15) / 16) >= (int64_t(1) << 31)) return MI_OOV_ERR_SHAPE;
+    const int grid = grid_for(K * ((B + 15) / 16) * 16, 16 * kWpb);
+    if (dch == 2)
+      hipLaunchKernelGGL((slsh64_kernel<2, true>), dim3(grid), dim3(kBlk), lds, st, ids, static_cast<unsigned>(B), static_cast<unsigned>(K),
+                         feat, N, planes, H, buckets, n_buckets, out, idx);
+    else
+      hipLaunchKernelGGL((slsh64_kernel<1, true>), dim3(grid), dim3(kBlk), lds, st, ids, static_cast<unsigned>(B), static_cast<unsigned>(K),
+                         feat, N, planes, H, buckets, n_buckets, out, idx);
+    return check_launch();
+  }
   for (int64_t b0 = 0; b0 < B; b0 += kMaxRows) {
     const int64_t nb = (B - b0 < kMaxRows) ? B - b0 : kMaxRows;
     const int grid = grid_for(nb, 16 * kWpb);
-    if (out && D == 128)
-      hipLaunchKernelGGL((slsh64_kernel<2>), dim3(grid), dim3(kBlk), HP * 64 * sizeof(float), st, ids + b0,
-                         static_cast<unsigned>(nb), feat, N, planes, H, buckets, n_buckets, out + b0 * D, idx ? idx + b0 : nullptr);
+    const void* ids_b = static_cast<const int64_t*>(ids) + b0;
+    void* out_b = out ? static_cast<void*>(static_cast<float*>(out) + b0 * D) : nullptr;
+    void* idx_b = idx ? static_cast<void*>(static_cast<int64_t*>(idx) + b0) : nullptr;
+    if (dch == 2)
+      hipLaunchKernelGGL((slsh64_kernel<2, false>), dim3(grid), dim3(kBlk), lds, st, ids_b, static_cast<unsigned>(nb), 1u, feat, N, planes, H,
+                         buckets, n_buckets, out_b, idx_b);
     else
-      hipLaunchKernelGGL((slsh64_kernel<1>), dim3(grid), dim3(kBlk), HP * 64 * sizeof(float), st, ids + b0,
-                         static_cast<unsigned>(nb), feat, N, planes, H, buckets, n_buckets, out ? out + b0 * D : nullptr,
-                         idx ? idx + b0 : nullptr);
+      hipLaunchKernelGGL((slsh64_kernel<1, false>), dim3(grid), dim3(kBlk), lds, st, ids_b, static_cast<unsigned>(nb), 1u, feat, N, planes, H,
+                         buckets, n_buckets, out_b, idx_b);
     if (int rc = check_launch()) return rc;
   }
   return MI_OOV_OK;
@@ -550,13 +613,13 @@ int launch_lsh64_persistent_single(const int64_t* ids, int64_t B, const float* f
                                    int64_t n_vocab, const float* planes, int H, const float* buckets, const float* other,
                                    float* score, float* out, hipStream_t st);  // lsh64p.hip
 constexpr int64_t kCodesMinB = 262144;
-// One batch of scores or rows from this many lookups on: the persistent, software-pipelined kernel (a wave then walks
-// several tile pairs; below, the one-tile-per-wave launch of this file is faster).  MI_OOV_PERSIST_MIN_B: developer knob.
+// One batch of scores from this many lookups on: the persistent, software-pipelined kernel (a wave then walks several
+// tile pairs; below, the one-tile-per-wave launch of this file is faster).  MI_OOV_PERSIST_MIN_B: developer knob.
 static int64_t persist_min_b() {
   static const int64_t v = [] {
     const char* e = getenv("MI_OOV_PERSIST_MIN_B");
     const int64_t x = e ? atoll(e) : 0;
-    return x > 0 ? x : int64_t(262144);
+    return x > 0 ? x : int64_t(524288);
   }();
   return v;
 }
@@ -594,7 +657,10 @@ int launch_lsh64(const int64_t* ids, int64_t B, const float* feat, int64_t N, co
     if (out) return launch64<8, false, true, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);
     return launch64<8, false, false, false, true>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st, bits);
   }
-  if (B >= persist_min_b() && !(score && out)) return launch_lsh64_persistent_single(ids, B, feat, N, vtable, n_vocab, planes, H, buckets, other, score, out, st);
+  // one large batch of SCORES: the persistent kernel from kPersistMinB lookups on (524288: 49.3 vs 52.0 us, 4 M: 352 vs
+  // 401 us).  Rows: the grid-stride launch below keeps pace with it at every size (4 M rows: 391 vs 392 us) and stays.
+  if (score && !out && B >= persist_min_b())
+    return launch_lsh64_persistent_single(ids, B, feat, N, vtable, n_vocab, planes, H, buckets, other, score, out, st);
   switch (H) {
 #define MI_CASE(HV) \
   case HV: return launch64_h<HV>(ids, B, feat, N, vtable, n_vocab, planes, buckets, other, score, out, st);

@@ -78,6 +78,12 @@ namespace mi_oov {
 #ifndef MI_PNT_U
 #define MI_PNT_U 1
 #endif
+#ifndef MI_PROWS_WAIT
+#define MI_PROWS_WAIT 1  // rows / mean modes: s_waitcnt vmcnt(n) in front of each reduction, 0 = none (see step_pair)
+#endif
+#ifndef MI_PSCORE_WAIT
+#define MI_PSCORE_WAIT 0
+#endif
 #ifndef MI_PROWS_WG
 #define MI_PROWS_WG 1
 #endif
@@ -85,7 +91,7 @@ namespace mi_oov {
 #define MI_PNT_O 1  // non-temporal stores for the rows of the rows mode
 #endif
 constexpr int kPWpb = MI_PWPB, kPBlk = 64 * kPWpb;
-constexpr int kModeScore = 0, kModeCodes = 1, kModeFromCodes = 2, kModeRows = 3;
+constexpr int kModeScore = 0, kModeCodes = 1, kModeFromCodes = 2, kModeRows = 3, kModeMean = 4;
 
 typedef const int64_t __attribute__((address_space(1))) * gptr_i64;
 typedef float __attribute__((address_space(1))) * gptr_f32;
@@ -167,6 +173,12 @@ __device__ __forceinline__ void build_code_table(const float* sbuckets, Dst dst,
   }
 }
 
+// where the empty result that primes a wave's pipeline is "stored" (16 rows of 64 floats at most; contents never read).
+// One sink per wave slot of the resident grid: 2048 waves writing the SAME 4 KiB at the start of every launch are a hot
+// spot in one memory channel (rows mode, K = 64: 5.90 us per batch with one shared sink).
+constexpr int kJunkSlots = 2048;
+__device__ float g_junk[kJunkSlots][16 * 64];
+
 // mi_oov_lsh_table_prepare: table f32[2^H][64] in global memory, one workgroup
 template <int H>
 __global__ __launch_bounds__(kPBlk) void lsh64_table_kernel(const float* __restrict__ buckets, float* __restrict__ table) {
@@ -195,17 +207,27 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
                                                                         unsigned* __restrict__ sched_busy,
                                                                         const float* __restrict__ vtable, int64_t n_vocab,
                                                                         const float* __restrict__ tab_prep) {
-  static_assert(MODE == kModeScore || MODE == kModeRows || H == 8, "codes are written as one 8-byte word per lookup");
+  static_assert(MODE == kModeScore || MODE == kModeRows || MODE == kModeMean || H == 8, "codes are written as one 8-byte word per lookup");
   static_assert(!LOOKUP || MODE == kModeScore || MODE == kModeRows, "the in-vocabulary splice exists for scores and rows");
   constexpr bool kFromCodes = MODE == kModeFromCodes;  // ids = int32 slots, feat = u8[N,8] codes
   constexpr bool kScore = MODE == kModeScore || kFromCodes;
-  constexpr bool kRows = MODE == kModeRows;
-  constexpr bool kTable = kScore || kRows;  // the 2^H-row table of aggregates is needed
-  constexpr int NU = kScore ? 4 : 1;
+  // The knn aggregate on the same pipeline (mi_oov_gather_mean_multi, D = 64, the reference's group size 2):
+  //   MODE_MEAN    out[o] = (W[idx[2o]] + W[idx[2o+1]]) / 2     `.split(2)` + mean (knn_embedder.py:125-126,146-147)
+  // feat = W, B = outputs per batch; the second row of an output travels in the registers the score modes use for the
+  // rows of the other side.  No planes, no table, no LDS.  (The plain gather out[b] = W[ids[b]] was tried here too and
+  // is no faster than the grid-stride row_copy_kernel of gather.hip -- 108.2 against 107.9 us for 20 x 65536 rows -- so
+  // mi_oov_gather_rows_multi stays there, for every row width.)
+  constexpr bool kMean = MODE == kModeMean;
+  constexpr bool kMover = kMean;
+  constexpr bool kRows = MODE == kModeRows || kMover;  // f32[B,64] rows are written
+  constexpr bool kTable = kScore || MODE == kModeRows;  // the 2^H-row table of aggregates is needed
+  constexpr bool kPlanes = !kFromCodes && !kMover;
+  constexpr int NU = (kScore || kMean) ? 4 : 1;
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
   const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const unsigned tpb = (B + 15) / 16, nfull = B / 16;
+  const unsigned tpb = (B + 15) / 16;
   const unsigned G = gridDim.x * kPWpb;
+  const unsigned mean_m = static_cast<unsigned>(n_vocab);  // MODE_MEAN: indices per batch (2 B or 2 B - 1), in the n_vocab slot
 #ifdef MI_PSTAMPS  // developer build (tools/multi_bench MB_STAMPS=1): per-wave s_memrealtime stamps behind the bucket table
   uint64_t* stamps = reinterpret_cast<uint64_t*>(const_cast<float*>(buckets) + H * 64) + (blockIdx.x * kPWpb + wv) * 4;
   const uint64_t st0 = __builtin_amdgcn_s_memrealtime();
@@ -241,6 +263,11 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     row = row < B ? row : B - 1;  // tail tiles recompute the last row
     if constexpr (kFromCodes) return static_cast<int64_t>(((gptr_i32)ids_src)[row]);  // -1 / -2: no answer
     gptr_i64 idp = ids_of(p.batch);
+    if constexpr (kMean) {  // lanes 0-3 of a row hold the first index of rounds 0-3, lanes 4-7 the second
+      unsigned e = 2u * row + ((l16 >> 2) & 1u);
+      e = e < mean_m ? e : mean_m - 1;  // an odd count: the last output has one row (its second slot is not used)
+      return idp[e];
+    }
     return idp[row];
   };
   // stage B: the 4 gathers first (second hop of the ids -> rows chain), the sequential rows of the other side behind
@@ -261,6 +288,18 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
       } else {
         const bool valid = static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N);
         x[r] = gload4<MI_PNT_X != 0>(feat + (valid ? id[r] : 0) * 64 + l16 * 4);
+      }
+    }
+    if constexpr (kMean) {
+      int64_t id2[4];
+      id2[0] = bcast_id<4>(idv);
+      id2[1] = bcast_id<5>(idv);
+      id2[2] = bcast_id<6>(idv);
+      id2[3] = bcast_id<7>(idv);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const bool valid = static_cast<uint64_t>(id2[r]) < static_cast<uint64_t>(N);
+        u[r] = gload4<MI_PNT_X != 0>(feat + (valid ? id2[r] : 0) * 64 + l16 * 4);
       }
     }
     if constexpr (kScore) {
@@ -394,7 +433,7 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     const bool stage = threadIdx.x < H * 16;
     float4 pv = make_float4(0.f, 0.f, 0.f, 0.f), bv = pv;
     float4 tv[kTabPer];
-    if constexpr (!kFromCodes) {
+    if constexpr (kPlanes) {
       if (stage) pv = *reinterpret_cast<const float4*>(planes + threadIdx.x * 4);
     }
     if constexpr (kTable) {
@@ -417,7 +456,7 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     asm volatile("" ::: "memory");
     if (have) tk = draw();
     asm volatile("" ::: "memory");
-    if constexpr (!kFromCodes) {
+    if constexpr (kPlanes) {
       if (stage) *reinterpret_cast<float4*>(splanes + threadIdx.x * 4) = pv;
     }
     if constexpr (kTable) {
@@ -432,7 +471,7 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
       }
     }
   }
-  __syncthreads();
+  if constexpr (!kMover) __syncthreads();
   if (MI_PEARLY && have && !prep) load_rows(pa, ida, xa, ua);
   if constexpr (kTable) {
     if (!prep) {  // table build: see build_code_table
@@ -440,8 +479,8 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
       __syncthreads();
     }
   }
-  float4 pw[kFromCodes ? 1 : H];
-  if constexpr (!kFromCodes) {
+  float4 pw[kPlanes ? H : 1];
+  if constexpr (kPlanes) {
 #pragma unroll
     for (int h = 0; h < H; ++h) pw[h] = *reinterpret_cast<const float4*>(splanes + (h * 16 + l16) * 4);
   }
@@ -491,15 +530,13 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     uint32_t lo, hi;
     void* op;        // the batch's output (wave-uniform)
     unsigned first;  // first row of the tile
-    bool full;       // all 16 rows exist (wave-uniform); otherwise rows < B are stored
-    unsigned lim;    // B; 0 in the empty result the pipeline starts with
+    unsigned last;   // last row of the batch (B - 1): rows of a partial tile beyond it are stored ONTO it (see commit)
   };
   auto reduce = [&](TilePos p, int64_t idv, const float4 (&x)[4], const float4 (&u)[NU]) -> Res {
     Res res;
     res.op = out_of(p.batch);
     res.first = p.local * 16u;
-    res.full = p.local < nfull;
-    res.lim = B;
+    res.last = B - 1u;
     res.sc = 0.f;
     res.lo = res.hi = 0u;
     int64_t id[4];
@@ -507,6 +544,28 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     // the embedding of round r's lookup: the table row at its code; with LOOKUP the gathered row itself when the id is
     // in the vocabulary; NaN for an id that addresses no row
     auto emb_of = [&](int r) -> float4 {
+      if constexpr (kMean) {
+        // sum in increasing position from +0, one division by the group's length (torch.split: an odd count leaves the
+        // last output a group of one) -- gather_mean_kernel's order, oracle/oov_oracle.c's
+        int64_t id2;
+        switch (r) {
+          case 0: id2 = bcast_id<4>(idv); break;
+          case 1: id2 = bcast_id<5>(idv); break;
+          case 2: id2 = bcast_id<6>(idv); break;
+          default: id2 = bcast_id<7>(idv); break;
+        }
+        unsigned o = p.local * 16u + r * 4u + grp;
+        o = o < B ? o : B - 1u;  // (tail lanes recompute the last output, as their ids do)
+        const bool two = 2u * o + 1u < mean_m;
+        const bool ok = static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N) &&
+                        (!two || static_cast<uint64_t>(id2) < static_cast<uint64_t>(N));
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        acc.x += x[r].x; acc.y += x[r].y; acc.z += x[r].z; acc.w += x[r].w;
+        if (two) { acc.x += u[r].x; acc.y += u[r].y; acc.z += u[r].z; acc.w += u[r].w; }
+        const float n = two ? 2.f : 1.f;
+        acc.x /= n; acc.y /= n; acc.z /= n; acc.w /= n;
+        return ok ? acc : make_float4(qnan(), qnan(), qnan(), qnan());
+      } else {
       float4 emb = *reinterpret_cast<const float4*>(sw + (code_of(x[r]) * 16u + l16) * 4u);
       bool bad;
       if constexpr (LOOKUP) {
@@ -520,6 +579,7 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
         bad = bad || ((__float_as_uint(x[r].x) | __float_as_uint(x[r].y)) & 0xFEFEFEFEu) != 0;
       if (bad) emb = make_float4(qnan(), qnan(), qnan(), qnan());
       return emb;
+      }
     };
     if constexpr (kScore) {
 #pragma unroll
@@ -530,6 +590,12 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     } else if constexpr (kRows) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) res.e[r] = emb_of(r);
+      if constexpr (kMover) {
+        // (three additions and a division: pinned HERE -- left to itself the compiler sinks them to the stores of the
+        //  next step, behind a wait for every row request in between)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) asm volatile("" : "+v"(res.e[r].x), "+v"(res.e[r].y), "+v"(res.e[r].z), "+v"(res.e[r].w));
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -546,11 +612,18 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     }
     return res;
   };
+  // Every store of a tile is UNCONDITIONAL: a lane-predicated store of more than a few instructions is compiled into a
+  // branch around it (s_cbranch_execz), and a memory instruction that may or may not have been issued makes every
+  // s_waitcnt count behind it a lower bound -- the loop then waits for the stores' acknowledgements as well, or for
+  // vmcnt(0).  Rows of a partial tile beyond the batch are stored ONTO its last row instead: those lanes were given the
+  // last row's id (and row of the other side) by the clamped loads, so they hold the same value bit for bit and the
+  // duplicate stores are benign.  The empty result the pipeline starts with goes to a junk sink (g_junk).
   auto commit = [&](const Res& res) {
-    const unsigned row = res.first + l16 * 4u + grp;
+    unsigned row = res.first + l16 * 4u + grp;
+    row = row < res.last ? row : res.last;
     if constexpr (kScore) {
       // the tile's 16 contiguous scores in one store
-      if (l16 < 4 && (res.full || row < res.lim)) ((gptr_f32)res.op)[row] = res.sc;
+      if (l16 < 4) ((gptr_f32)res.op)[row] = res.sc;
     } else if constexpr (kRows) {
       // four 256-byte rows per 16-lane group, all four stores together (a store between the rounds of `reduce` would sit
       // in front of the waits that follow it).  Non-temporal: the rows are written once and not read by this launch,
@@ -558,19 +631,18 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
       gptr_v4 op = (gptr_v4)res.op;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const unsigned orow = res.first + r * 4u + grp;
+        unsigned orow = res.first + r * 4u + grp;
+        orow = orow < res.last ? orow : res.last;
         const v4f v = {res.e[r].x, res.e[r].y, res.e[r].z, res.e[r].w};
-        if (res.full || orow < res.lim) {
 #if MI_PNT_O
-          __builtin_nontemporal_store(v, op + (orow * 16u + l16));
+        __builtin_nontemporal_store(v, op + (orow * 16u + l16));
 #else
-          op[orow * 16u + l16] = v;
+        op[orow * 16u + l16] = v;
 #endif
-        }
       }
     } else {
       // the tile's 16 code rows (128 contiguous bytes) in one store
-      if (l16 < 4 && (res.full || row < res.lim)) {
+      if (l16 < 4) {
         v2u v = {res.lo, res.hi};
         ((gptr_u2)res.op)[row] = v;
       }
@@ -595,10 +667,9 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
 #define MI_PDEFER 1
 #endif
   Res pend;
-  pend.op = out_src;
+  pend.op = g_junk[gwave % kJunkSlots];
   pend.first = 0u;
-  pend.full = false;
-  pend.lim = 0u;
+  pend.last = 15u;
   pend.sc = 0.f;
   pend.lo = pend.hi = 0u;
 #pragma unroll
@@ -610,6 +681,18 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     asm volatile("" ::: "memory");
     if (MI_PDEFER) commit(pend);
     if (pool) tk = draw();
+    // Rows modes: everything the wave has in flight but its youngest request is waited for before a tile is reduced --
+    // more than the reduction needs (the compiler's own count would leave the next tile's rows and the last stores in
+    // flight: MI_PROWS_WAIT=0), and faster: K = 64, 5.92 -> 5.72 us per batch (the version with lane-predicated stores,
+    // whose waits were lower bounds, ran at that speed by accident and is where this was found).  Row stores and gathers
+    // of one wave then alternate instead of overlapping; the other waves of the CU cover the wait.  The score modes,
+    // which store 4 bytes per lookup, run the same with and without (5.14-5.20 us).
+#if MI_PROWS_WAIT
+    if constexpr (kRows) __builtin_amdgcn_s_waitcnt(0x0F70 | MI_PROWS_WAIT);
+#endif
+#if MI_PSCORE_WAIT
+    if constexpr (kScore) __builtin_amdgcn_s_waitcnt(0x0F70 | MI_PSCORE_WAIT);
+#endif
     const Res ra = reduce(pa, ida, xa, ua);
     if (!MI_PDEFER) commit(ra);
 #ifdef MI_PSTAMPS
@@ -620,6 +703,12 @@ __global__ __launch_bounds__(kPBlk, MI_PW) void lsh64_persistent_kernel(const vo
     load_rows(pn, idn, xa, ua);
     asm volatile("" ::: "memory");
     if (MI_PDEFER) commit(ra);
+#if MI_PROWS_WAIT
+    if constexpr (kRows) __builtin_amdgcn_s_waitcnt(0x0F70 | MI_PROWS_WAIT);
+#endif
+#if MI_PSCORE_WAIT
+    if constexpr (kScore) __builtin_amdgcn_s_waitcnt(0x0F70 | MI_PSCORE_WAIT);
+#endif
     pend = reduce(pb, idb, xb, ub);
     if (!MI_PDEFER) commit(pend);
     pa = pn; ida = idn;
@@ -766,13 +855,13 @@ struct PersistArgs {
 
 template <int H, int MODE, bool TAB, bool LOOKUP>
 static int launch_persistent(const PersistArgs& a, hipStream_t st) {
-  constexpr bool kTable = MODE != kModeCodes;
-  constexpr size_t lds = ((kTable ? (size_t(1) << H) : 0) + (kTable ? 2 * H : H)) * 64 * sizeof(float);
+  constexpr bool kTable = MODE != kModeCodes && MODE != kModeMean;
+  constexpr size_t lds = MODE == kModeMean ? 0 : ((kTable ? (size_t(1) << H) : 0) + (kTable ? 2 * H : H)) * 64 * sizeof(float);
   auto kern = lsh64_persistent_kernel<H, MODE, TAB, LOOKUP>;
   if (int rc = set_lds(kern, lds)) return rc;
   static int cached = 0;
   // MI_PROWS_WG workgroups per CU in rows mode (its 97 registers would admit two: measured in DESIGN.md section 5)
-  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached, MODE == kModeRows ? MI_PROWS_WG : 0);
+  int resident = grid_override() > 0 ? grid_override() : resident_blocks(kern, lds, cached, (MODE == kModeRows || MODE == kModeMean) ? MI_PROWS_WG : 0);
   if (resident <= 0) {
     g_last_hip_error = static_cast<int>(hipGetLastError());
     return MI_OOV_ERR_LAUNCH;
@@ -799,7 +888,7 @@ static int launch_persistent(const PersistArgs& a, hipStream_t st) {
   } else {
     constexpr int64_t kMaxRows = int64_t(1) << 23;
     constexpr int64_t id_bytes = MODE == kModeFromCodes ? 4 : 8;
-    constexpr int64_t out_bytes = MODE == kModeRows ? 256 : (MODE == kModeCodes ? 8 : 4);
+    constexpr int64_t out_bytes = (MODE == kModeRows || MODE == kModeMean) ? 256 : (MODE == kModeCodes ? 8 : 4);
     for (int64_t b0 = 0; b0 < a.B; b0 += kMaxRows) {
       const int64_t nb = (a.B - b0 < kMaxRows) ? a.B - b0 : kMaxRows;
       if (int rc = launch(static_cast<const char*>(a.ids) + b0 * id_bytes,
@@ -847,6 +936,16 @@ int launch_lsh64_persistent_single(const int64_t* ids, int64_t B, const float* f
   PersistArgs a{ids, other, score ? static_cast<void*>(score) : static_cast<void*>(out), 1, B, feat, N, vtable, n_vocab,
                 planes, buckets, nullptr};
   return launch_persistent_any(false, H, a, score != nullptr, st);
+}
+
+// The knn aggregate on the persistent pipeline, D = 64, group size 2, K batches of M indices behind pointer tables: host
+// entry used by mi_oov_gather_mean_multi (gather.hip).
+int launch_gather_mean64_persistent(const int64_t* const* idx_tab, float* const* out_tab, int64_t K, int64_t M,
+                                    const float* W, int64_t N, hipStream_t st) {
+  const int64_t B = (M + 1) / 2;  // outputs per batch
+  if (B > (int64_t(1) << 23) || M >= (int64_t(1) << 31)) return MI_OOV_ERR_SHAPE;
+  PersistArgs a{idx_tab, nullptr, const_cast<float**>(out_tab), K, B, W, N, nullptr, M, nullptr, nullptr, nullptr};
+  return launch_persistent<1, kModeMean, true, false>(a, st);
 }
 
 // Codes of one large batch (H = 8, F = 64): host entry used by launch_lsh64 (lsh64.hip) for codes-only calls of at

@@ -262,9 +262,7 @@ class LshBatchQueue:
                 raise ValueError(f"rows of batch {k} are not 16-byte aligned")
         self.ids, self.other, self.scores = list(ids_list), (None if rows else list(other_list)), list(score_list)
         self.K, self.B, self.D, self.device, self.rows = K, B, D, dev, bool(rows)
-        ptrs = [[t.data_ptr() for t in self.ids], [0] * K if rows else [t.data_ptr() for t in self.other],
-                [t.data_ptr() for t in self.scores]]
-        self.tab = torch.tensor(ptrs, dtype=torch.int64).to(dev)  # [3, K] device pointers
+        self.tab = _ptr_table(self.ids, self.other, self.scores)  # [3, K] device pointers
 
     @property
     def outputs(self):
@@ -378,6 +376,107 @@ def lsh_lookup_multi(ids_list, table, feat, planes, buckets, other_list=None, ou
     sc = LshMultiScorer(feat, planes, buckets, vtable=table, prepared=False)
     sc._table = lsh_table
     return sc.run(q)
+
+
+def _batch_list(tensors, dtype, name, shape_tail=None):
+    """K equally shaped, contiguous device tensors -> (list, rows per batch)."""
+    if len(tensors) == 0:
+        raise ValueError(f"{name}: need at least one batch")
+    out = [C.dev_tensor(t, dtype, f"{name}[{k}]") for k, t in enumerate(tensors)]
+    n0 = out[0].shape
+    for k, t in enumerate(out):
+        if t.shape != n0 or t.device != out[0].device:
+            raise ValueError(f"{name}[{k}] has shape {tuple(t.shape)} on {t.device}; every queued batch must be {tuple(n0)} on {out[0].device}")
+    return out
+
+
+_PTR_TABLES = {}  # (device, addresses) -> device int64 table; a table holds nothing but the addresses that key it
+_PTR_TABLES_MAX = 256
+
+
+def _ptr_table(*lists):
+    """device int64[len(lists), K] of data pointers.  Cached by the addresses themselves (a table is valid for whatever
+    lives at those addresses), so a loop that rotates over preallocated buffers uploads each of its tables once: the
+    host -> device copy of a fresh table costs more than the launch it feeds."""
+    dev = next(t for lst in lists if lst is not None for t in lst).device
+    K = len(next(lst for lst in lists if lst is not None))
+    rows = tuple(tuple(t.data_ptr() for t in lst) if lst is not None else (0,) * K for lst in lists)
+    key = (dev, rows)
+    tab = _PTR_TABLES.get(key)
+    if tab is None:
+        if len(_PTR_TABLES) >= _PTR_TABLES_MAX:
+            _PTR_TABLES.pop(next(iter(_PTR_TABLES)))
+        tab = _PTR_TABLES[key] = torch.tensor(rows, dtype=torch.int64).to(dev)
+    return tab
+
+
+def _out_rows(out, K, rows, D, dev):
+    """Caller-owned f32[rows, D] output buffers (validated), or K slices of one fresh block."""
+    if out is None:
+        block = torch.empty((K, rows, D), dtype=torch.float32, device=dev)
+        return [block[k] for k in range(K)]
+    outs = _batch_list(out, torch.float32, "out")
+    if len(outs) != K or outs[0].shape != (rows, D) or any(o.data_ptr() != t.data_ptr() for o, t in zip(outs, out)) \
+            or any(o.data_ptr() % 16 for o in outs):
+        raise ValueError(f"out must be {K} contiguous, 16-byte aligned f32[{rows},{D}] tensors")
+    return outs
+
+
+def gather_rows_multi(ids_list, W, out=None):
+    """[W[ids] for ids in ids_list] (nn.Embedding forward, bpr.py:77-81) for K equally sized batches in ONE launch
+    (mi_oov_gather_rows_multi).  Inference only.  Widths that are not a multiple of 4 floats: K single launches."""
+    W = _f32(W, "W")
+    ids = _batch_list(ids_list, torch.int64, "ids")
+    K, B, (N, D) = len(ids), ids[0].numel(), W.shape
+    if D % 4 or W.data_ptr() % 16:
+        return [_gather_rows_forward(i, W) for i in ids]
+    outs = _out_rows(out, K, B, D, W.device)
+    tab = _ptr_table(ids, outs)
+    with C.on_device(W):
+        rc = C.lib().mi_oov_gather_rows_multi(tab[0].data_ptr(), tab[1].data_ptr(), K, B, C.ptr(W), N, D, C.stream_of(W))
+    C.check(rc, "mi_oov_gather_rows_multi")
+    return outs
+
+
+def gather_mean_multi(idx_list, W, g=2, out=None):
+    """[gather_mean(idx, W, g) for idx in idx_list] (the knn aggregate, knn_embedder.py:125-126) for K equally sized
+    batches in ONE launch (mi_oov_gather_mean_multi).  Inference only."""
+    W = _f32(W, "W")
+    idx = _batch_list([i.reshape(-1) for i in idx_list], torch.int64, "idx")
+    K, M, (N, D) = len(idx), idx[0].numel(), W.shape
+    if D % 4 or W.data_ptr() % 16:
+        return [_gather_mean_forward(i, W, g) for i in idx]
+    nout = (M + g - 1) // g
+    outs = _out_rows(out, K, nout, D, W.device)
+    tab = _ptr_table(idx, outs)
+    with C.on_device(W):
+        rc = C.lib().mi_oov_gather_mean_multi(tab[0].data_ptr(), tab[1].data_ptr(), K, M, g, C.ptr(W), N, D, C.stream_of(W))
+    C.check(rc, "mi_oov_gather_mean_multi")
+    return outs
+
+
+def slsh_embed_multi(ids_list, feat, planes, buckets, want_idx=False, out=None):
+    """[slsh_embed(ids, feat, planes, buckets) for ids in ids_list] (single_lsh_embedder.py:82-109) for K equally sized
+    batches in ONE launch (mi_oov_slsh_embed_multi); shapes off the hot tile run as K single launches.  Inference only.
+    want_idx: also the bucket ids -> (rows list, idx list)."""
+    feat, planes, buckets = _f32(feat, "feat"), _f32(planes, "planes"), _f32(buckets, "buckets")
+    ids = _batch_list(ids_list, torch.int64, "ids")
+    K, B, (N, F), H, (nb, D) = len(ids), ids[0].numel(), feat.shape, planes.shape[0], buckets.shape
+    hot = F == 64 and H <= 32 and D in (64, 128) and not (feat.data_ptr() % 16 or planes.data_ptr() % 16 or buckets.data_ptr() % 16)
+    if not hot or B > (1 << 22):
+        res = [_slsh_forward(i, feat, planes, buckets, nb) for i in ids]
+        return ([r[0] for r in res], [r[1] for r in res]) if want_idx else [r[0] for r in res]
+    outs = _out_rows(out, K, B, D, feat.device)
+    idxs = None
+    if want_idx:
+        iblock = torch.empty((K, B), dtype=torch.int64, device=feat.device)
+        idxs = [iblock[k] for k in range(K)]
+    tab = _ptr_table(ids, outs, idxs)
+    with C.on_device(feat):
+        rc = C.lib().mi_oov_slsh_embed_multi(tab[0].data_ptr(), tab[1].data_ptr(), tab[2].data_ptr() if want_idx else None, K, B,
+                                             C.ptr(feat), N, F, C.ptr(planes), H, C.ptr(buckets), nb, D, C.stream_of(feat))
+    C.check(rc, "mi_oov_slsh_embed_multi")
+    return (outs, idxs) if want_idx else outs
 
 
 def bucket_by_owner(ids, n_rows, rows_per_rank, world, cap, overflow=None):

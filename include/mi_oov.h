@@ -212,6 +212,14 @@ int mi_oov_slsh_embed(const int64_t* ids, int64_t B,
                       const float* buckets, int64_t n_buckets, int64_t D,
                       float* out, int64_t* idx, void* stream);
 
+/* K queued batches of mi_oov_slsh_embed in ONE launch (every batch B ids).  Hot tile only: F == 64, H <= 32 and D 64 or
+ * 128 when rows are wanted; any other shape returns MI_OOV_ERR_SHAPE (callers issue K single launches).
+ * ids_tab / out_tab / idx_tab: DEVICE arrays of K device pointers; out_tab or idx_tab may be NULL.                */
+int mi_oov_slsh_embed_multi(const int64_t* const* ids_tab, float* const* out_tab, int64_t* const* idx_tab, int64_t K,
+                            int64_t B, const float* feat, int64_t N, int64_t F,
+                            const float* planes, int64_t H,
+                            const float* buckets, int64_t n_buckets, int64_t D, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * dhe: DeepHashEmbedder._get_hashes / _hash_ids (R/inductive/dh_embedder.py:140-170):
  *     out[b,j] = float( SipHash-2-4(key_j, LE64(ids[b])) mod mod )      (mod = 16777216)
@@ -249,11 +257,22 @@ int mi_oov_gather_mean(const int64_t* idx, int64_t M, int64_t g,
                        const float* W, int64_t N, int64_t D,
                        float* out, void* stream);
 
+/* K queued batches of mi_oov_gather_mean in ONE launch (every batch M indices, same g): idx_tab / out_tab are DEVICE
+ * arrays of K device pointers (int64[M] / f32[ceil(M/g), D]); D a multiple of 4, W and the output rows 16-byte aligned.
+ * Batch k gives exactly what mi_oov_gather_mean gives for idx_tab[k].                                            */
+int mi_oov_gather_mean_multi(const int64_t* const* idx_tab, float* const* out_tab, int64_t K, int64_t M, int64_t g,
+                             const float* W, int64_t N, int64_t D, void* stream);
+
 /* nn.Embedding forward (bpr.py:77-81 _user_id_lookup/_item_id_lookup; slsh bucket gather):
  *   out[b,:] = W[ids[b],:]                                                              */
 int mi_oov_gather_rows(const int64_t* ids, int64_t B,
                        const float* W, int64_t N, int64_t D,
                        float* out, void* stream);
+
+/* K queued batches of mi_oov_gather_rows in ONE launch (every batch B ids): ids_tab / out_tab are DEVICE arrays of K
+ * device pointers (int64[B] / f32[B,D]); D a multiple of 4, W and the output rows 16-byte aligned.                  */
+int mi_oov_gather_rows_multi(const int64_t* const* ids_tab, float* const* out_tab, int64_t K, int64_t B,
+                             const float* W, int64_t N, int64_t D, void* stream);
 
 /* BPR.get_*_embedding splice for plugins other than lsh (bpr.py:62-76,108-123):
  *   out[b,:] = table[ids[b],:]              if ids[b] < n_vocab

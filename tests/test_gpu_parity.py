@@ -902,3 +902,55 @@ def test_lsh_multi_generic_entry_raw_cabi_errors(ops, dev):
     assert lib.mi_oov_lsh_table_prepare(None, 8, 64, table.data_ptr(), st) == -1
     assert lib.mi_oov_lsh_table_prepare(buckets.data_ptr(), 8, 64, table.data_ptr() + 8, st) == -5
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("K,B,N,D", [(1, 1, 5, 64), (3, 63, 100, 64), (5, 4097, 3000, 64), (40, 333, 200, 128), (7, 130, 90, 32),
+                                     (2, 17, 40, 50), (300, 17, 40, 64)])
+def test_gather_multi_entries_vs_oracle(K, B, N, D, oracle, ops, dev):
+    """K queued batches of gather_rows / gather_mean in one launch: every batch equals the oracle's result for that batch
+    (and the single-batch kernels), invalid ids give NaN rows, odd index counts keep torch.split's short last group."""
+    rng = np.random.default_rng(K * 100 + B + D)
+    W = rng.standard_normal((N, D), dtype=np.float32)
+    ids = rng.integers(0, N, size=(K, B), dtype=np.int64)
+    if B > 5:
+        ids[0, 2], ids[K - 1, 4] = -1, N
+    W_d, ids_d = T(W, dev), T(ids, dev)
+    rows = ops.gather_rows_multi([ids_d[k] for k in range(K)], W_d)
+    for k in range(K):
+        assert bits_equal(rows[k].cpu().numpy(), oracle.gather_rows(ids[k], W)), f"gather_rows, batch {k}"
+        assert bits_equal(ops.gather_rows(ids_d[k], W_d).cpu().numpy(), oracle.gather_rows(ids[k], W))
+    for g in (2, 3):
+        for M in (B, B - 1 if B > 1 else 1):  # an odd count leaves a short last group
+            idx = [ids_d[k][:M] for k in range(K)]
+            means = ops.gather_mean_multi(idx, W_d, g)
+            for k in range(K):
+                want = oracle.gather_mean(ids[k][:M], W, g)
+                assert bits_equal(means[k].cpu().numpy(), want), f"gather_mean g={g} M={M}, batch {k}"
+                assert bits_equal(ops.gather_mean(idx[k], W_d, g).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("K,B,H,D,nb", [(1, 1, 3, 64, 8), (3, 4099, 3, 64, 8), (4, 1000, 10, 64, 1000), (2, 65, 27, 128, 100_000),
+                                        (5, 16, 32, 128, 40), (3, 300, 8, 64, 5), (2, 77, 12, 32, 100)])
+def test_slsh_multi_and_lds_bucket_rows_vs_oracle(K, B, H, D, nb, oracle, ops, dev):
+    """slsh on the hot tile reads its bucket rows from an LDS copy of the H + 1 rows the reference's arithmetic can reach
+    ((bits_req + popcount) % n_buckets): rows and bucket ids of single launches and of K queued batches equal the
+    oracle's, for bucket tables smaller than, equal to and far larger than that set, D = 64 / 128 (D = 32: fallback)."""
+    rng = np.random.default_rng(K + B + H + nb)
+    N = 500
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    feat[0] = 0
+    planes = rng.standard_normal((H, 64), dtype=np.float32)
+    buckets = rng.standard_normal((nb, D), dtype=np.float32)
+    ids = rng.integers(0, N, size=(K, B), dtype=np.int64)
+    ids[0, 0] = 0
+    if B > 5:
+        ids[0, 3], ids[K - 1, 1] = N + 2, -7
+    f, p, w, i = T(feat, dev), T(planes, dev), T(buckets, dev), T(ids, dev)
+    rows, idxs = ops.slsh_embed_multi([i[k] for k in range(K)], f, p, w, want_idx=True)
+    rows_only = ops.slsh_embed_multi([i[k] for k in range(K)], f, p, w)
+    for k in range(K):
+        o_emb, o_idx = oracle.slsh_embed(ids[k], feat, planes, buckets)
+        assert bits_equal(rows[k].cpu().numpy(), o_emb) and bits_equal(rows_only[k].cpu().numpy(), o_emb), f"batch {k}"
+        assert np.array_equal(idxs[k].cpu().numpy(), o_idx)
+        assert bits_equal(ops.slsh_embed(i[k], f, p, w).cpu().numpy(), o_emb)
+        assert np.array_equal(ops.slsh_index(i[k], f, p, nb).cpu().numpy(), o_idx)

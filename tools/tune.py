@@ -119,7 +119,7 @@ def main():
     # round 2: the persistent launch and the two ends of the sharded exchange (1 M lookups = 16 batches per call)
     BIG = 16 * B
     big_ids = ids[:16].reshape(-1)
-    q50 = ops.LshBatchQueue([ids[i] for i in range(50)], [users[i % 8] for i in range(50)])
+    q50 = ops.LshBatchQueue([ids[i] for i in range(50)], [users[i % 8] for i in range(50)])  # (838 MB of rows per launch: no reuse)
     multi = ops.LshMultiScorer(feat, planes, buckets)
     codes_big = (torch.rand((BIG, H), generator=g, device=dev) < 0.5).to(torch.uint8)
     slot_big = torch.randperm(BIG, generator=g, device=dev).to(torch.int32)
@@ -132,6 +132,35 @@ def main():
         "lsh_codes_embed 1M lookups score only (sharded requester side)": (lambda i: ops.lsh_codes_embed(codes_big, slot_big, buckets, users_big, want_emb=False, score_out=sc_big), BIG, 4 + H + 4 * D + 4, 0),
         "bucket_by_owner 1M lookups world=8": (lambda i: ops.bucket_by_owner(big_ids, N, -(-N // 8), 8, BIG // 8 + 8192, over), BIG, 8 + 8 + 4, 0),
         "bucket_by_owner 65536 lookups world=8": (lambda i: ops.bucket_by_owner(ids[i], N, -(-N // 8), 8, B // 8 + 2048, over), B, 8 + 8 + 4, 0),
+    })
+    # round 3: K = 20 queued batches per launch of the rows / lookup modes of the persistent kernel and of the gather family.
+    # Consecutive launches alternate between TWO queues of 20 distinct id batches (and two sets of preallocated outputs: a
+    # serving loop rotates over its buffers), so that a launch finds none of its 335 MB of table rows in the 256 MiB
+    # Infinity Cache; pointer tables are built once (ops caches them by address).
+    KQ = 20
+    idsq = [[ids[j * KQ + i] for i in range(KQ)] for j in range(2)]
+    usersq = [users[i % 8] for i in range(KQ)]
+    vt = feat[:N // 2]
+    q_rows = [ops.LshBatchQueue(idsq[j], rows=True) for j in range(2)]
+    q_sc = [ops.LshBatchQueue(idsq[j], usersq) for j in range(2)]
+    m_rows, m_lrows = ops.LshMultiScorer(feat, planes, buckets), ops.LshMultiScorer(feat, planes, buckets, vtable=vt)
+    m_lall = ops.LshMultiScorer(feat, planes, buckets, vtable=feat)  # every id in the vocabulary: a gather through the lsh kernel
+    idx2q = [[idx2[j * KQ + i] for i in range(KQ)] for j in range(2)]
+    big_bk = torch.randn((1000, 128), generator=g, device=dev)
+    planes10 = planes24[:10].contiguous()
+    o64 = [[t for t in torch.empty((KQ, B, 64), device=dev)] for j in range(2)]
+    o128 = [[t for t in torch.empty((KQ, B, 128), device=dev)] for j in range(2)]
+    cases.update({
+        f"lsh_embed_multi {KQ} batches per launch (persistent kernel, rows stored, prepared table)": (lambda i: m_rows.run(q_rows[i % 2]), KQ * B, 8 + 4 * F + 4 * D, 0),
+        f"lsh_lookup_multi rows {KQ} batches per launch (persistent kernel, 50% OOV)": (lambda i: m_lrows.run(q_rows[i % 2]), KQ * B, 8 + 4 * F + 4 * D, 0),
+        f"lsh_lookup_multi rows {KQ} batches per launch (persistent kernel, 0% OOV = a plain gather)": (lambda i: m_lall.run(q_rows[i % 2]), KQ * B, 8 + 4 * F + 4 * D, 0),
+        f"lsh_lookup_multi score {KQ} batches per launch (persistent kernel, 50% OOV)": (lambda i: m_lrows.run(q_sc[i % 2]), KQ * B, 16 + 4 * F + 4 * D + 4, 0),
+        f"lsh_embed_score_multi {KQ} batches per launch (persistent kernel, prepared table)": (lambda i: m_rows.run(q_sc[i % 2]), KQ * B, 16 + 4 * F + 4 * D + 4, 0),
+        f"gather_rows_multi {KQ} batches per launch": (lambda i: ops.gather_rows_multi(idsq[i % 2], feat, out=o64[i % 2]), KQ * B, 8 + 8 * D, 0),
+        f"gather_mean_multi k=2 {KQ} batches per launch": (lambda i: ops.gather_mean_multi(idx2q[i % 2], feat, 2, out=o64[i % 2]), KQ * B, 16 + 8 * D + 4 * D, 0),
+        f"slsh_embed_multi nb=N {KQ} batches per launch (bucket rows from LDS)": (lambda i: ops.slsh_embed_multi(idsq[i % 2], feat, planes24, feat, out=o64[i % 2]), KQ * B, 8 + 4 * F + 8 * D, 0),
+        f"slsh_embed_multi nb=1000 D=128 10 planes {KQ} batches per launch": (lambda i: ops.slsh_embed_multi(idsq[i % 2], feat, planes10, big_bk, out=o128[i % 2]), KQ * B, 8 + 4 * F + 8 * 128, 0),
+        "slsh_embed nb=1000 D=128 10 planes": (lambda i: ops.slsh_embed(ids[i], feat, planes10, big_bk), B, 8 + 4 * F + 8 * 128, 0),
     })
     if args.only.startswith("score_topk_excl"):  # full-sort evaluation: histories masked (bitmap in the kernel vs top-(k + h_max))
         gh = torch.Generator(device=dev).manual_seed(5)
