@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--batches-per-exchange", type=int, default=64, help="--table sharded: steps carried by one all-to-all")
     ap.add_argument("--force-sharded", action="store_true",
                     help="developer: run the sharded path at N = 1 too (one-rank RCCL group, self-exchange) to time its kernels")
+    ap.add_argument("--local-fast", action="store_true",
+                    help="--table sharded: lookups a rank owns itself skip the exchange (fused kernel on the local block)")
     ap.add_argument("--cap-factor", type=float, default=1.0,
                     help="--table sharded: segment capacity = this multiple of the expected share of an exchange + 8 "
                          "standard deviations (ids are uniform; the run fails loudly if a segment ever overflows)")
@@ -359,7 +361,7 @@ def main():
         lo, hi, _ = sharded.shard_bounds(N, world, rank)
         feat_l, planes_l, buckets_l = make_inputs(args, dev, hi - lo, lo)
         table = sharded.ShardedLSHTable(feat_l, N, cap_factor=args.cap_factor, uniform_batches=True)
-        pipe = sharded.LshPipeline(table, planes_l, buckets_l)
+        pipe = sharded.LshPipeline(table, planes_l, buckets_l, local_fast=args.local_fast)
         flat_ids = all_ids.view(-1)
         ramp_rows, ring_rows, ring_scores = ramp_users.view(-1, D), users.view(-1, D), scores.view(-1)
 
@@ -407,7 +409,7 @@ def main():
                              "launches": n_blocks, "avg_launch_us": region_ms * 1e3 / n_blocks, "traffic": None,
                              "note": "one 'launch' = one exchange (three kernels + two all-to-alls); HIP events over the timed region"},
                 "detail": {"steps_per_exchange": S, "exchanges": n_blocks, "segment_capacity": table.capacity(min(S, K) * B),
-                           "cap_factor": args.cap_factor, "bytes_on_wire_per_lookup": 8 + H,
+                           "cap_factor": args.cap_factor, "bytes_on_wire_per_lookup": 8 + H, "local_fast": bool(args.local_fast),
                            "region_ms_hip_events": region_ms, "us_per_step_hip_events": region_ms * 1e3 / K,
                            "overflowed_lookups": 0}}
 

@@ -19,6 +19,14 @@ take no sizes from the device and a step contains NO host synchronisation (tests
 torch.cuda.set_sync_debug_mode("error")).  capacity = B (the default) can never overflow; a tighter
 `cap_factor` (bench.py) drops lookups of an overfull segment (NaN) and records it in `overflow` for the caller.
 
+`ShardedEmbeddingTable` shards the D-wide tables themselves (item / user embedding tables, big slsh bucket tables): the
+owner gathers the rows it holds and the D-wide rows DO cross the links -- there is nothing smaller to send when the row
+is the answer -- for BPR's in-vocabulary gather, the knn aggregate and the full-catalogue top-k (per-shard fused top-k
+with global item numbers + `merge_topk`).  Lookups that the requester owns itself never enter an exchange (local fast
+path): `ShardedEmbeddingTable.gather` serves them from its own block inside the same splice kernel, and
+`ShardedLSHTable.embed_score(..., local_fast=True)` answers them with the fused single-GPU kernel while the exchange of the
+remote ones is in flight.
+
 `LshPipeline` issues consecutive steps software-pipelined so that both exchanges of a step hide under the kernels of
 its neighbours.  The local compute is injectable (`prims`): the CPU tests (gloo, world 2) run the exchange logic
 with the oracle in its place; the product default is the HIP kernels and nothing else.
@@ -65,7 +73,33 @@ class HipPrims:
     @staticmethod
     def gather_rows(idx, table):
         from . import ops
+        if table.shape[0] == 0:  # a rank that owns nothing answers NaN rows (it is never asked for a valid one)
+            return torch.full((idx.numel(), table.shape[1]), float("nan"), dtype=torch.float32, device=idx.device)
         return ops.gather_rows(idx, table)
+
+    @staticmethod
+    def splice(key, slot, table_local, back):
+        """out[b] = table_local[key[b]] where 0 <= key[b] < n_local (the requester's own rows), else back[slot[b]] (the
+        owners' answers), NaN where neither exists: mi_oov_splice_rows with the answers in the place of the OOV rows."""
+        from . import ops
+        return ops._splice_forward(key, slot, table_local, back)
+
+    @staticmethod
+    def gather_mean(rows, g):
+        """mean over consecutive groups of g rows, summed in position order (the knn aggregate on gathered rows)."""
+        from . import ops
+        idx = torch.arange(rows.shape[0], dtype=torch.int64, device=rows.device)
+        return ops.gather_mean(idx, rows, g)
+
+    @staticmethod
+    def score_topk(U, E_local, k, n_skip_low):
+        from . import ops
+        return ops.score_topk(U, E_local, k, n_skip_low)
+
+    @staticmethod
+    def lsh_embed_score(ids_local, feat_local, planes, buckets, other, score_out=None):
+        from . import ops
+        return ops.lsh_embed_score(ids_local, feat_local, planes, buckets, other, score_out=score_out)
 
 
 def _backend(group):
@@ -185,10 +219,25 @@ class ShardedLSHTable(_ShardedBase):
         self.owner(p, planes)
         return self.finish(p, buckets)[1]
 
-    def embed_score(self, ids, planes, buckets, other, score_out=None):
-        p = self.begin(ids)
+    def embed_score(self, ids, planes, buckets, other, score_out=None, local_fast=False):
+        """local_fast: lookups whose row this rank owns skip both collectives -- they are answered by the fused
+        single-GPU kernel on the local block (ids outside it give NaN there and are filled in from the exchange), which
+        runs while the ids of the remote lookups are on the wire; remote and local answers are the same arithmetic on the
+        same bits, so the result is unchanged.  1 / world of a uniform batch is local."""
+        if not local_fast or self.hi == self.lo:
+            p = self.begin(ids)
+            self.owner(p, planes)
+            return self.finish(p, buckets, other, want_emb=False, score_out=score_out)[0]
+        local = (ids >= self.lo) & (ids < self.hi)
+        p = self.begin(torch.where(local, torch.full_like(ids, -1), ids), async_op=_backend(self.group) == "nccl")
+        sc_local = self.prims.lsh_embed_score(ids - self.lo, self.feat_local, planes, buckets, other)  # NaN off the block
         self.owner(p, planes)
-        return self.finish(p, buckets, other, want_emb=False, score_out=score_out)[0]
+        sc = self.finish(p, buckets, other, want_emb=False)[0]
+        out = torch.where(local, sc_local, sc)
+        if score_out is not None:
+            score_out.copy_(out)
+            return score_out
+        return out
 
 
 class LshPipeline:
@@ -207,8 +256,14 @@ class LshPipeline:
     are recorded on the stream that reads them (torch's allocator then keeps their memory until that stream has
     passed); the caller's stream waits for all three at the end of `run`."""
 
-    def __init__(self, table, planes, buckets, streams=None):
+    def __init__(self, table, planes, buckets, streams=None, local_fast=False):
+        """local_fast: the lookups of a step whose row this rank owns (1 / world of a uniform batch) skip both collectives:
+        they are masked out of the exchange and scored by the fused single-GPU kernel on the local block (issued with
+        the step's bucketing, so it runs while the remote ids travel); the requester stage selects per lookup.  Same
+        arithmetic on the same bits either way.  The fused kernel walks the WHOLE batch to find its share, so this pays
+        in latency (a short run is one serial chain of exchanges), not in throughput."""
         self.table, self.planes, self.buckets = table, planes, buckets
+        self.local_fast = bool(local_fast) and table.hi > table.lo
         dev = table.feat_local.device
         if streams is None:
             streams = dev.type == "cuda" and _backend(table.group) == "nccl"
@@ -219,18 +274,30 @@ class LshPipeline:
         t_, n = self.table, len(ids)
         if n == 0:
             return
+        def begin_step(t):
+            if not self.local_fast:
+                return t_.begin(ids[t], async_op=True), None, None
+            local = (ids[t] >= t_.lo) & (ids[t] < t_.hi)
+            p = t_.begin(torch.where(local, torch.full_like(ids[t], -1), ids[t]), async_op=True)
+            return p, local, t_.prims.lsh_embed_score(ids[t] - t_.lo, t_.feat_local, self.planes, self.buckets, others[t])
+
+        def finish_step(p, local, sc_local, t):
+            t_.finish(p, self.buckets, others[t], want_emb=False, score_out=scores[t])
+            if local is not None:
+                torch.where(local, sc_local, scores[t], out=scores[t])
+
         if self.streams is None:
-            pend = [t_.begin(ids[t], async_op=True) for t in range(min(2, n))]
+            pend = [begin_step(t) for t in range(min(2, n))]
             prev = None
             for t in range(n):
-                p = pend.pop(0)
-                t_.owner(p, self.planes, async_op=True)
+                st = pend.pop(0)
+                t_.owner(st[0], self.planes, async_op=True)
                 if prev is not None:
-                    t_.finish(prev[0], self.buckets, others[prev[1]], want_emb=False, score_out=scores[prev[1]])
+                    finish_step(*prev)
                 if t + 2 < n:
-                    pend.append(t_.begin(ids[t + 2], async_op=True))
-                prev = (p, t)
-            t_.finish(prev[0], self.buckets, others[prev[1]], want_emb=False, score_out=scores[prev[1]])
+                    pend.append(begin_step(t + 2))
+                prev = (*st, t)
+            finish_step(*prev)
             return
         s_bucket, s_owner, s_req = self.streams
         caller = torch.cuda.current_stream(t_.feat_local.device)
@@ -239,31 +306,35 @@ class LshPipeline:
 
         def begin(t):
             with torch.cuda.stream(s_bucket):
-                return t_.begin(ids[t], async_op=True)
+                return begin_step(t)
 
         def owner(p):
             with torch.cuda.stream(s_owner):
                 p.recv.record_stream(s_owner)  # allocated on the bucket stream, read here
                 t_.owner(p, self.planes, async_op=True)
 
-        def finish(p, t):
+        def finish(p, local, sc_local, t):
             with torch.cuda.stream(s_req):
                 p.slot.record_stream(s_req)  # bucket stream -> here
                 t_._wait(p.w_back)
                 p.w_back = None
                 p.back.record_stream(s_req)  # owner stream -> here
-                t_.finish(p, self.buckets, others[t], want_emb=False, score_out=scores[t])
+                if local is not None:
+                    s_req.wait_stream(s_bucket)  # the local share was scored on the bucket stream
+                    local.record_stream(s_req)
+                    sc_local.record_stream(s_req)
+                finish_step(p, local, sc_local, t)
 
         pend = [begin(t) for t in range(min(2, n))]
         prev = None
         for t in range(n):
-            p = pend.pop(0)
-            owner(p)
+            st = pend.pop(0)
+            owner(st[0])
             if prev is not None:
                 finish(*prev)
             if t + 2 < n:
                 pend.append(begin(t + 2))
-            prev = (p, t)
+            prev = (*st, t)
         finish(*prev)
         for s in self.streams:  # results (and the overflow counter) are visible to the caller's stream
             caller.wait_stream(s)
@@ -331,19 +402,81 @@ class ShardedSLSHTable(_ShardedBase):
         return self.prims.gather_rows(local, self.window), idx
 
 
+class ShardedEmbeddingTable(_ShardedBase):
+    """The local block of a row-sharded [N, D] embedding table: `item_embedding.weight` / `user_embedding.weight` of BPR
+    (bpr.py:77-81,103-125), the table the knn aggregate averages over (knn_embedder.py:117-147), a bucket table too big to
+    replicate.  table_local: float32[hi-lo, D], rows [lo, hi) of the global table.
+
+        gather(ids)            == ops.gather_rows(ids, table)            rows are copies: identical bits, NaN off the table
+        gather_mean(idx, g)    == ops.gather_mean(idx, table, g)         same sums in the same order on the gathered rows
+        topk(U, k, n_skip_low) == ops.score_topk(U, table, k, n_skip_low)  per-shard fused top-k + merge, users replicated
+
+    The D-wide row is the answer, so D * 4 bytes per REMOTE lookup cross the links on the way back (8 on the way out);
+    lookups this rank owns are served from its block by the same splice kernel that places the remote answers and never
+    enter the exchange."""
+
+    def __init__(self, table_local, n_rows_global, group=None, prims=None, cap_factor=None, max_batch=None,
+                 uniform_batches=False):
+        super().__init__(table_local, n_rows_global, group, prims, cap_factor, max_batch, uniform_batches)
+        self.table_local = table_local
+
+    def gather(self, ids):
+        ids = ids.reshape(-1)
+        local = (ids >= self.lo) & (ids < self.hi)
+        p = self.begin(torch.where(local, torch.full_like(ids, -1), ids))  # local lookups are not sent anywhere
+        self._wait(p.w_ids)
+        rows = self.prims.gather_rows(p.recv.view(-1), self.table_local)   # NaN rows for the -1 padding
+        self._reply(p, rows.view(self.world, -1), False)
+        self._wait(p.w_back)
+        # own rows by key = id - lo (anything else keyed past the block), remote ones by slot; one kernel for both
+        key = torch.where(local, ids - self.lo, torch.full_like(ids, self.hi - self.lo))
+        return self.prims.splice(key, p.slot.to(torch.int64), self.table_local, p.back.view(-1, self.table_local.shape[1]))
+
+    def gather_mean(self, idx, g=2):
+        """vstack(chunk.mean(0) for chunk in W[idx.ravel()].split(g)) over the sharded W: the rows are gathered through the
+        exchange and averaged on the requester in position order -- what the owner could pre-add (two neighbours of one
+        lookup in one shard, 1 / world of the pairs) is not worth a second record format."""
+        return self.prims.gather_mean(self.gather(idx.reshape(-1)), g)
+
+    def topk(self, U, k, n_skip_low=0):
+        """Per-row top-k of U @ table.T over the sharded catalogue: U replicated on every rank (all_gather it first if the
+        user batch itself is split), each rank runs the fused top-k on its block -- the [B, N] scores exist nowhere --
+        and the [B, k] candidates with GLOBAL row numbers are merged (larger score first, ties to the lower row)."""
+        n_local = self.hi - self.lo
+        skip = min(max(int(n_skip_low) - self.lo, 0), n_local)
+        kk = min(k, n_local)
+        vals = torch.full((U.shape[0], k), float("-inf"), dtype=torch.float32, device=U.device)
+        idx = torch.full((U.shape[0], k), -1, dtype=torch.int64, device=U.device)
+        if kk > 0:
+            v, i = self.prims.score_topk(U, self.table_local, kk, skip)
+            vals[:, :kk] = v
+            idx[:, :kk] = torch.where(i >= 0, i + self.lo, i)
+        return merge_topk(vals, idx, k, self.group)
+
+
 def merge_topk(vals, idx, k, group=None):
     """Full-catalogue scoring over an item-sharded table: every rank holds its local top-k
     (vals, idx with GLOBAL item numbers) for the same replicated users; all_gather the [B,k]
     candidates and keep the k best (larger value first, ties to the lower item id)."""
     world = dist.get_world_size(group)
-    gv = [torch.empty_like(vals) for _ in range(world)]
-    gi = [torch.empty_like(idx) for _ in range(world)]
-    dist.all_gather(gv, vals.contiguous(), group=group)
-    dist.all_gather(gi, idx.contiguous(), group=group)
+    if vals.is_cuda and _backend(group) != "nccl":  # gloo rehearsal on a device: through the host
+        hv = [torch.empty(vals.shape, dtype=vals.dtype) for _ in range(world)]
+        hi_ = [torch.empty(idx.shape, dtype=idx.dtype) for _ in range(world)]
+        dist.all_gather(hv, vals.cpu().contiguous(), group=group)
+        dist.all_gather(hi_, idx.cpu().contiguous(), group=group)
+        gv, gi = [t.to(vals.device) for t in hv], [t.to(idx.device) for t in hi_]
+    else:
+        gv = [torch.empty_like(vals) for _ in range(world)]
+        gi = [torch.empty_like(idx) for _ in range(world)]
+        dist.all_gather(gv, vals.contiguous(), group=group)
+        dist.all_gather(gi, idx.contiguous(), group=group)
     v = torch.cat(gv, dim=1)
     i = torch.cat(gi, dim=1)
+    # (-inf, -1) fillers of shards with fewer than k admissible rows go behind every real candidate, -inf ones included
+    i = torch.where(i < 0, torch.full_like(i, 1 << 62), i)
     # sort by (value desc, index asc): stable sort on index first, then stable sort on value
     o1 = torch.argsort(i, dim=1, stable=True)
     v, i = torch.gather(v, 1, o1), torch.gather(i, 1, o1)
     o2 = torch.argsort(v, dim=1, descending=True, stable=True)
-    return torch.gather(v, 1, o2)[:, :k], torch.gather(i, 1, o2)[:, :k]
+    v, i = torch.gather(v, 1, o2)[:, :k], torch.gather(i, 1, o2)[:, :k]
+    return v, torch.where(i == (1 << 62), torch.full_like(i, -1), i)

@@ -663,3 +663,50 @@ def test_driver_evaluate_queues_its_batches(mi, dev):
     assert len(res["per_batch"][1]) > 5 and max(res["per_batch"][1]) <= 5000
     assert len(res["pairs"][1]) < len(res["per_batch"][1])
     assert "overall" in res["queued"][0] and "new_users" in res["queued"][0]
+
+
+def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkeypatch):
+    """'fdhe' pinned on the REAL FeatDeepHashEmbedder (tests/golden/make_golden_fdhe.py; feat_dh_embedder.py:86-210): the
+    feature matrices the constructor builds (per-column L2 normalisation), the hash matrix of the UN-stripped ids
+    (identical integers), the MLP input (hashes ++ feature row of the STRIPPED id), pre-sigmoid activations within the
+    GEMM tolerance used for dhe (raw hashes up to 1.6e7 feed the first Linear un-normalised), outputs within 1e-5;
+    hidden width dhe_layer_size = 96, eval and train mode (prime-padded ids), the caller's id tensor left untouched."""
+    z = golden("fdhe.npz")
+    K, D, L, n = (int(v) for v in z["dims"])
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("hash_keys")
+    json.dump([bytes(k).hex() for k in z["keys"]], open(f"hash_keys/{K}.hashes", "w"))  # the reference's key file protocol
+    ft_u = mi.FeatureTable({"user_id": torch.arange(n), "age": torch.from_numpy(z["user_age"]), "vec": torch.from_numpy(z["user_vec"])})
+    ft_i = mi.FeatureTable({"item_id": torch.arange(n), "year": torch.from_numpy(z["item_year"]), "genre": torch.from_numpy(z["item_genre"])})
+    emb = mi.FeatDeepHashEmbedder(ft_u, ft_i, 40, 40, 8, 8, D, dev, PRIME_PAD, K, L)
+    assert emb.user_hash_net[0].weight.shape == (L, K + 6) and emb.item_hash_net[2].weight.shape == (L, L)
+    assert np.allclose(emb.user_feature_mat.cpu().numpy(), z["user_feature_mat"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(emb.item_feature_mat.cpu().numpy(), z["item_feature_mat"], rtol=1e-6, atol=1e-7)
+    sd = emb.state_dict()
+    for k in z.files:
+        if k.startswith("sd__"):
+            name = k[4:].replace("__", ".")
+            assert name in sd and tuple(sd[name].shape) == z[k].shape, name  # the reference's checkpoint keys
+            sd[name] = T(z[k], dev)
+    emb.load_state_dict(sd)
+    for mode in ("eval", "train"):
+        emb.set_train() if mode == "train" else emb.set_eval()
+        ids = T(z[f"ids_{mode}"], dev)
+        for side in ("user", "item"):
+            keep = ids.clone()
+            with torch.no_grad():
+                out = emb.embed_user_ids(ids, None) if side == "user" else emb.embed_item_ids(ids, None)
+                hashes = emb._hash_ids(ids)
+                net = emb.user_hash_net if side == "user" else emb.item_hash_net
+                fm = emb.user_feature_mat if side == "user" else emb.item_feature_mat
+                x = torch.hstack((hashes, mi.ops.gather_rows(emb._lookup(ids), fm)))
+                pre = x
+                layers = mi.ops._hash_net_layers(net)
+                for j, (lin, act) in enumerate(layers):  # this library's GEMM, the last activation left off
+                    pre = mi.ops.linear_act(pre, lin.weight, lin.bias, act if j + 1 < len(layers) else None)
+            assert torch.equal(ids, keep)  # fdhe strips a COPY (feat_dh_embedder.py:182-185)
+            assert np.array_equal(hashes.cpu().numpy(), z[f"{mode}_{side}_hashes"])
+            assert np.allclose(x.cpu().numpy(), z[f"{mode}_{side}_input"], rtol=1e-6, atol=1e-7)
+            ref = z[f"{mode}_{side}_pre_sigmoid"]
+            assert np.abs(pre.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), (mode, side)
+            assert np.abs(out.cpu().numpy() - z[f"{mode}_{side}_out"]).max() <= 1e-5, (mode, side)

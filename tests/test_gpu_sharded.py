@@ -134,6 +134,34 @@ def test_sharded_world1_rccl_matches_unsharded_and_never_syncs(rccl_world1, ops,
     table.check_overflow()
 
 
+def test_sharded_embedding_table_world1_rccl(rccl_world1, ops, dev):
+    """ShardedEmbeddingTable through real RCCL collectives (one rank: everything is local, the exchange carries padding
+    only): gather, the knn aggregate, the full-catalogue top-k and the lsh local fast path equal the unsharded kernels."""
+    from mi_oov import sharded
+    rng = np.random.default_rng(2)
+    N, B, D = 30_001, 3000, 64
+    W = T(rng.standard_normal((N, D), dtype=np.float32), dev)
+    ids_np = rng.integers(0, N, size=B).astype(np.int64)
+    ids_np[1], ids_np[2] = -4, N
+    ids = T(ids_np, dev)
+    tab = sharded.ShardedEmbeddingTable(W, N, max_batch=2 * B)
+    assert bits_equal(tab.gather(ids).cpu().numpy(), ops.gather_rows(ids, W).cpu().numpy())
+    idx2 = T(rng.integers(0, N, size=(B, 2)).astype(np.int64), dev)
+    assert bits_equal(tab.gather_mean(idx2, 2).cpu().numpy(), ops.gather_mean(idx2, W, 2).cpu().numpy())
+    U = T(rng.standard_normal((200, D), dtype=np.float32), dev)
+    gv, gi = tab.topk(U, 20, 1)
+    wv, wi = ops.score_topk(U, W, 20, 1)
+    assert torch.equal(gi, wi) and torch.equal(gv, wv)
+    feat = T(rng.standard_normal((N, 64), dtype=np.float32), dev)
+    planes = T(rng.standard_normal((8, 64), dtype=np.float32), dev)
+    buckets = T(rng.standard_normal((8, 64), dtype=np.float32), dev)
+    other = T(rng.standard_normal((B, 64), dtype=np.float32), dev)
+    lt = sharded.ShardedLSHTable(feat, N, max_batch=B)
+    want = ops.lsh_embed_score(ids, feat, planes, buckets, other)
+    assert bits_equal(lt.embed_score(ids, planes, buckets, other, local_fast=True).cpu().numpy(), want.cpu().numpy())
+    tab.check_overflow()
+
+
 def _rank_worker(rank, world, port, ret):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -180,6 +208,32 @@ def _rank_worker(rank, world, port, ret):
             fails.append("slsh idx")
         if not torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want, 7.0)):
             fails.append("slsh rows")
+        # row e': the D-wide tables sharded -- BPR's in-vocabulary gather, the knn aggregate, the sharded full-catalogue
+        # top-k on the HIP kernels per shard, and the lsh exchange with the local share served by the fused kernel
+        et = sharded.ShardedEmbeddingTable(big[blo:bhi].contiguous(), NB)
+        if not torch.equal(torch.nan_to_num(et.gather(ids), 7.0), torch.nan_to_num(ops.gather_rows(ids, big), 7.0)):
+            fails.append("embedding gather")
+        idx2 = torch.randint(0, NB, (B // 4, 2), generator=gr, device=dev)
+        if not torch.equal(et.gather_mean(idx2, 2), ops.gather_mean(idx2, big, 2)):
+            fails.append("embedding gather_mean")
+        items = torch.randn((120_000, 64), generator=g, device=dev)
+        items[100_000] = items[5]  # a tie across shards
+        ilo, ihi, _ = sharded.shard_bounds(items.shape[0], world, rank)
+        it = sharded.ShardedEmbeddingTable(items[ilo:ihi].contiguous(), items.shape[0])
+        U = torch.randn((512, 64), generator=g, device=dev)  # users replicated
+        gv, gi = it.topk(U, 20, 1)
+        wv, wi = ops.score_topk(U, items, 20, 1)
+        if not (torch.equal(gi, wi) and torch.equal(gv, wv)):
+            fails.append("sharded top-k")
+        lt = sharded.ShardedLSHTable(feat[lo:hi].contiguous(), N, max_batch=B)
+        got = lt.embed_score(ids, planes, buckets, other, local_fast=True)
+        if not torch.equal(torch.nan_to_num(got, 7.0), torch.nan_to_num(want_score, 7.0)):
+            fails.append("lsh local fast path")
+        sc = [torch.empty((B,), device=dev) for _ in range(3)]
+        sharded.LshPipeline(lt, planes, buckets, local_fast=True).run([ids] * 3, [other] * 3, sc)
+        for s_ in sc:
+            if not torch.equal(torch.nan_to_num(s_, 7.0), torch.nan_to_num(want_score, 7.0)):
+                fails.append("lsh pipeline local fast path")
         torch.cuda.synchronize()
         ret[rank] = fails
     finally:

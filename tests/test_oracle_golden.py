@@ -161,3 +161,22 @@ def test_lsh_backward_oracle_matches_autograd(oracle):
     bt = torch.from_numpy(bits).float()
     ((bt @ W) / bt.sum(1, keepdim=True) * torch.from_numpy(g)).sum().backward()
     assert torch.isnan(W.grad).all() and np.isnan(oracle.lsh_embed_backward(bits, g)).all()
+
+
+def test_fdhe_hashes_of_unstripped_ids(golden, oracle):
+    """'fdhe' (feat_dh_embedder.py:180-206): the hashes are SipHash-2-4 of the UN-stripped id (prime pad included) mod
+    2^24 -- the oracle's restatement against the reference's own _hash_ids on the fixture's train-mode ids -- and the MLP
+    input is those K hashes followed by the feature row of the STRIPPED id."""
+    z = golden("fdhe.npz")
+    K = int(z["dims"][0])
+    for mode in ("eval", "train"):
+        ids = z[f"ids_{mode}"]
+        want = z[f"{mode}_user_hashes"]
+        assert np.array_equal(oracle.siphash24_mod(ids, z["keys"]), want)
+        assert np.array_equal(z[f"{mode}_item_hashes"], want)  # both sides hash the id with the same keys
+        stripped = np.where(ids >= 112062759511, ids - 112062759511, ids)
+        for side in ("user", "item"):
+            x = z[f"{mode}_{side}_input"]
+            assert np.array_equal(x[:, :K], want)
+            assert np.array_equal(x[:, K:], z[f"{side}_feature_mat"][stripped])
+    assert (z["ids_train"] >= 112062759511).sum() == 4

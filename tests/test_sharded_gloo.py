@@ -67,6 +67,104 @@ class OraclePrims:
         return torch.from_numpy(out)
 
 
+    @staticmethod
+    def splice(key, slot, table_local, back):
+        k, sl, tl, bk = key.numpy(), slot.numpy(), table_local.numpy(), back.numpy()
+        out = np.full((len(k), bk.shape[1]), np.nan, np.float32)
+        own = (k >= 0) & (k < tl.shape[0])
+        out[own] = tl[k[own]]
+        rem = ~own & (k >= tl.shape[0]) & (sl >= 0) & (sl < bk.shape[0])
+        out[rem] = bk[sl[rem]]
+        return torch.from_numpy(out)
+
+    @staticmethod
+    def gather_mean(rows, g):
+        from oracle import oov_oracle as oracle
+        r = rows.numpy()
+        return torch.from_numpy(oracle.gather_mean(np.arange(r.shape[0], dtype=np.int64), r, g))
+
+    @staticmethod
+    def score_topk(U, E_local, k, n_skip_low):
+        from oracle import oov_oracle as oracle
+        v, i = oracle.score_topk(U.numpy(), E_local.numpy(), k, n_skip_low)
+        return torch.from_numpy(v), torch.from_numpy(i)
+
+    @staticmethod
+    def lsh_embed_score(ids_local, feat_local, planes, buckets, other, score_out=None):
+        from oracle import oov_oracle as oracle
+        sc, _ = oracle.lsh_embed_score(ids_local.numpy(), feat_local.numpy(), planes.numpy(), buckets.numpy(), other.numpy())
+        return torch.from_numpy(sc)
+
+
+def _check_embedding_table(sharded, oracle, rank, world, chk, seed=0):
+    """ShardedEmbeddingTable (row e'): D-wide gathers, the knn aggregate and the sharded full-catalogue top-k against the
+    unsharded oracle, on every rank with its own ids; plus the local fast path of the lsh exchange."""
+    T = torch.from_numpy
+    rng = np.random.default_rng(100 + seed)  # same tables on every rank
+    N, D = 1003, 20
+    W = rng.standard_normal((N, D), dtype=np.float32)
+    W[5] = -0.0  # bits must survive the wire
+    lo, hi, _ = sharded.shard_bounds(N, world, rank)
+    tab = sharded.ShardedEmbeddingTable(T(W[lo:hi].copy()), N, prims=OraclePrims)
+    r = np.random.default_rng(200 + rank)
+    cases = {
+        "ragged": r.integers(0, N, size=150 + 61 * rank),
+        "all_local": r.integers(lo, max(lo + 1, hi), size=40) if hi > lo else np.zeros((0,), np.int64),
+        "all_remote": r.integers(0, N, size=300),
+        "edges": np.array([0, lo, max(lo, hi - 1), hi % N, N - 1, N, -1, 5, 5]),
+        "empty": np.zeros((0,), np.int64) if rank == 0 else np.arange(0, N, 13),
+    }
+    cases["all_remote"] = cases["all_remote"][(cases["all_remote"] < lo) | (cases["all_remote"] >= hi)][:120]
+    n_remote = len(cases["all_remote"])
+    sizes = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([n_remote]))
+    for name, ids in cases.items():
+        ids = ids.astype(np.int64)
+        chk(f"gather {name}", _same(tab.gather(T(ids)).numpy().view(np.uint32), oracle.gather_rows(ids, W).view(np.uint32)))
+        for g in (2, 3):
+            m = len(ids) // g * g if name != "ragged" else len(ids)  # ragged keeps a short last group
+            chk(f"gather_mean {name} g={g}", _same(tab.gather_mean(T(ids[:m]), g).numpy(), oracle.gather_mean(ids[:m], W, g)))
+    chk("emb overflow", int(tab.overflow) == 0)
+    # sharded full-catalogue top-k: users replicated, ties across shards, padding column skipped, NaN score first
+    U = rng.standard_normal((11, D), dtype=np.float32)
+    E = W.copy()
+    E[N - 2] = E[3]  # a tie across the first and the last shard -> the lower global row wins
+    E[7, 0] = np.nan
+    tabE = sharded.ShardedEmbeddingTable(T(E[lo:hi].copy()), N, prims=OraclePrims)
+    for k, skip in ((5, 0), (5, 1), (20, 1), (3, 400)):
+        gv, gi = tabE.topk(T(U), k, skip)
+        wv, wi = oracle.score_topk(U, E, k, skip)
+        chk(f"topk k={k} skip={skip}", np.array_equal(gi.numpy(), wi) and _same(gv.numpy(), wv))
+    # a catalogue smaller than k * world: shards with fewer than k rows pad with (-inf, -1)
+    small = sharded.ShardedEmbeddingTable(T(E[:7][slice(*sharded.shard_bounds(7, world, rank)[:2])].copy()), 7, prims=OraclePrims)
+    gv, gi = small.topk(T(U), 5, 1)
+    wv, wi = oracle.score_topk(U, E[:7], 5, 1)
+    chk("topk tiny catalogue", np.array_equal(gi.numpy(), wi) and _same(gv.numpy(), wv))
+    # lsh: lookups this rank owns skip the exchange (fused kernel on the local block), same scores
+    F, H = 12, 5
+    feat = rng.standard_normal((N, F), dtype=np.float32)
+    planes = rng.standard_normal((H, F), dtype=np.float32)
+    buckets = rng.standard_normal((H, D), dtype=np.float32)
+    lt = sharded.ShardedLSHTable(T(feat[lo:hi].copy()), N, prims=OraclePrims)
+    for name, ids in cases.items():
+        ids = ids.astype(np.int64)
+        other = np.random.default_rng(300 + rank).standard_normal((len(ids), D), dtype=np.float32)
+        want = oracle.lsh_embed_score(ids, feat, planes, buckets, other)[0]
+        got = lt.embed_score(T(ids), T(planes), T(buckets), T(other), local_fast=True).numpy()
+        chk(f"lsh local_fast {name}", _same(got, want))
+        buf = torch.empty(len(ids))
+        lt.embed_score(T(ids), T(planes), T(buckets), T(other), score_out=buf, local_fast=True)
+        chk(f"lsh local_fast score_out {name}", _same(buf.numpy(), want))
+    # the pipelined steps with the local share on the fused kernel
+    r3 = np.random.default_rng(400 + rank)
+    ids_l = [r3.integers(-2, N + 2, size=90).astype(np.int64) for _ in range(4)]
+    oth_l = [r3.standard_normal((90, D), dtype=np.float32) for _ in range(4)]
+    sc_l = [torch.empty(90) for _ in range(4)]
+    sharded.LshPipeline(lt, T(planes), T(buckets), local_fast=True).run([T(i) for i in ids_l], [T(o) for o in oth_l], sc_l)
+    for t in range(4):
+        chk(f"pipeline local_fast step {t}", _same(sc_l[t].numpy(), oracle.lsh_embed_score(ids_l[t], feat, planes, buckets, oth_l[t])[0]))
+
+
 def _same(a, b):
     a, b = np.asarray(a), np.asarray(b)
     return a.shape == b.shape and np.array_equal(np.nan_to_num(a, nan=7.0), np.nan_to_num(b, nan=7.0))
@@ -173,6 +271,7 @@ def _worker(rank, world, port, ret):
         mv, mi = sharded.merge_topk(T(lv), T(li + lo), k)
         wv, wi = oracle.score_topk(U, E, k)
         chk(159, np.array_equal(mi.numpy(), wi) and np.array_equal(mv.numpy(), wv))
+        _check_embedding_table(sharded, oracle, rank, world, chk)
         ret[rank] = fails
     finally:
         dist.destroy_process_group()
@@ -238,6 +337,7 @@ def _worker_odd(rank, world, port, ret):
             want, widx = oracle.slsh_embed(ids, feat, planes_s, bigt)
             if not (np.array_equal(gidx.numpy(), widx) and _same(got.numpy(), want)):
                 fails.append(f"slsh {name}")
+        _check_embedding_table(sharded, oracle, rank, world, lambda line, cond: cond or fails.append(line), seed=1)
         ret[rank] = fails
     finally:
         dist.destroy_process_group()
