@@ -1568,9 +1568,15 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
     const int ns = sl.ns, cap = sl.cap;  // ns <= 128, cap a power of two, ns * cap <= kStripSlots
     const int cap_shift = __builtin_ctz(cap);
     // the lists' lengths and their offsets in the gathered array
-    const int c0 = lane < ns ? sl.cnt[static_cast<int64_t>(row) * ns + lane] : 0;
-    const int c1 = lane + 64 < ns ? sl.cnt[static_cast<int64_t>(row) * ns + lane + 64] : 0;
-    const int oc_raw = sl.ovf_cnt[row];
+    // (counts are clamped to their lists' capacities HERE as well as where they are written: every address this kernel
+    //  forms from workspace contents then stays inside the workspace whatever those contents are -- a filter pass that
+    //  did not write a counter, as a development build of it once did not ("the fault of record"),
+    //  costs wrong candidates and the exact fallback, never an access outside the buffers)
+    auto clamp_cnt = [&](int c) { return c < 0 ? 0 : (c > cap ? cap : c); };
+    const int c0 = lane < ns ? clamp_cnt(sl.cnt[static_cast<int64_t>(row) * ns + lane]) : 0;
+    const int c1 = lane + 64 < ns ? clamp_cnt(sl.cnt[static_cast<int64_t>(row) * ns + lane + 64]) : 0;
+    int oc_raw = sl.ovf_cnt[row];
+    oc_raw = oc_raw < 0 ? kOvfCap + 1 : oc_raw;  // (a negative count can only be garbage: exact fallback)
     const int i0 = wave_incl_scan(c0, lane), t0 = __shfl(i0, 63, 64);
     const int i1 = wave_incl_scan(c1, lane), t1 = __shfl(i1, 63, 64);
     lcnt[lane] = c0;
@@ -1653,6 +1659,10 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
         if (i < m) {
           const uint32_t inv = static_cast<uint32_t>(lc[i]);
           float acc = 0.f;
+          if (static_cast<int64_t>(0xFFFFFFFFu - inv) >= N) {  // no such column (a list entry the filter pass never wrote:
+            lc[i] = 0;                                          // see clamp_cnt above): ranked below every real key
+            continue;
+          }
           if (D == 64) {
             const float4* e4 = reinterpret_cast<const float4*>(E + static_cast<int64_t>(0xFFFFFFFFu - inv) * 64);
             float4 ev[16];

@@ -954,3 +954,32 @@ def test_slsh_multi_and_lds_bucket_rows_vs_oracle(K, B, H, D, nb, oracle, ops, d
         assert np.array_equal(idxs[k].cpu().numpy(), o_idx)
         assert bits_equal(ops.slsh_embed(i[k], f, p, w).cpu().numpy(), o_emb)
         assert np.array_equal(ops.slsh_index(i[k], f, p, nb).cpu().numpy(), o_idx)
+
+
+@pytest.mark.parametrize("B,N,D,k,skip", [(300, 128 * 40 + 1, 64, 20, 1), (64, 128 * 129 + 1, 64, 5, 0), (130, 50_000, 22, 20, 1),
+                                          (65, 128 * 9 + 127, 64, 2, 3)])
+@pytest.mark.parametrize("poison", [0xFF, 0x7F, 0x00])
+def test_fused_topk_reads_nothing_it_has_not_written(B, N, D, k, skip, poison, oracle, ops, dev):
+    """The fused top-k's kernels form addresses from counters and candidate entries they keep in the caller's workspace
+    (list lengths, overflow counts, column numbers).  Whatever the workspace held before the call -- here every byte
+    0xFF / 0x7F / 0x00 -- the result is the oracle's: each stage overwrites what the next one reads, on shapes whose last
+    128-row block of the bf16 catalogue copy is one row or 127 rows full (the padding rows are written too).  The raw C
+    ABI is called so that the workspace is the test's own buffer.  (The finalize kernel additionally clamps every count
+    and column it reads: DESIGN.md section 5a, "the fault of record".)"""
+    from mi_oov import _cabi as C
+    lib = C.lib()
+    rng = np.random.default_rng(B + N + k)
+    U = rng.standard_normal((B, D), dtype=np.float32)
+    E = rng.standard_normal((N, D), dtype=np.float32)
+    U_d, E_d = T(U, dev), T(E, dev)
+    need = int(lib.mi_oov_score_topk_workspace(B, N, k))
+    ws = torch.full((need + 4096,), poison, dtype=torch.uint8, device=dev)
+    vals = torch.empty((B, k), dtype=torch.float32, device=dev)
+    idx = torch.empty((B, k), dtype=torch.int64, device=dev)
+    rc = lib.mi_oov_score_topk(U_d.data_ptr(), B, E_d.data_ptr(), N, D, k, skip, vals.data_ptr(), idx.data_ptr(), ws.data_ptr(),
+                               C.stream_of(U_d))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert (ws[need:] == poison).all(), "the call wrote past the workspace size it asked for"
+    o_vals, o_idx = oracle.score_topk(U, E, k, skip)
+    assert np.array_equal(idx.cpu().numpy(), o_idx) and bits_equal(vals.cpu().numpy(), o_vals)
