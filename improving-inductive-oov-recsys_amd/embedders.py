@@ -383,6 +383,15 @@ class _HashKeyMixin:
         """[B, K] float hashes; one HIP launch instead of B*K csiphash calls (dh_embedder.py:154-170)."""
         return ops.siphash24_mod(ids, self._key_tensor(ids.device), self.MAX_HASH)
 
+    def _hash_then_net(self, ids, net, extra=None):
+        """net(hstack(hashes(ids), extra rows)) -- the dhe / fdhe forward (dh_embedder.py:191-217, feat_dh_embedder.py:164-172).
+        One SipHash launch, then the layers.  (Cutting the batch in chunks and hashing chunk c + 1 on a side stream under
+        the layers of chunk c was built and measured in round 3: 1.71 ms serial against 1.94 / 2.07 / 2.16 / 3.04 ms with
+        2 / 3 / 4 / 8 chunks at K = 1024, 65536 lookups -- the f32 matrix instruction issues at the vector rate, so the
+        integer hash and the GEMM compete for the same issue slots, and the smaller GEMMs fill the chip worse.)"""
+        h = self._hash_ids(ids)
+        return _run_hash_net(net, h if extra is None else torch.hstack((h, extra)))
+
     def __deepcopy__(self, memo):
         # device key cache is derived state: drop it so copies (get_flops deep-copies the model) stay light
         import copy
@@ -413,10 +422,10 @@ class DeepHashEmbedder(_HashKeyMixin, _FeatureEmbedder):
         self.hash_keys = self.get_hash_keys()
 
     def _hash_users(self, users):
-        return _run_hash_net(self.user_hash_net, self._hash_ids(users))
+        return self._hash_then_net(users, self.user_hash_net)
 
     def _hash_items(self, items):
-        return _run_hash_net(self.item_hash_net, self._hash_ids(items))
+        return self._hash_then_net(items, self.item_hash_net)
 
     def embed_user_ids(self, user_ids, model):
         return self._hash_users(user_ids)
@@ -449,12 +458,10 @@ class FeatDeepHashEmbedder(_HashKeyMixin, _FeatureEmbedder):
         return old_ids
 
     def _hash_users(self, users, feat_lookup_users):
-        nn_input = torch.hstack((self._hash_ids(users), ops.gather_rows(feat_lookup_users, self.user_feature_mat)))
-        return _run_hash_net(self.user_hash_net, nn_input)
+        return self._hash_then_net(users, self.user_hash_net, ops.gather_rows(feat_lookup_users, self.user_feature_mat))
 
     def _hash_items(self, items, feat_lookup_items):
-        nn_input = torch.hstack((self._hash_ids(items), ops.gather_rows(feat_lookup_items, self.item_feature_mat)))
-        return _run_hash_net(self.item_hash_net, nn_input)
+        return self._hash_then_net(items, self.item_hash_net, ops.gather_rows(feat_lookup_items, self.item_feature_mat))
 
     def embed_user_ids(self, old_user_ids, model):
         return self._hash_users(old_user_ids, self._lookup(old_user_ids))

@@ -33,6 +33,7 @@ with torch.no_grad():
     h = emb._hash_ids(ids[0])
     t_mlp = timeit(lambda i: emb.item_hash_net(h))
     t_all = timeit(lambda i: emb.embed_item_ids(ids[i], None))
+
 flop = 2 * (512 * K + 2 * 512 * 512 + 512 * D) * B
 print(json.dumps({"siphash_ms": round(t_hash, 3), "mlp_ms": round(t_mlp, 3), "embed_ms": round(t_all, 3),
                   "hashes_per_s": B * K / t_hash * 1e3, "mlp_TFLOPs": flop / t_mlp / 1e9, "lookups_per_s": B / t_all * 1e3}))
