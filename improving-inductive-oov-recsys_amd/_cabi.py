@@ -24,6 +24,7 @@ _lib = None
 
 _SIGNATURES = {
     "mi_oov_version": (ctypes.c_int, []),
+    "mi_oov_init": (ctypes.c_int, []),
     "mi_oov_strerror": (ctypes.c_char_p, [ctypes.c_int]),
     "mi_oov_last_hip_error": (ctypes.c_int, []),
     "mi_oov_lsh_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),

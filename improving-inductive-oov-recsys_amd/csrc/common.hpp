@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "mi_oov.h"
 
@@ -21,6 +22,18 @@ inline int check_launch() {
     return MI_OOV_ERR_LAUNCH;
   }
   return MI_OOV_OK;
+}
+
+// Developer knobs ("Developer knobs"): an integer from the environment, read where it is first used
+// and CLAMPED at parse time -- a value that does not parse or lies outside [lo, hi] is ignored (the default applies), so
+// no knob can push a launch parameter out of the range its kernel was written for.  Results never depend on a knob.
+inline int64_t env_knob(const char* name, int64_t dflt, int64_t lo, int64_t hi) {
+  const char* e = getenv(name);
+  if (!e || !*e) return dflt;
+  char* end = nullptr;
+  const long long v = strtoll(e, &end, 10);
+  if (end == e || *end != '\0' || v < lo || v > hi) return dflt;
+  return static_cast<int64_t>(v);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -626,10 +626,7 @@ namespace mi_oov {
 int launch_gather_mean64_persistent(const int64_t* const* idx_tab, float* const* out_tab, int64_t K, int64_t M,
                                     const float* W, int64_t N, hipStream_t st);  // lsh64p.hip
 static bool persist_movers() {
-  static const bool on = [] {
-    const char* e = getenv("MI_OOV_PERSIST_MOVERS");  // developer A/B knob: 0 = the grid-stride kernels for every width
-    return !(e && e[0] == '0');
-  }();
+  static const bool on = env_knob("MI_OOV_PERSIST_MOVERS", 1, 0, 1) != 0;  // developer A/B knob: 0 = the grid-stride kernels for every width
   return on;
 }
 }  // namespace mi_oov

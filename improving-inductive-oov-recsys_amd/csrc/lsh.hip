@@ -459,10 +459,7 @@ int launch_slsh64(const void* ids, int64_t B, int64_t K, bool tab, const float* 
                   const float* buckets, int64_t n_buckets, int64_t D, void* out, void* idx, hipStream_t st);
 
 static bool lsh64_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("MI_OOV_LSH64");  // developer A/B knob; default on
-    return !(e && e[0] == '0');
-  }();
+  static const bool on = env_knob("MI_OOV_LSH64", 1, 0, 1) != 0;  // developer A/B knob; default on
   return on;
 }
 

@@ -616,18 +616,11 @@ constexpr int64_t kCodesMinB = 262144;
 // One batch of scores from this many lookups on: the persistent, software-pipelined kernel (a wave then walks several
 // tile pairs; below, the one-tile-per-wave launch of this file is faster).  MI_OOV_PERSIST_MIN_B: developer knob.
 static int64_t persist_min_b() {
-  static const int64_t v = [] {
-    const char* e = getenv("MI_OOV_PERSIST_MIN_B");
-    const int64_t x = e ? atoll(e) : 0;
-    return x > 0 ? x : int64_t(524288);
-  }();
+  static const int64_t v = env_knob("MI_OOV_PERSIST_MIN_B", 524288, 1, int64_t(1) << 40);
   return v;
 }
 static bool codes_persistent_enabled() {
-  static const bool on = [] {
-    const char* e = getenv("MI_OOV_CODES_PERSISTENT");  // developer A/B knob; default on
-    return !(e && e[0] == '0');
-  }();
+  static const bool on = env_knob("MI_OOV_CODES_PERSISTENT", 1, 0, 1) != 0;  // developer A/B knob; default on
   return on;
 }
 

@@ -758,11 +758,27 @@ struct SchedPool {
 static SchedPool g_pools[kSchedDevices];
 static std::mutex g_pool_mutex;
 
+// The one allocation this library ever makes: kSchedSlots "busy" words (128 bytes) of pinned, device-mapped host memory
+// per device, through which the last wave of a pool-scheduled launch hands its counter set back.  Made by mi_oov_init()
+// or, when that was not called, by the first persistent launch on the device (never while a stream is being captured:
+// such launches do not use the pool).  Called with g_pool_mutex held.
+static bool init_pool_locked(SchedPool& pool) {
+  if (pool.state == 0) {
+    pool.state = -1;
+    void* host = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&pool.counters), HIP_SYMBOL(g_sched)) == hipSuccess &&
+        hipHostMalloc(&host, kSchedSlots * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+      memset(host, 0, kSchedSlots * sizeof(unsigned));
+      pool.busy = static_cast<unsigned*>(host);
+      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&pool.busy_dev), host, 0) == hipSuccess) pool.state = 1;
+    }
+    if (pool.state != 1) (void)hipGetLastError();
+  }
+  return pool.state == 1;
+}
+
 static bool pool_enabled() {
-  static const bool v = [] {
-    const char* e = getenv("MI_OOV_POOL");  // developer knob: 0 = always deal the tickets in a fixed order
-    return !(e && atoi(e) == 0);
-  }();
+  static const bool v = env_knob("MI_OOV_POOL", 1, 0, 1) != 0;  // developer knob: 0 = always deal the tickets in a fixed order
   return v;
 }
 
@@ -783,18 +799,7 @@ static SchedSlot take_sched_slot(hipStream_t st, int64_t tiles, int grid) {
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kSchedDevices) return none;
   std::lock_guard<std::mutex> lock(g_pool_mutex);
   SchedPool& pool = g_pools[dev];
-  if (pool.state == 0) {
-    pool.state = -1;
-    void* host = nullptr;
-    if (hipGetSymbolAddress(reinterpret_cast<void**>(&pool.counters), HIP_SYMBOL(g_sched)) == hipSuccess &&
-        hipHostMalloc(&host, kSchedSlots * sizeof(unsigned), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
-      memset(host, 0, kSchedSlots * sizeof(unsigned));
-      pool.busy = static_cast<unsigned*>(host);
-      if (hipHostGetDevicePointer(reinterpret_cast<void**>(&pool.busy_dev), host, 0) == hipSuccess) pool.state = 1;
-    }
-    if (pool.state != 1) (void)hipGetLastError();
-  }
-  if (pool.state != 1) return none;
+  if (!init_pool_locked(pool)) return none;
   for (int i = 0; i < kSchedSlots; ++i) {
     const unsigned s = (pool.turn + i) % kSchedSlots;
     if (__atomic_load_n(&pool.busy[s], __ATOMIC_ACQUIRE) == 0) {
@@ -831,10 +836,8 @@ static int resident_blocks(Kern kernel, size_t lds, int& cached, int max_per_cu 
 }
 
 static int grid_override() {
-  static const int v = [] {
-    const char* e = getenv("MI_OOV_MULTI_BLOCKS");  // developer knob: grid size of the persistent launches
-    return e ? atoi(e) : 0;
-  }();
+  // developer knob: grid size of the persistent launches (0 = occupancy x CUs)
+  static const int v = static_cast<int>(env_knob("MI_OOV_MULTI_BLOCKS", 0, 0, 4096));
   return v;
 }
 
@@ -967,6 +970,17 @@ int launch_lsh64_from_codes(const uint8_t* codes, int64_t M, const int32_t* slot
 }  // namespace mi_oov
 
 using namespace mi_oov;
+
+extern "C" int mi_oov_init(void) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) {
+    g_last_hip_error = static_cast<int>(hipGetLastError());
+    return MI_OOV_ERR_LAUNCH;
+  }
+  if (dev >= kSchedDevices) return MI_OOV_OK;  // (launches on such a device deal their tiles in a fixed order)
+  std::lock_guard<std::mutex> lock(g_pool_mutex);
+  return init_pool_locked(g_pools[dev]) ? MI_OOV_OK : MI_OOV_ERR_LAUNCH;
+}
 
 extern "C" int64_t mi_oov_lsh_table_bytes(int64_t H, int64_t D) {
   if (H < 1 || H > 8 || D != 64) return 0;

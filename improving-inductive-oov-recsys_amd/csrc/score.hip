@@ -124,6 +124,9 @@ __device__ __forceinline__ float epilogue(float v, float b) {
   return v;
 }
 
+#ifndef MI_FS_NT
+#define MI_FS_NT 1
+#endif
 template <bool VEC, int EPI>
 __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __restrict__ U, int64_t B,
                                                            const float* __restrict__ E, int64_t N, int64_t D,
@@ -267,7 +270,13 @@ __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __res
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (row < B && col < N) S[row * ldS + col] = epilogue<EPI>(acc[m][n][r], bcol);
+          if (row < B && col < N) {
+            // the [B, N] score matrix is written once and read by a later launch, if at all, long after it has left the
+            // caches (819 MB at 4096 x 50 000): non-temporal stores (MI_FS_NT=0: plain).  The layers of the hash nets
+            // keep plain stores: their 134 MB outputs are the next layer's input and are served from the Infinity Cache.
+            if (EPI == EPI_NONE && MI_FS_NT) __builtin_nontemporal_store(acc[m][n][r], &S[row * ldS + col]);
+            else S[row * ldS + col] = epilogue<EPI>(acc[m][n][r], bcol);
+          }
         }
       }
   }
@@ -872,7 +881,7 @@ extern "C" int mi_oov_segment_topk(const float* scores, const int64_t* cols, con
   if (S < 0 || k <= 0 || k > 256) return MI_OOV_ERR_SHAPE;
   if (S == 0) return MI_OOV_OK;
   if (!scores || !cols || !seg_ptr || !vals || !idx) return MI_OOV_ERR_NULL;
-  static const bool wg_kernel = [] { const char* e = getenv("MI_OOV_SEGMENT_TOPK_WG"); return e && e[0] == '1'; }();
+  static const bool wg_kernel = env_knob("MI_OOV_SEGMENT_TOPK_WG", 0, 0, 1) != 0;
   if (wg_kernel)
     hipLaunchKernelGGL(segment_topk_kernel, dim3(static_cast<unsigned>(S)), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
                        scores, cols, seg_ptr, S, static_cast<int>(k), col_lo, col_hi, vals, idx);
@@ -1809,7 +1818,7 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16) {
   const int64_t nblk = (N + BN - 1) / BN;
   // The bf16 path's passes are cheap next to its per-candidate work: stride 4-5 is its optimum (k = 20, 4096 x 50000:
   // 8 -> 124 us, 4-5 -> 106 us, 3 -> 153 us); the f32 path pays a full-rate GEMM for pass 1 and keeps 8.
-  static const int64_t env_stride = [] { const char* e = getenv("MI_OOV_TOPK_STRIDE"); return e ? atoll(e) : 0LL; }();
+  static const int64_t env_stride = env_knob("MI_OOV_TOPK_STRIDE", 0, 0, 64);
   int64_t stride = env_stride > 0 ? env_stride : (bf16 ? (k <= 32 ? 4 : 2) : 8);  // (k = 50: 2 -> 130 us, 3 -> 135 us, 4 -> 151 us)
   if (bf16 && env_stride <= 0 && k < 20) {
     // small k over a big catalogue (the knn search: k = 2, 10 M rows): ~80 candidates per row allow a wider stride, as
@@ -1875,7 +1884,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535) {
     const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
-    static const bool bf16_path = [] { const char* e = getenv("MI_OOV_TOPK_BF16"); return !(e && e[0] == '0'); }();
+    static const bool bf16_path = env_knob("MI_OOV_TOPK_BF16", 1, 0, 1) != 0;
     // the bf16 path serves rows of up to 64 floats (narrower ones are zero-padded in the bf16 copies; 64-float rows must be 16-byte aligned)
     const bool use_bf16 = (bf16_path || mask || catalogue) && (D < 64 || (D == 64 && vec));
     if ((mask || catalogue) && !use_bf16) return MI_OOV_ERR_ALIGN;  // (the entry points checked the shape; only alignment is left)
@@ -1907,8 +1916,8 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       }
       const int64_t nblk = (N + BN - 1) / BN;
       const int64_t rb = (B + BM - 1) / BM;
-      static const int64_t target = [] { const char* e = getenv("MI_OOV_STRIP_WGS"); return e ? atoll(e) : 1024LL; }();
-      static const int64_t target1 = [] { const char* e = getenv("MI_OOV_STRIP_WGS1"); return e ? atoll(e) : 768LL; }();  // pass 1: 3 workgroups per CU, one round
+      static const int64_t target = env_knob("MI_OOV_STRIP_WGS", 1024, 1, 65536);
+      static const int64_t target1 = env_knob("MI_OOV_STRIP_WGS1", 768, 1, 65536);  // pass 1: 3 workgroups per CU, one round
       auto strips = [&](int64_t nvisit, int64_t tgt, int64_t row_blocks) {  // ~tgt workgroups in all, at most 128 strips, a multiple of 8 when there are 8 blocks
         int64_t n = tgt / row_blocks;
         if (n > 128) n = 128;
@@ -1918,13 +1927,13 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
         return n > 128 ? 128 : n;
       };
       const int64_t nvisit1 = (nblk + L.stride - 1) / L.stride;
-      static const bool direct_on = [] { const char* e = getenv("MI_OOV_FILTER_DIRECT"); return !(e && e[0] == '0'); }();  // developer knob: 0 = pass 2 with LDS-staged operands
+      static const bool direct_on = env_knob("MI_OOV_FILTER_DIRECT", 1, 0, 1) != 0;  // developer knob: 0 = pass 2 with LDS-staged operands
       const bool direct = direct_on && nblk < (1 << 20);  // (a queue record has 20 bits for the block)
       // direct pass 2: workgroups of 64 user rows (2 tiles of 32: 123 registers, 4 waves per SIMD) and one round of 1024;
       // MI_OOV_FILTER_TILES=4: 128 rows, 211 registers, 2 waves per SIMD, 512 workgroups (48 us instead of 41)
-      static const int mt_env = [] { const char* e = getenv("MI_OOV_FILTER_TILES"); return e && atoi(e) == 4 ? 4 : 2; }();
+      static const int mt_env = env_knob("MI_OOV_FILTER_TILES", 2, 2, 4) == 4 ? 4 : 2;  // 2 or 4 tiles of 32 user rows
       const int mt = (B + 63) / 64 > 65535 ? 4 : mt_env;  // (grid.y)
-      static const int64_t target_env = [] { const char* e = getenv("MI_OOV_STRIP_WGS2"); return e ? atoll(e) : 0LL; }();
+      static const int64_t target_env = env_knob("MI_OOV_STRIP_WGS2", 0, 0, 65536);
       const int64_t target_d = target_env > 0 ? target_env : (mt == 2 ? 1024 : 512);
       const int64_t rbd = (B + mt * 32 - 1) / (mt * 32);
       const int64_t ns1 = strips(nvisit1, target1, rb), ns2 = direct ? strips(nblk, target_d, rbd) : strips(nblk, target, rb);
@@ -1933,7 +1942,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       {  // list capacity: a power of two >= `MI_OOV_LIST_SLACK` (2) x the expected share of ~1.3 k stride candidates per
          // row, within the finalize kernel's slots: the rare longer list continues in the row's overflow list, and a
          // smaller gathered array lets the finalize kernel keep more rows in flight
-        static const int64_t slack = [] { const char* e = getenv("MI_OOV_LIST_SLACK"); return e ? atoll(e) : 2LL; }();
+        static const int64_t slack = env_knob("MI_OOV_LIST_SLACK", 2, 1, 64);
         const int64_t want = slack * 13 * k * L.stride / 10 / ns2 + 1;
         int64_t cap = 8;
         while (cap < want && cap * 2 * ns2 <= kStripSlots) cap *= 2;

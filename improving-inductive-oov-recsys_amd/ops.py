@@ -295,6 +295,9 @@ class LshMultiScorer:
         self._idx = self.device.index
         self._fn = C.lib().mi_oov_lsh_multi
         self.persistent = self.F == 64 and self.D == 64 and 1 <= self.H <= 8
+        if self.persistent:
+            with C.on_device(self.feat):
+                C.lib().mi_oov_init()  # the library's one allocation (128 pinned bytes per device), made here, not by a launch
         self._table = LshTable(buckets) if (prepared and self.persistent) else None
 
     def run(self, q, k0=0, k=None):

@@ -10,7 +10,11 @@
  *   - every pointer is a DEVICE pointer (HBM) unless the name ends in _host;
  *   - matrices are dense row-major, float = IEEE binary32, ids = int64 (torch.long);
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls only
- *     ENQUEUE work, they never synchronise, allocate or free (graph-capture safe);
+ *     ENQUEUE work and never synchronise (graph-capture safe).  They never allocate or free
+ *     either, with ONE exception: the persistent launches (mi_oov_lsh_multi and the calls that
+ *     route to the same kernel) hand their tile-pool counters back through 128 bytes of pinned
+ *     host memory per device, allocated once -- by mi_oov_init(), or by the first such launch on
+ *     the device when mi_oov_init() was not called (never during stream capture);
  *   - return value: 0 = MI_OOV_OK, negative = error code (mi_oov_strerror); no C++
  *     exception crosses the boundary;
  *   - ids that do not address a row (id < 0 or id >= N) never fault: the row's outputs are
@@ -46,6 +50,10 @@ enum {
 };
 
 int mi_oov_version(void);
+/* Optional, once per device (the current one) before the first launch: makes the library's one allocation up front
+ * (see Conventions).  Idempotent; MI_OOV_ERR_LAUNCH if the pinned allocation fails (launches then still work: they deal
+ * their tiles in a fixed order).                                                                                  */
+int mi_oov_init(void);
 const char* mi_oov_strerror(int code);
 /* last hipError_t (as int) seen by a failing launch on this thread, 0 if none */
 int mi_oov_last_hip_error(void);

@@ -901,6 +901,7 @@ def test_lsh_multi_generic_entry_raw_cabi_errors(ops, dev):
     assert lib.mi_oov_lsh_table_prepare(buckets.data_ptr(), 9, 64, table.data_ptr(), st) == -2
     assert lib.mi_oov_lsh_table_prepare(None, 8, 64, table.data_ptr(), st) == -1
     assert lib.mi_oov_lsh_table_prepare(buckets.data_ptr(), 8, 64, table.data_ptr() + 8, st) == -5
+    assert lib.mi_oov_init() == 0 and lib.mi_oov_init() == 0  # idempotent
     torch.cuda.synchronize()
 
 

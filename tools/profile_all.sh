@@ -4,13 +4,14 @@
 # rocprofv3 --kernel-trace --stats over tools/tune.py; the summary (kernel stats + the tool's own per-case lines)
 # lands in gpurun_out/<tag>_all_kernels.json -- copy it to profiles/.
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r03}
+commit=${2:-}   # `git rev-parse --short HEAD` of the build container (the GPU box has no .git)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out
 rm -rf $out/${tag}_all_trace
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_all_trace -- python3 tools/tune.py > $out/${tag}_all_cases.log 2>&1 || { tail -5 $out/${tag}_all_cases.log; exit 2; }
 python3 tools/summarize_profile.py --trace $out/${tag}_all_trace --out $out/${tag}_all_kernels.json \
-  --command "rocprofv3 --kernel-trace --stats -- python3 tools/tune.py" > /dev/null
+  --command "rocprofv3 --kernel-trace --stats -- python3 tools/tune.py" --commit "$commit" > /dev/null
 rm -f $out/${tag}_all_trace/*/*kernel_trace.csv
 python3 - <<PY
 import json

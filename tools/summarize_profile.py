@@ -44,7 +44,10 @@ def main():
     ap.add_argument("--command", default="")
     ap.add_argument("--commit", default="")
     a = ap.parse_args()
-    out = {"command": a.command, "commit": a.commit, "kernels": [], "pmc_per_launch": {}}
+    out = {"command": a.command, "commit": a.commit, "kernels": [], "pmc_per_launch": {},
+           "resource_columns": "vgpr / sgpr / lds_bytes below are the dispatch packet's: architected VGPRs in allocation granules, STATIC "
+                               "LDS only (dynamic LDS -- the persistent kernel's table -- shows 0); the compiler's figures per kernel are "
+                               "in profiles/<round>_kernel_resources.json (tools/kernel_resources.py)"}
     tline, pline = load_line(a.trace_line), load_line(a.pmc_line)
     for ln in (tline, pline):
         if ln:
