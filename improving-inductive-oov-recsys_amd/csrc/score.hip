@@ -539,9 +539,9 @@ struct Bf16Bound {
 };
 // max_j |e_j|^2 as float bits: the callers pass the partial maxima they loaded (strided over the wave or the thread)
 __device__ __forceinline__ void bf16_threshold(const Bf16Bound& bb, int64_t row, float tauf, uint32_t e2) {
-  // + what flushing subnormal bf16 operands to zero could cost: 2^-126 * sqrt(D) * (|u| + |e|), D <= 64
+  // + what flushing subnormal bf16 operands to zero could cost: 2^-126 * sqrt(D) * (|u| + |e|), D <= 128
   const float nu = sqrtf(bb.u2[row]), ne = sqrtf(__uint_as_float(e2));
-  const float eps = 1.05f * 0x1p-8f * nu * ne + 0x1p-123f * (nu + ne) + 1e-30f;
+  const float eps = 1.05f * 0x1p-8f * nu * ne + 0x1p-122f * (nu + ne) + 1e-30f;
   const float t = tauf - 2.f * eps;
   const bool ok = eps < __builtin_inff() && t == t;
   bb.thr[row] = ok ? t : -__builtin_inff();
@@ -924,8 +924,11 @@ constexpr int BLD = 72;  // bf16 elements per LDS row: 64 + 8 (144 B: staggers t
 // texture path's line rate, not latency); in this order the 64 lanes of a step read one contiguous KB.  The copy is
 // private to the library (workspace / prepared catalogue), so only its writer and its three readers know.
 __host__ __device__ constexpr int64_t eb_rows(int64_t N) { return (N + 127) / 128 * 128; }
-__device__ __forceinline__ int64_t eb_chunk(int64_t row, int chunk) {  // offset (bf16 elements) of 8 k of a row
-  return (row >> 5) * 2048 + (static_cast<int64_t>(chunk) * 32 + (row & 31)) * 8;
+// KH = number of 64-k halves of a row: 1 for D <= 64, 2 for 64 < D <= 128 (round 3: the same kernels with twice the
+// k-steps; a tile is then [16 chunks of 8 k][32 rows][8 bf16] = 8 KB and a row of the U copy 128 bf16).
+template <int KH = 1>
+__device__ __forceinline__ int64_t eb_chunk(int64_t row, int chunk) {  // offset (bf16 elements) of 8 k of a row; chunk < 8 KH
+  return (row >> 5) * (2048 * KH) + (static_cast<int64_t>(chunk) * 32 + (row & 31)) * 8;
 }
 
 // bf16 copies of U and E (64-float rows) + squared row norms, one launch: workgroups [0, gu) take U (norms to u2[], the
@@ -934,11 +937,12 @@ __device__ __forceinline__ int64_t eb_chunk(int64_t row, int chunk) {  // offset
 // tau kernel reduces the <= 512 partials -- an atomicMax per row on one word took 140 us, one per workgroup 2.5 us, and
 // the word needed zeroing by an earlier launch).  16 lanes per row, 4 rows per thread and round (independent loads).
 // Separate launches for U and E were 5.2 + 9.3 us: a launch that moves 1 MB costs 5 us all the same.
+template <int KH>
 __global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __restrict__ U, int64_t B, __bf16* __restrict__ Ub,
                                                               float* __restrict__ u2, int* __restrict__ zero_rows, int gu,
                                                               const float* __restrict__ E, int64_t N, __bf16* __restrict__ Eb,
                                                               uint32_t* __restrict__ e2part, int D) {
-  // D <= 64 floats per row (any alignment when D < 64): the bf16 copies are zero-padded to 64 k
+  // D <= 64 KH floats per row (any alignment unless D is 64 or 128): the bf16 copies are zero-padded to 64 KH k
   __shared__ uint32_t bmax;
   const bool is_u = static_cast<int>(blockIdx.x) < gu;
   const float* M = is_u ? U : E;
@@ -953,36 +957,48 @@ __global__ __launch_bounds__(kBlock) void to_bf16_norm_kernel(const float* __res
   const int64_t step = static_cast<int64_t>(nblk) * per;
   uint32_t mine = 0u;
   for (int64_t r0 = static_cast<int64_t>(blk) * per + (threadIdx.x >> 4); r0 < rows_out; r0 += 4 * step) {
-    float4 v[4];
+    float4 v[KH][4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t r = r0 + q * step;
-      v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < rows) {
-        if (D == 64) {
-          v[q] = *reinterpret_cast<const float4*>(M + r * 64 + l16 * 4);
-        } else {
-          const float* src = M + r * D + l16 * 4;
-          if (l16 * 4 + 0 < D) v[q].x = src[0];
-          if (l16 * 4 + 1 < D) v[q].y = src[1];
-          if (l16 * 4 + 2 < D) v[q].z = src[2];
-          if (l16 * 4 + 3 < D) v[q].w = src[3];
+#pragma unroll
+      for (int h = 0; h < KH; ++h) {
+        const int e = h * 64 + l16 * 4;  // this lane's four floats of the half
+        v[h][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < rows) {
+          if (D == 64 * KH) {
+            v[h][q] = *reinterpret_cast<const float4*>(M + r * (64 * KH) + e);
+          } else {
+            const float* src = M + r * D + e;
+            if (e + 0 < D) v[h][q].x = src[0];
+            if (e + 1 < D) v[h][q].y = src[1];
+            if (e + 2 < D) v[h][q].z = src[2];
+            if (e + 3 < D) v[h][q].w = src[3];
+          }
         }
       }
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int64_t r = r0 + q * step;
-      float s = v[q].x * v[q].x;
-      s = __builtin_fmaf(v[q].y, v[q].y, s);
-      s = __builtin_fmaf(v[q].z, v[q].z, s);
-      s = __builtin_fmaf(v[q].w, v[q].w, s);
+      float s = 0.f;
+#pragma unroll
+      for (int h = 0; h < KH; ++h) {
+        s = __builtin_fmaf(v[h][q].x, v[h][q].x, s);
+        s = __builtin_fmaf(v[h][q].y, v[h][q].y, s);
+        s = __builtin_fmaf(v[h][q].z, v[h][q].z, s);
+        s = __builtin_fmaf(v[h][q].w, v[h][q].w, s);
+      }
       s = row16_sum(s);  // (every lane takes part: no divergence around the cross-lane sum)
       if (r < rows_out) {
-        uint2 pk;  // (rows past N: v = 0)
-        pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v[q].x), static_cast<__bf16>(v[q].y)});
-        pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v[q].z), static_cast<__bf16>(v[q].w)});
-        *reinterpret_cast<uint2*>(Mb + (is_u ? r * 64 + l16 * 4 : eb_chunk(r, l16 >> 1) + (l16 & 1) * 4)) = pk;
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+          uint2 pk;  // (rows past N: v = 0)
+          pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v[h][q].x), static_cast<__bf16>(v[h][q].y)});
+          pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(v[h][q].z), static_cast<__bf16>(v[h][q].w)});
+          *reinterpret_cast<uint2*>(Mb + (is_u ? r * (64 * KH) + h * 64 + l16 * 4
+                                               : eb_chunk<KH>(r, h * 8 + (l16 >> 1)) + (l16 & 1) * 4)) = pk;
+        }
       }
       if (r < rows) {
         if (l16 == 0) {
@@ -1051,15 +1067,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // (pass 1 runs ~3 workgroups per CU anyway -- 800 working workgroups -- and at 128 registers it spills: the reload's
 // s_waitcnt vmcnt(0) then also waits for the block prefetch)
-template <int EPI, bool MASKED>
-__global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_kernel(const __bf16* __restrict__ Ub, int64_t B,
+template <int EPI, bool MASKED, int KH = 1>
+__global__ __launch_bounds__(kBlock, KH == 2 ? 2 : (EPI == EPI_TILEMAX ? 3 : 4)) void bf16_tile_kernel(const __bf16* __restrict__ Ub, int64_t B,
                                                              const __bf16* __restrict__ Eb, int64_t N,
                                                              const float* __restrict__ thr, TopkArgs ta, StripLists sl,
                                                              int nvisit) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  __bf16* sA = reinterpret_cast<__bf16*>(smem);  // [BM][BLD]
-  __bf16* sB = sA + BM * BLD;                    // [BN][BLD]
-  float* snthr = reinterpret_cast<float*>(sB + BN * BLD);  // FILTER only: -thr[row], then the rows' list counters
+  __bf16* sA = reinterpret_cast<__bf16*>(smem);  // [KH][BM][BLD]
+  __bf16* sB = sA + KH * BM * BLD;               // [KH][BN][BLD]
+  float* snthr = reinterpret_cast<float*>(sB + KH * BN * BLD);  // FILTER only: -thr[row], then the rows' list counters
   int* rowcnt = reinterpret_cast<int*>(snthr + BM);
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
@@ -1077,16 +1093,19 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
   const uint32_t skip = ta.n_skip_low < N ? static_cast<uint32_t>(ta.n_skip_low) : n_cols;
   const int erow = tid >> 3, eoff = (tid & 7) * 8;  // operand staging: 128 rows x 8 units of 8 k (16 B), 4 units per thread
   const int brow = tid & 31, bchunk = tid >> 5;     // ... of E (fragment order, eb_chunk): thread = (row of a 32-row tile, chunk)
-  u32x4 pf[4];  // the next block of E (a native vector type: an array of HIP's uint4 struct lands in scratch)
+  u32x4 pf[KH][4];  // the next block of E (a native vector type: an array of HIP's uint4 struct lands in scratch)
 
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int r = erow + 32 * q;
-    const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
-    const int64_t n0 = static_cast<int64_t>(strip) * stride * BN;
-    *reinterpret_cast<u32x4*>(sA + r * BLD + eoff) = *reinterpret_cast<const u32x4*>(Ub + ra * 64 + eoff);
-    *reinterpret_cast<u32x4*>(sB + (brow + 32 * q) * BLD + bchunk * 8) = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n0 + brow + 32 * q, bchunk));
-  }
+  for (int h = 0; h < KH; ++h)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = erow + 32 * q;
+      const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
+      const int64_t n0 = static_cast<int64_t>(strip) * stride * BN;
+      *reinterpret_cast<u32x4*>(sA + (h * BM + r) * BLD + eoff) = *reinterpret_cast<const u32x4*>(Ub + ra * (64 * KH) + h * 64 + eoff);
+      *reinterpret_cast<u32x4*>(sB + (h * BN + brow + 32 * q) * BLD + bchunk * 8) =
+          *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n0 + brow + 32 * q, h * 8 + bchunk));
+    }
   if constexpr (EPI == EPI_FILTER) {
     if (tid < BM) {
       snthr[tid] = (tid < rows_here) ? 0.f - thr[b0 + tid] : -__builtin_inff();  // (0 - t: never -0)
@@ -1101,7 +1120,9 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
     {
       const int64_t n1 = static_cast<int64_t>(more ? j + nstrip : j) * stride * BN;  // (the last block re-reads itself)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) pf[q] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n1 + brow + 32 * q, bchunk));
+      for (int h = 0; h < KH; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) pf[h][q] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n1 + brow + 32 * q, h * 8 + bchunk));
     }
     // the epilogue's row / column offsets are loop invariant: made opaque here so that the compiler recomputes them per
     // block instead of carrying 64+ registers of addresses (i.e. spills) across the strip loop
@@ -1131,14 +1152,15 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {  // lane (r, h) supplies k = 16 ks + 8 h + j
+      for (int kk = 0; kk < 4 * KH; ++kk) {  // lane (r, h) supplies k = 16 kk + 8 h + j
+        const int kh = kk >> 2, ks = kk & 3;
         bf16x8 a[2], b[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sA + (wm * 64 + m * 32 + i32) * BLD + ks * 16 + hh * 8));
+          a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sA + (kh * BM + wm * 64 + m * 32 + i32) * BLD + ks * 16 + hh * 8));
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-          b[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sB + (wn * 64 + n * 32 + i32) * BLD + ks * 16 + hh * 8));
+          b[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sB + (kh * BN + wn * 64 + n * 32 + i32) * BLD + ks * 16 + hh * 8));
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -1212,19 +1234,20 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
           seed[m][4 * g + 3] = t4.w;
         }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
+      for (int kk = 0; kk < 4 * KH; ++kk) {
+        const int kh = kk >> 2, ks = kk & 3;
         bf16x8 a[2], b[2];
 #pragma unroll
         for (int m = 0; m < 2; ++m)
-          a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sA + (wm * 64 + m * 32 + i32) * BLD + ks * 16 + hh * 8));
+          a[m] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sA + (kh * BM + wm * 64 + m * 32 + i32) * BLD + ks * 16 + hh * 8));
 #pragma unroll
         for (int n = 0; n < 2; ++n)
-          b[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sB + (wn * 64 + n * 32 + i32) * BLD + ks * 16 + hh * 8));
+          b[n] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(sB + (kh * BN + wn * 64 + n * 32 + i32) * BLD + ks * 16 + hh * 8));
 #pragma unroll
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int n = 0; n < 2; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], ks == 0 ? seed[m] : acc[m][n], 0, 0, 0);
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m], b[n], kk == 0 ? seed[m] : acc[m][n], 0, 0, 0);
       }
       // A passing score costs one queue push here (no waiting): the wave's queue is drained once per tile, one LDS
       // atomic on the row's list counter and one store per entry, all entries in parallel.  (Taking the list slot inside
@@ -1302,7 +1325,9 @@ __global__ __launch_bounds__(kBlock, EPI == EPI_TILEMAX ? 3 : 4) void bf16_tile_
     if (more) {
       __syncthreads();  // every wave is done with sB
 #pragma unroll
-      for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(sB + (brow + 32 * q) * BLD + bchunk * 8) = pf[q];
+      for (int h = 0; h < KH; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) *reinterpret_cast<u32x4*>(sB + (h * BN + brow + 32 * q) * BLD + bchunk * 8) = pf[h][q];
       __syncthreads();
     }
   }
@@ -1353,8 +1378,8 @@ __device__ __forceinline__ uint32_t bf16_bits_rne(float v) {  // finite v
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <bool MASKED, int MT>  // MT 32-row tiles = the workgroup's user rows (every wave holds all of them)
-__global__ __launch_bounds__(kBlock, MT == 4 ? 2 : 4) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
+template <bool MASKED, int MT, int KH = 1>  // MT 32-row tiles = the workgroup's user rows (every wave holds all of them)
+__global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
                                                                        const __bf16* __restrict__ Eb, int64_t N,
                                                                        const float* __restrict__ thr, TopkArgs ta, StripLists sl,
                                                                        int nvisit) {
@@ -1377,20 +1402,21 @@ __global__ __launch_bounds__(kBlock, MT == 4 ? 2 : 4) void bf16_filter_direct_ke
 
   // the wave's B slice of the strip's first block, then A
   const int ccol = wv * 32 + i32;  // this lane's column inside a block
-  u32x4 bq[4], bn[4];
+  constexpr int NKS = 4 * KH;  // k-steps of 16 per row
+  u32x4 bq[NKS], bn[NKS];
   {
     const int64_t n0 = static_cast<int64_t>(strip) * BN;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bq[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n0 + ccol, ks * 2 + hh));
+    for (int ks = 0; ks < NKS; ++ks) bq[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n0 + ccol, ks * 2 + hh));
   }
-  u32x4 aq[MT][4];
+  u32x4 aq[MT][NKS];
   s16x4 at[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int r = m * 32 + i32;
     const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) aq[m][ks] = *reinterpret_cast<const u32x4*>(Ub + ra * 64 + ks * 16 + hh * 8);
+    for (int ks = 0; ks < NKS; ++ks) aq[m][ks] = *reinterpret_cast<const u32x4*>(Ub + ra * (64 * KH) + ks * 16 + hh * 8);
     float nt = (r < rows_here) ? 0.f - thr[b0 + r] : -__builtin_inff();
     if (nt != nt) nt = __builtin_inff();
     uint32_t p0, p1 = 0u, p2 = 0u;
@@ -1458,7 +1484,7 @@ __global__ __launch_bounds__(kBlock, MT == 4 ? 2 : 4) void bf16_filter_direct_ke
     {
       const int64_t n1 = static_cast<int64_t>(j + nstrip < nvisit ? j + nstrip : j) * BN;  // (the last block re-reads itself)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) bn[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk(n1 + ccol, ks * 2 + hh));
+      for (int ks = 0; ks < NKS; ++ks) bn[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n1 + ccol, ks * 2 + hh));
     }
     f32x16 acc[MT];
 #pragma unroll
@@ -1468,7 +1494,7 @@ __global__ __launch_bounds__(kBlock, MT == 4 ? 2 : 4) void bf16_filter_direct_ke
       for (int r = 0; r < 16; ++r) c[r] = 0.f;
       c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[m], ones, c, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+      for (int ks = 0; ks < NKS; ++ks)
         c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[m][ks]), __builtin_bit_cast(bf16x8, bq[ks]), c, 0, 0, 0);
       acc[m] = c;
     }
@@ -1529,7 +1555,7 @@ __global__ __launch_bounds__(kBlock, MT == 4 ? 2 : 4) void bf16_filter_direct_ke
     __builtin_amdgcn_s_setprio(0);
 #endif
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) bq[ks] = bn[ks];
+    for (int ks = 0; ks < NKS; ++ks) bq[ks] = bn[ks];
   }
   drain();
   __syncthreads();
@@ -1807,7 +1833,7 @@ struct FusedLayout {
   int64_t NT, cap, stride, seg_width, off_tilemax, off_tau, off_tauf, off_u2, off_thr, off_eps, off_e2max, off_ub, off_eb, off_cnt, off_cand, bytes;
 };
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
-static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16) {
+static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16, int kh = 1) {
   FusedLayout L;
   // Pass 1 only needs a LOWER bound of the k-th best score, and the k-th best of any subset of the columns is
   // one: it visits every `stride`-th 128-column block (1/stride of the GEMM work).  The filter pass then lets
@@ -1844,8 +1870,8 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16) {
   L.off_eps = align256(L.off_thr + B * 4);
   L.off_e2max = align256(L.off_eps + B * 4);
   L.off_ub = align256(L.off_e2max + kNormGrid * 4);        // bf16 copies of U and E (64-column inputs only)
-  L.off_eb = align256(L.off_ub + B * 128);
-  L.off_cnt = align256(L.off_eb + eb_rows(N) * 128);
+  L.off_eb = align256(L.off_ub + B * 128 * kh);  // kh = 64-k halves per row: 1 (D <= 64) or 2 (D <= 128)
+  L.off_cnt = align256(L.off_eb + eb_rows(N) * 128 * kh);
   L.off_cand = align256(L.off_cnt + B * (128 + 1) * 4);  // f32 path: kSeg + 1 counters per row; bf16 path: <= 128 strips + 1
   L.bytes = align256(L.off_cand + B * (L.cap + kOvfCap) * 8);
   return L;
@@ -1856,7 +1882,7 @@ static bool use_fused_topk(int64_t N, int64_t k) { return k <= 256 && (N + 63) /
 extern "C" int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k) {
   if (B <= 0 || N <= 0 || k <= 0) return 0;
   if (use_fused_topk(N, k)) {  // the path is chosen per call (D, alignment): room for either
-    const int64_t a = fused_layout(B, N, k, true).bytes, b = fused_layout(B, N, k, false).bytes;
+    const int64_t a = fused_layout(B, N, k, true, 2).bytes, b = fused_layout(B, N, k, false).bytes;
     return a > b ? a : b;
   }
   return topk_chunk_rows(B, N) * N * static_cast<int64_t>(sizeof(float));
@@ -1864,11 +1890,11 @@ extern "C" int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k) 
 
 // The bf16 fused path can take per-row exclusions (a bitmap built from the CSR); `mask` is then B x ceil(N / 64) words.
 static bool masked_topk_supported(int64_t B, int64_t N, int64_t D, int64_t k) {
-  return B > 0 && N > 0 && N < (1LL << 32) && D > 0 && D <= 64 && k > 0 && use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535;
+  return B > 0 && N > 0 && N < (1LL << 32) && D > 0 && D <= 128 && k > 0 && use_fused_topk(N, k) && (B + BM - 1) / BM <= 65535;
 }
 
 // `catalogue`: bf16 copy of E + partial norm maxima made by mi_oov_topk_catalogue_prepare (null: made per call).
-static int64_t catalogue_e2_offset(int64_t N) { return align256(eb_rows(N) * 128); }
+static int64_t catalogue_e2_offset(int64_t N, int64_t D) { return align256(eb_rows(N) * 128 * (D > 64 ? 2 : 1)); }
 static int64_t catalogue_parts(int64_t N) {
   const int64_t ge = grid_for(N, kBlock / 16);
   return ge > kNormGrid ? kNormGrid : ge;
@@ -1886,9 +1912,12 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
     const bool vec = (D % 4 == 0) && aligned16(U) && aligned16(E);
     static const bool bf16_path = env_knob("MI_OOV_TOPK_BF16", 1, 0, 1) != 0;
     // the bf16 path serves rows of up to 64 floats (narrower ones are zero-padded in the bf16 copies; 64-float rows must be 16-byte aligned)
-    const bool use_bf16 = (bf16_path || mask || catalogue) && (D < 64 || (D == 64 && vec));
+    // the bf16 path serves rows of up to 128 floats (narrower ones are zero-padded in the bf16 copies to 64 or 128 k;
+    // rows of exactly 64 / 128 floats are loaded as float4 and must be 16-byte aligned)
+    const bool use_bf16 = (bf16_path || mask || catalogue) && D <= 128 && ((D != 64 && D != 128) || vec);
     if ((mask || catalogue) && !use_bf16) return MI_OOV_ERR_ALIGN;  // (the entry points checked the shape; only alignment is left)
-    const FusedLayout L = fused_layout(B, N, k, use_bf16);
+    const int kh = (use_bf16 && D > 64) ? 2 : 1;
+    const FusedLayout L = fused_layout(B, N, k, use_bf16, kh);
     char* ws = static_cast<char*>(workspace);
     TopkArgs ta{};
     ta.tilemax = reinterpret_cast<uint32_t*>(ws + L.off_tilemax);
@@ -1912,7 +1941,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       __bf16* Eb = reinterpret_cast<__bf16*>(ws + L.off_eb);
       if (catalogue) {  // prepared once for a catalogue that many user batches are scored against
         Eb = const_cast<__bf16*>(static_cast<const __bf16*>(catalogue));
-        e2max = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(static_cast<const char*>(catalogue) + catalogue_e2_offset(N)));
+        e2max = const_cast<uint32_t*>(reinterpret_cast<const uint32_t*>(static_cast<const char*>(catalogue) + catalogue_e2_offset(N, D)));
       }
       const int64_t nblk = (N + BN - 1) / BN;
       const int64_t rb = (B + BM - 1) / BM;
@@ -1932,7 +1961,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       // direct pass 2: workgroups of 64 user rows (2 tiles of 32: 123 registers, 4 waves per SIMD) and one round of 1024;
       // MI_OOV_FILTER_TILES=4: 128 rows, 211 registers, 2 waves per SIMD, 512 workgroups (48 us instead of 41)
       static const int mt_env = env_knob("MI_OOV_FILTER_TILES", 2, 2, 4) == 4 ? 4 : 2;  // 2 or 4 tiles of 32 user rows
-      const int mt = (B + 63) / 64 > 65535 ? 4 : mt_env;  // (grid.y)
+      const int mt = kh == 2 ? 2 : ((B + 63) / 64 > 65535 ? 4 : mt_env);  // (grid.y; two k-halves: 64-row workgroups only)
       static const int64_t target_env = env_knob("MI_OOV_STRIP_WGS2", 0, 0, 65536);
       const int64_t target_d = target_env > 0 ? target_env : (mt == 2 ? 1024 : 512);
       const int64_t rbd = (B + mt * 32 - 1) / (mt * 32);
@@ -1965,17 +1994,26 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       int64_t gu = grid_for(B, kBlock / 16);
       const int64_t ge = catalogue_parts(N);
       if (gu > kNormGrid) gu = kNormGrid;
-      hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
-                         sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max, static_cast<int>(D));
-      if ((rc = check_launch())) return rc;
-      const size_t lds_ops = static_cast<size_t>(BM + BN) * BLD * sizeof(__bf16);
-      const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
-      if (mask)
-        hipLaunchKernelGGL((bf16_tile_kernel<EPI_TILEMAX, true>), dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
-                           Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
+      if (kh == 2)
+        hipLaunchKernelGGL(to_bf16_norm_kernel<2>, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
+                           sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max, static_cast<int>(D));
       else
-        hipLaunchKernelGGL((bf16_tile_kernel<EPI_TILEMAX, false>), dim3(static_cast<unsigned>(ns1), static_cast<unsigned>(rb)), dim3(kBlock), lds_ops, st,
-                           Ub, B, Eb, N, static_cast<const float*>(nullptr), ta, sl, static_cast<int>(nvisit1));
+        hipLaunchKernelGGL(to_bf16_norm_kernel<1>, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
+                           sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max, static_cast<int>(D));
+      if ((rc = check_launch())) return rc;
+      const size_t lds_ops = static_cast<size_t>(BM + BN) * BLD * sizeof(__bf16) * kh;
+      const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
+      auto launch_tile = [&](auto kern, size_t lds, int64_t ns, const float* thr_arg, int64_t nvisit) -> int {
+        if (int rc2 = set_lds(kern, lds)) return rc2;  // (two k-halves: 73.7 KiB of operands)
+        hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(ns), static_cast<unsigned>(rb)), dim3(kBlock), lds, st, Ub, B, Eb, N, thr_arg, ta, sl,
+                           static_cast<int>(nvisit));
+        return MI_OOV_OK;
+      };
+      if (kh == 2) rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 2>, lds_ops, ns1, nullptr, nvisit1)
+                             : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 2>, lds_ops, ns1, nullptr, nvisit1);
+      else rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 1>, lds_ops, ns1, nullptr, nvisit1)
+                     : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 1>, lds_ops, ns1, nullptr, nvisit1);
+      if (rc) return rc;
       Bf16Bound bb{u2, e2max, static_cast<int>(ge), thr, eps};
       if (L.NT <= 256)
         hipLaunchKernelGGL(tile_kth_wave_kernel<4>, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
@@ -1994,19 +2032,24 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rbd)), dim3(kBlock), lds_direct, st, Ub, B, Eb, N, thr, ta, sl,
                            static_cast<int>(nblk));
       };
-      if (direct && mask) {
+      if (direct && kh == 2) {  // 128-k rows: the user fragments alone are 64 registers per 64 rows -- workgroups of 64 rows
+        if (mask) launch_direct(bf16_filter_direct_kernel<true, 2, 2>);
+        else launch_direct(bf16_filter_direct_kernel<false, 2, 2>);
+      } else if (direct && mask) {
         if (mt == 2) launch_direct(bf16_filter_direct_kernel<true, 2>);
         else launch_direct(bf16_filter_direct_kernel<true, 4>);
       } else if (direct) {
         if (mt == 2) launch_direct(bf16_filter_direct_kernel<false, 2>);
         else launch_direct(bf16_filter_direct_kernel<false, 4>);
+      } else if (kh == 2) {
+        rc = mask ? launch_tile(bf16_tile_kernel<EPI_FILTER, true, 2>, lds_filter, ns2, thr, nblk)
+                  : launch_tile(bf16_tile_kernel<EPI_FILTER, false, 2>, lds_filter, ns2, thr, nblk);
+        if (rc) return rc;
+      } else {
+        rc = mask ? launch_tile(bf16_tile_kernel<EPI_FILTER, true, 1>, lds_filter, ns2, thr, nblk)
+                  : launch_tile(bf16_tile_kernel<EPI_FILTER, false, 1>, lds_filter, ns2, thr, nblk);
+        if (rc) return rc;
       }
-      else if (mask)
-        hipLaunchKernelGGL((bf16_tile_kernel<EPI_FILTER, true>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
-                           Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
-      else
-        hipLaunchKernelGGL((bf16_tile_kernel<EPI_FILTER, false>), dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rb)), dim3(kBlock), lds_filter, st,
-                           Ub, B, Eb, N, thr, ta, sl, static_cast<int>(nblk));
       if ((rc = check_launch())) return rc;
       hipLaunchKernelGGL(topk_finalize_exact_kernel, dim3(static_cast<unsigned>((B + kFinRows - 1) / kFinRows)), dim3(kBlock),
                          static_cast<size_t>(kFinRows) * (sl.ns * sl.cap + kOvfLds) * 8, st, U, E, B, N, D,
@@ -2074,19 +2117,24 @@ extern "C" int mi_oov_score_topk_masked(const float* U, int64_t B, const float* 
 // run) is converted once: the counterpart of the reference building its ScaNN searcher at construction
 // (knn_embedder.py:84-93).  The buffer holds the bf16 copy of E and the per-workgroup maxima of its squared row norms.
 extern "C" int64_t mi_oov_topk_catalogue_bytes(int64_t N, int64_t D) {
-  if (N <= 0 || N >= (1LL << 32) || D <= 0 || D > 64) return 0;
-  return catalogue_e2_offset(N) + align256(kNormGrid * 4);
+  if (N <= 0 || N >= (1LL << 32) || D <= 0 || D > 128) return 0;
+  return catalogue_e2_offset(N, D) + align256(kNormGrid * 4);
 }
 
 extern "C" int mi_oov_topk_catalogue_prepare(const float* E, int64_t N, int64_t D, void* catalogue, void* stream) {
-  if (N <= 0 || N >= (1LL << 32) || D <= 0 || D > 64) return MI_OOV_ERR_SHAPE;
+  if (N <= 0 || N >= (1LL << 32) || D <= 0 || D > 128) return MI_OOV_ERR_SHAPE;
   if (!E || !catalogue) return MI_OOV_ERR_NULL;
-  if ((D == 64 && !aligned16(E)) || (reinterpret_cast<uintptr_t>(catalogue) & 15u) != 0) return MI_OOV_ERR_ALIGN;
+  if (((D == 64 || D == 128) && !aligned16(E)) || (reinterpret_cast<uintptr_t>(catalogue) & 15u) != 0) return MI_OOV_ERR_ALIGN;
   __bf16* Eb = static_cast<__bf16*>(catalogue);
-  uint32_t* e2part = reinterpret_cast<uint32_t*>(static_cast<char*>(catalogue) + catalogue_e2_offset(N));
-  hipLaunchKernelGGL(to_bf16_norm_kernel, dim3(static_cast<unsigned>(catalogue_parts(N))), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
-                     static_cast<const float*>(nullptr), 0, static_cast<__bf16*>(nullptr), static_cast<float*>(nullptr),
-                     static_cast<int*>(nullptr), 0, E, N, Eb, e2part, static_cast<int>(D));
+  uint32_t* e2part = reinterpret_cast<uint32_t*>(static_cast<char*>(catalogue) + catalogue_e2_offset(N, D));
+  if (D > 64)
+    hipLaunchKernelGGL(to_bf16_norm_kernel<2>, dim3(static_cast<unsigned>(catalogue_parts(N))), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(nullptr), 0, static_cast<__bf16*>(nullptr), static_cast<float*>(nullptr),
+                       static_cast<int*>(nullptr), 0, E, N, Eb, e2part, static_cast<int>(D));
+  else
+    hipLaunchKernelGGL(to_bf16_norm_kernel<1>, dim3(static_cast<unsigned>(catalogue_parts(N))), dim3(kBlock), 0, static_cast<hipStream_t>(stream),
+                       static_cast<const float*>(nullptr), 0, static_cast<__bf16*>(nullptr), static_cast<float*>(nullptr),
+                       static_cast<int*>(nullptr), 0, E, N, Eb, e2part, static_cast<int>(D));
   return check_launch();
 }
 

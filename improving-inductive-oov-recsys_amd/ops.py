@@ -1055,8 +1055,8 @@ class TopkCatalogue:
     def __init__(self, E):
         E = _f32(E, "E")
         nbytes = int(C.lib().mi_oov_topk_catalogue_bytes(E.shape[0], E.shape[1]))
-        if nbytes <= 0 or (E.shape[1] == 64 and E.data_ptr() % 16):
-            raise ValueError("TopkCatalogue needs a float32 table of at most 64 columns (16-byte aligned when it has 64)")
+        if nbytes <= 0 or (E.shape[1] in (64, 128) and E.data_ptr() % 16):
+            raise ValueError("TopkCatalogue needs a float32 table of at most 128 columns (16-byte aligned when it has 64 or 128)")
         self.E = E
         self.version = E._version
         self.buf = torch.empty((nbytes,), dtype=torch.uint8, device=E.device)
@@ -1067,7 +1067,7 @@ class TopkCatalogue:
     @staticmethod
     def of(E):
         ok = torch.is_tensor(E) and E.is_cuda and E.dtype == torch.float32 and E.dim() == 2 and E.is_contiguous() \
-            and 0 < E.shape[1] <= 64 and E.shape[0] > 0 and (E.shape[1] < 64 or E.data_ptr() % 16 == 0)
+            and 0 < E.shape[1] <= 128 and E.shape[0] > 0 and (E.shape[1] not in (64, 128) or E.data_ptr() % 16 == 0)
         return TopkCatalogue(E) if ok else None
 
     def fresh(self, E=None):
@@ -1081,7 +1081,7 @@ def _prepared_call(U, cat, k, n_skip_low, excl_ptr, excl_cols, vals, idx):
     B, N, D = U.shape[0], cat.E.shape[0], U.shape[1]
     need = int(lib.mi_oov_score_topk_masked_workspace(B, N, D, k)) if excl_ptr is not None else \
         (int(lib.mi_oov_score_topk_workspace(B, N, k)) if int(lib.mi_oov_score_topk_masked_workspace(B, N, D, k)) > 0 else 0)
-    if need <= 0 or (D == 64 and U.data_ptr() % 16):
+    if need <= 0 or (D in (64, 128) and U.data_ptr() % 16):
         return False
     ws = torch.empty((need,), dtype=torch.uint8, device=U.device)
     with C.on_device(U):

@@ -393,8 +393,8 @@ int mi_oov_score_topk_excl(const float* U, int64_t B, const float* E, int64_t N,
 /* The same result with exclusion lists of ANY length, still without a [B,N] matrix: the CSR becomes a bitmap of
  * B x ceil(N/64) words inside the workspace; the first pass of the fused kernel leaves excluded columns out of its tile
  * maxima (so its bound is the k-th best ALLOWED one and the candidate count does not grow with the histories), the
- * second pass drops them when it emits a candidate.  Rows of D <= 64 floats (16-byte aligned when D = 64; narrower rows are
- * zero-padded in the library's bf16 copies), k <= 256, N >= 128 k (the fused bf16 path); the workspace query returns 0 for shapes it does not take (use mi_oov_score_topk_excl or materialise).
+ * second pass drops them when it emits a candidate.  Rows of D <= 128 floats (16-byte aligned when D = 64 or 128; other widths
+ * are zero-padded to 64 or 128 in the library's bf16 copies), k <= 256, N >= 128 k (the fused bf16 path); the workspace query returns 0 for shapes it does not take (use mi_oov_score_topk_excl or materialise).
  * excl_cols need not be sorted; entries outside [0, N) are ignored.
  *   workspace: mi_oov_score_topk_masked_workspace(B, N, D, k) bytes, 16-byte aligned.                            */
 int64_t mi_oov_score_topk_masked_workspace(int64_t B, int64_t N, int64_t D, int64_t k);
@@ -404,7 +404,7 @@ int mi_oov_score_topk_masked(const float* U, int64_t B, const float* E, int64_t 
 
 /* A catalogue E that many user batches are scored against (the knn search's feature table -- the reference builds a ScaNN
  * searcher over it at construction, knn_embedder.py:84-93 -- or the item table of an evaluation run) can be prepared once:
- * the buffer receives what the fused bf16 path otherwise derives from E on every call.  D <= 64 (E 16-byte aligned when D = 64);
+ * the buffer receives what the fused bf16 path otherwise derives from E on every call.  D <= 128 (E 16-byte aligned when D = 64 or 128);
  * mi_oov_topk_catalogue_bytes returns 0 for other shapes.  The catalogue is valid for exactly the E it was made from.
  * mi_oov_score_topk_prepared = mi_oov_score_topk (excl_ptr NULL; workspace mi_oov_score_topk_workspace) or
  * mi_oov_score_topk_masked (excl_ptr given; workspace mi_oov_score_topk_masked_workspace) with the per-call pass over E

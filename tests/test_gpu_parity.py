@@ -411,18 +411,20 @@ def test_topk_prepared_catalogue(oracle, ops, dev):
     v2, i2 = ops.score_topk_excl(T(U, dev), cat, 15, T(ptr, dev), T(cols, dev), n_skip_low=1)
     ov, oi = oracle.score_topk_excl(U, E, 15, ptr, cols, 1)
     assert np.array_equal(i2.cpu().numpy(), oi) and np.array_equal(v2.cpu().numpy(), ov)
-    assert ops.TopkCatalogue.of(torch.zeros((7000, 80), device=dev)) is None       # a width the fused path does not take
+    assert ops.TopkCatalogue.of(torch.zeros((7000, 80), device=dev)) is not None   # rows of up to 128 floats (round 3)
+    assert ops.TopkCatalogue.of(torch.zeros((7000, 129), device=dev)) is None      # a width the fused path does not take
     Eg[5] += 1.0
     assert not cat.fresh()
     with pytest.raises(ValueError):
         ops.score_topk(T(U, dev), cat, 15, 1)
 
 
-@pytest.mark.parametrize("D", [22, 40])
+@pytest.mark.parametrize("D", [22, 40, 65, 100, 128])
 def test_topk_narrow_rows_take_the_bf16_path(D, oracle, ops, dev):
-    """Rows of fewer than 64 floats (a knn search over 22 feature columns, a 32-d model): the bf16 copies are zero-padded
-    to 64, the exact re-score runs the oracle's chain for the real width -- plain, with exclusions, and through a
-    prepared catalogue; same results as the oracle, bit for bit."""
+    """Rows that are not 64 floats wide -- a knn search over 22 feature columns, a 32-d model, and from round 3 on 65..128
+    floats (a 128-d model: BASELINE config 4's row width): the bf16 copies are zero-padded to 64 or 128 k, the exact
+    re-score runs the oracle's chain for the real width -- plain, with exclusions, and through a prepared catalogue; same
+    results as the oracle, bit for bit."""
     rng = np.random.default_rng(D)
     B, N, k = 200, 12000, 12
     U = rng.standard_normal((B, D), dtype=np.float32)
@@ -445,16 +447,16 @@ def test_topk_narrow_rows_take_the_bf16_path(D, oracle, ops, dev):
         v2, i2 = ops.score_topk_excl(Ug, table, k, T(ptr, dev), T(cols, dev), n_skip_low=1)
         assert np.array_equal(i2.cpu().numpy(), oi) and np.array_equal(v2.cpu().numpy(), ov)
     from mi_oov import _cabi as C
-    assert C.lib().mi_oov_score_topk_masked_workspace(B, N, D, k) > 0 and C.lib().mi_oov_score_topk_masked_workspace(B, N, 65, k) == 0
+    assert C.lib().mi_oov_score_topk_masked_workspace(B, N, D, k) > 0 and C.lib().mi_oov_score_topk_masked_workspace(B, N, 129, k) == 0
 
 
 def test_fused_topk_random_shapes(oracle, ops, dev):
-    """Forty random shapes through the fused path -- user batches that are not multiples of the 64-row workgroups,
-    catalogues that end inside a tile, widths 1..64, k up to 64, skipped low columns, tie runs and a zero user row --
-    against the oracle, bit for bit."""
+    """Sixty random shapes through the fused path -- user batches that are not multiples of the 64-row workgroups,
+    catalogues that end inside a tile, widths 1..128 (two k-halves above 64), k up to 64, skipped low columns, tie runs and
+    a zero user row -- against the oracle, bit for bit."""
     rng = np.random.default_rng(2026)
-    for case in range(40):
-        D = int(rng.choice([1, 3, 8, 16, 22, 31, 32, 40, 48, 63, 64]))
+    for case in range(60):
+        D = int(rng.choice([1, 3, 8, 16, 22, 31, 32, 40, 48, 63, 64] if case < 40 else [65, 72, 96, 100, 127, 128]))
         k = int(rng.choice([1, 2, 5, 10, 20, 33, 64]))
         N = int(rng.integers(128 * k, 128 * k + 30000))
         B = int(rng.integers(1, 200))

@@ -162,6 +162,9 @@ def main():
         f"slsh_embed_multi nb=1000 D=128 10 planes {KQ} batches per launch": (lambda i: ops.slsh_embed_multi(idsq[i % 2], feat, planes10, big_bk, out=o128[i % 2]), KQ * B, 8 + 4 * F + 8 * 128, 0),
         "slsh_embed nb=1000 D=128 10 planes": (lambda i: ops.slsh_embed(ids[i], feat, planes10, big_bk), B, 8 + 4 * F + 8 * 128, 0),
     })
+    U128 = torch.randn((Bs, 128), generator=g, device=dev)
+    E128 = torch.randn((Ns, 128), generator=g, device=dev)
+    cases["score_topk k=20 B=4096 N=50000 D=128 (two k-halves on the bf16 path)"] = (lambda i: ops.score_topk(U128, E128, 20, 1), Bs * Ns, 0, 2 * 128)
     if args.only.startswith("score_topk_excl"):  # full-sort evaluation: histories masked (bitmap in the kernel vs top-(k + h_max))
         gh = torch.Generator(device=dev).manual_seed(5)
         for hmean, hmax in ((60, 120), (100, 230), (100, 1500)):
