@@ -316,7 +316,7 @@ def main():
                     scorer.run(q, k0, min(bpl, i0 + n - k0))
                     launches += 1
                 return launches
-            return run_steps, "lsh64_persistent_kernel<8, 0, true>", "mi_oov_lsh_embed_score_multi"
+            return run_steps, "lsh64_persistent_kernel<8, 0, true, false>", "mi_oov_lsh_multi (score mode, prepared 2^H table; = mi_oov_lsh_embed_score_multi)"
         if mode == "per_batch":
             scorer = ops.LshScorer(feat, planes, buckets)
             graphs = {}
@@ -402,8 +402,8 @@ def main():
                 "table": f"feature table row-sharded over {world} ranks ({hi - lo} rows here), planes + bucket table replicated",
                 "entry_point": "mi_oov_bucket_by_owner + mi_oov_lsh_embed(bits) + mi_oov_lsh_codes_embed",
                 "launch_mode": f"owner-computes exchange, up to {S} steps per exchange, three exchanges in flight on three streams",
-                "roofline": {"bound": "hbm", "kernel": "bucket_by_owner_small_kernel + lsh64_persistent_kernel<8, 1, false> (owner) + "
-                                                       "lsh64_persistent_kernel<8, 2, false> (requester), concurrent",
+                "roofline": {"bound": "hbm", "kernel": "bucket_by_owner_small_kernel + lsh64_persistent_kernel<8, 1, false, false> (owner) + "
+                                                       "lsh64_persistent_kernel<8, 2, false, false> (requester), concurrent",
                              "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                              "bytes_per_lookup": step_bytes, "lookups_per_launch": B * K / n_blocks,
                              "launches": n_blocks, "avg_launch_us": region_ms * 1e3 / n_blocks, "traffic": None,
