@@ -118,15 +118,27 @@ __device__ __forceinline__ void store4(float* row, int64_t e, int64_t L, float4 
 }
 
 // Dynamic LDS above 64 KiB needs an explicit opt-in (up to the CU's 160 KiB).
+// (The attribute sticks to the function: it is set when a kernel is first launched with a size, and again only when a
+//  larger one is asked for -- the call costs ~1.5 us of host time, which an isolated launch from an idle stream would
+//  otherwise pay inside the region its caller times.  One slot per kernel instantiation and thread.)
 template <typename K>
 inline int set_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) {
+    thread_local K last_kernel = nullptr;
+    thread_local size_t last_bytes = 0;
+    thread_local int last_dev = -1;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (last_kernel == kernel && last_dev == dev && bytes <= last_bytes) return MI_OOV_OK;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes));
     if (e != hipSuccess) {
       g_last_hip_error = static_cast<int>(e);
       return MI_OOV_ERR_LAUNCH;
     }
+    last_kernel = kernel;
+    last_bytes = bytes;
+    last_dev = dev;
   }
   return MI_OOV_OK;
 }

@@ -651,11 +651,23 @@ def test_lsh_multi_queue_slices_and_fallback(oracle, ops, dev):
         assert bits_equal(got[k, :B], oracle.lsh_embed_score(ids[k], feat, planes, buckets, other[k])[0])
     with pytest.raises(ValueError):
         scorer.run(q, 5, 5)
+    block.fill_(-7.0)
+    launch = scorer.bind(q, 3, 4)  # a prevalidated launch of batches 3..6 (what bench.py issues)
+    launch()
+    launch()
+    got = block.cpu().numpy()
+    assert (got[:3, :B] == -7.0).all() and (got[7:, :B] == -7.0).all()
+    for k in range(3, 7):
+        assert bits_equal(got[k, :B], oracle.lsh_embed_score(ids[k], feat, planes, buckets, other[k])[0])
+    with pytest.raises(ValueError):
+        scorer.bind(q, 8, 2)
     # 12 planes: not a persistent-kernel shape
     planes12 = rng.standard_normal((12, 64), dtype=np.float32)
     buckets12 = rng.standard_normal((12, 64), dtype=np.float32)
     s12 = ops.LshMultiScorer(T(feat, dev), T(planes12, dev), T(buckets12, dev))
     assert not s12.persistent
+    with pytest.raises(ValueError):
+        s12.bind(ops.LshBatchQueue([ids_d[k] for k in range(3)], [other_d[k] for k in range(3)]))
     res = s12.run(ops.LshBatchQueue([ids_d[k] for k in range(3)], [other_d[k] for k in range(3)]))
     for k in range(3):
         assert bits_equal(res[k].cpu().numpy(), oracle.lsh_embed_score(ids[k], feat, planes12, buckets12, other[k])[0])
