@@ -1710,7 +1710,22 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
               acc = __builtin_fmaf(u[4 * c + 2], ev[c].z, acc);
               acc = __builtin_fmaf(u[4 * c + 3], ev[c].w, acc);
             }
-          } else {  // narrower rows (D < 64): the oracle's chain for that width (DotKeys), zero-padded to the f32 kernel's K chunk
+          } else if (D == 128) {  // two 64-float halves, the same chain continued (16 independent float4 loads each)
+            const float4* e4 = reinterpret_cast<const float4*>(E + static_cast<int64_t>(0xFFFFFFFFu - inv) * 128);
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+              float4 ev[16];
+#pragma unroll
+              for (int c = 0; c < 16; ++c) ev[c] = e4[half * 16 + c];
+#pragma unroll
+              for (int c = 0; c < 16; ++c) {
+                acc = __builtin_fmaf(u[half * 64 + 4 * c + 0], ev[c].x, acc);
+                acc = __builtin_fmaf(u[half * 64 + 4 * c + 1], ev[c].y, acc);
+                acc = __builtin_fmaf(u[half * 64 + 4 * c + 2], ev[c].z, acc);
+                acc = __builtin_fmaf(u[half * 64 + 4 * c + 3], ev[c].w, acc);
+              }
+            }
+          } else {  // other widths: the oracle's chain for that width (DotKeys), zero-padded to the f32 kernel's K chunk
             const float* e = E + static_cast<int64_t>(0xFFFFFFFFu - inv) * D;
             for (int64_t d = 0; d < D; ++d) acc = __builtin_fmaf(u[d], e[d], acc);
             if (D % KC) acc = __builtin_fmaf(0.f, 0.f, acc);
