@@ -542,8 +542,9 @@ def test_dhe_full_size_properties(mi, oracle, dev):
     assert np.array_equal(hm[rows].cpu().numpy(), want)
     dims = [(K, 512), (512, 512), (512, 512), (512, D)]
     Ws = [torch.randn((o, i), generator=g, device=dev) / (i ** 0.5) for i, o in dims]
-    bs = [0.1 * torch.randn((o,), generator=g, device=dev) for _, o in dims]
-    x = hm / 16777216.0
+    Ws[0] = Ws[0] / 16777216.0  # the reference feeds the RAW hashes (up to 2^24) to the first Linear (dh_embedder.py:191-217):
+    bs = [0.1 * torch.randn((o,), generator=g, device=dev) for _, o in dims]  # so does this test; the first layer's weights
+    x = hm                                                                     # are scaled instead, keeping the net unsaturated
     y = x
     for j, (w, b) in enumerate(zip(Ws, bs)):
         y = ops.linear_act(y, w, b, "gelu" if j < 3 else "sigmoid")
