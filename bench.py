@@ -76,6 +76,7 @@ def parse():
     ap.add_argument("--per-batch", action="store_true", help="one launch per step (K launches in one HIP graph)")
     ap.add_argument("--unfused", action="store_true", help="two launches per step (lsh_embed + rowdot)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the untimed rows-stored measurement reported under 'also'")
     ap.add_argument("--no-graph", action="store_true", help="with --per-batch: launch every step from Python")
     ap.add_argument("--dist-backend", default="nccl", help="nccl (= RCCL, default) or gloo (rehearsal on a 1-GPU box)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -172,6 +173,36 @@ def cpu_baseline(args, feat, planes, buckets, seconds):
     return {"value": n_done * args.batch / t_total, "unit": "lookups/s", "cores": cores, "kind": "port",
             "sample": f"{n_done} batches of {args.batch} lookups+scores through the reference's torch-CPU op "
                       f"sequence (oracle/ref_torch.py), {t_total:.1f} s, torch.set_num_threads({cores})"}
+
+
+def also_rows_stored(args, ops, feat, planes, buckets, all_ids, n_ramp, dev):
+    """Outside the timed region, for the record: what the PLUGIN returns -- LSHInductiveEmbedder.embed_item_ids' [B, 64]
+    rows (lsh_embedder.py:161-179) -- for 20 queued batches per persistent launch (mi_oov_lsh_multi, rows mode, prepared
+    table), and ONE such call per launch (mi_oov_lsh_embed).  HIP events over 10 launches that alternate between two
+    queues of distinct id batches and two sets of output buffers; 8 + 4F + 4D = 520 algorithmic bytes per lookup."""
+    B, K = args.batch, 20
+    qs = [ops.LshBatchQueue([all_ids[j * K + i] for i in range(K)], rows=True) for j in range(2)]  # (40 of the 64 ramp batches)
+    sc = ops.LshMultiScorer(feat, planes, buckets)
+    calls = [sc.bind(q) for q in qs]
+    res = {}
+    with torch.no_grad():
+        for name, fn, lookups in (("lsh_embed rows, 20 queued batches per launch (mi_oov_lsh_multi)", lambda i: calls[i % 2](), K * B),
+                                  ("lsh_embed rows, one batch per launch (mi_oov_lsh_embed)",
+                                   lambda i: ops.lsh_embed(all_ids[i % n_ramp], feat, planes, buckets), B)):
+            for i in range(4):
+                fn(i)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 10 if lookups > B else 40
+            a.record()
+            for i in range(n):
+                fn(i)
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) * 1e3 / n
+            gbs = lookups * 520 / (us * 1e-6) / 1e9
+            res[name] = {"us_per_launch": us, "us_per_65536_lookups": us * 65536 / lookups, "GB_per_s": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}
+    return res
 
 
 def pmc_traffic(kernel, args):
@@ -488,6 +519,8 @@ def main():
             out["sharded"] = sharded_line.get("detail")
         elif sharded_line is not None:
             out["sharded"] = sharded_line
+        if world == 1 and mode == "multi" and F == 64 and D == 64 and H <= 8 and not args.no_also:
+            out["also"] = also_rows_stored(args, ops, feat, planes, buckets, all_ids, n_ramp, dev)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(args, feat, planes, buckets, args.cpu_seconds)

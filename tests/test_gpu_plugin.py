@@ -711,3 +711,45 @@ def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkey
             ref = z[f"{mode}_{side}_pre_sigmoid"]
             assert np.abs(pre.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), (mode, side)
             assert np.abs(out.cpu().numpy() - z[f"{mode}_{side}_out"]).max() <= 1e-5, (mode, side)
+
+
+def test_full_size_queued_batches_equal_single_launches(mi, dev):
+    """BASELINE's headline sizes (10 M-item x 64-feature table, 8 hashes, batches of 65536): every K-batch entry point of
+    round 3 against the single launches it replaces -- a size-independent property (the single launches are pinned on the
+    oracle at small sizes) -- for the rows / lookup / lookup-score modes of the persistent kernel with and without the
+    prepared table, the row gathers, the knn aggregate and slsh with a 128-d bucket table."""
+    from mi_oov import ops
+    g = torch.Generator(device=dev).manual_seed(21)
+    N, B, K = 10_000_000, 65536, 6
+    feat = torch.nn.functional.normalize(torch.randn((N, 64), generator=g, device=dev), dim=-1)
+    planes = torch.randn((8, 64), generator=g, device=dev)
+    buckets = torch.randn((8, 64), generator=g, device=dev)
+    ids = [torch.randint(0, N, (B,), generator=g, device=dev) for _ in range(K)]
+    ids[0][5], ids[K - 1][B - 1] = -1, N
+    users = [torch.randn((B, 64), generator=g, device=dev) for _ in range(K)]
+    vt = feat[:N // 2]
+
+    def same(a, b):
+        return torch.equal(torch.nan_to_num(a, 7.0), torch.nan_to_num(b, 7.0))
+
+    with torch.no_grad():
+        for tab in (None, ops.LshTable(buckets)):
+            rows = ops.lsh_embed_multi(ids, feat, planes, buckets, table=tab)
+            lrows = ops.lsh_lookup_multi(ids, vt, feat, planes, buckets, lsh_table=tab)
+            lsc = ops.lsh_lookup_multi(ids, vt, feat, planes, buckets, other_list=users, lsh_table=tab)
+            for k in range(K):
+                assert same(rows[k], ops.lsh_embed(ids[k], feat, planes, buckets)), ("rows", k)
+                assert same(lrows[k], ops.lsh_lookup(ids[k], vt, feat, planes, buckets)), ("lookup rows", k)
+                assert same(lsc[k], ops.lsh_lookup_score(ids[k], vt, feat, planes, buckets, users[k])), ("lookup score", k)
+        assert int(torch.isnan(rows[0]).all(1).sum()) > 100  # the all-zero codes' NaN rows are there (about 1 in 256)
+        gr = ops.gather_rows_multi(ids, feat)
+        idx2 = [torch.randint(0, N, (B, 2), generator=g, device=dev) for _ in range(K)]
+        gm = ops.gather_mean_multi(idx2, feat, 2)
+        planes27 = torch.randn((27, 64), generator=g, device=dev)
+        big = torch.randn((100_000, 128), generator=g, device=dev)
+        sl, sidx = ops.slsh_embed_multi(ids, feat, planes27, big, want_idx=True)
+        for k in range(K):
+            assert same(gr[k], ops.gather_rows(ids[k], feat)), ("gather", k)
+            assert torch.equal(gm[k], ops.gather_mean(idx2[k], feat, 2)), ("mean", k)
+            assert same(sl[k], ops.slsh_embed(ids[k], feat, planes27, big)) and torch.equal(sidx[k], ops.slsh_index(ids[k], feat, planes27, 100_000))
+        assert bool((sidx[1] >= 27).all() & (sidx[1] <= 54).all())  # (bits_req + popcount) % n_buckets: 27 .. 54 only
