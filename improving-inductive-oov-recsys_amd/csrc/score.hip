@@ -127,6 +127,10 @@ __device__ __forceinline__ float epilogue(float v, float b) {
 #ifndef MI_FS_NT
 #define MI_FS_NT 1
 #endif
+#ifndef MI_FS_WIDE
+#define MI_FS_WIDE 1
+#endif
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 template <bool VEC, int EPI>
 __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __restrict__ U, int64_t B,
                                                            const float* __restrict__ E, int64_t N, int64_t D,
@@ -261,6 +265,57 @@ __global__ __launch_bounds__(kBlock, 4) void full_sort_kernel(const float* __res
       append_candidate(ta, B, b0 + wrow[i], blockIdx.x, wbuf[i]);
     }
   } else {
+    // Store epilogue.  A lane holds 16 ROWS of one column per accumulator, so writing the accumulators as they stand is
+    // 64 dword stores per lane and tile (two 128-byte pieces per instruction).  WIDE: each wave turns its 64 x 64 sub-tile
+    // through LDS -- the operand tiles are dead by now; 32 rows x 64 columns at a time in a region of its own, so no
+    // workgroup barrier is needed after the first -- and stores 16 bytes per lane: 16 store instructions per lane and
+    // tile, each covering four 256-byte row pieces.  Worth 2 % on the full sort (4096 x 50 000 x 64: 367 -> 360 us) and
+    // 4 % on the dhe hash net (1339 -> 1281 us per 65536 lookups).  What bounds this kernel (round-3 knock-outs, same
+    // shape): one store in sixteen 268 us, the stores and the staging without the matrix instructions 183 us, all of it
+    // 358: the main loop runs at ~65 % of the f32 matrix rate (two K chunks per tile: a workgroup's first operand load
+    // overlaps nothing of its own) and the 819 MB of stores add ~90 us on top -- HBM writes at ~4.5 TB/s need 180 us and
+    // hide only half under the matrix phases of the neighbours.  Neither static wave priorities by workgroup (s_setprio
+    // 0..3) nor first-round workgroups staggered over eight start times moved it (365-376 us).
+    // Used when rows of S are 16-byte aligned (ldS % 4 == 0 and S aligned); otherwise the dword form below.
+    const bool wide = MI_FS_WIDE && (ldS % 4 == 0) && ((reinterpret_cast<uintptr_t>(S) & 15u) == 0);
+    if (wide) {
+      constexpr int TLD = 68;  // floats per LDS row of the turned sub-tile: 64 + 4 (16-byte aligned rows, staggered banks)
+      __syncthreads();         // every wave is done reading sA / sB
+      float* tw = smem + wv * (32 * TLD);  // 4 waves x 32 x 68 floats = 34 816 B of the 36 864 the operands had
+      const int l16 = lane & 15, lr4 = lane >> 4;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+          const int64_t col = n0 + wn * 64 + n * 32 + i32;
+          const float bcol = (EPI != EPI_NONE && col < N) ? bias[col] : 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            tw[((r & 3) + 8 * (r >> 2) + 4 * hh) * TLD + n * 32 + i32] = epilogue<EPI>(acc[m][n][r], bcol);
+        }
+        __builtin_amdgcn_wave_barrier();  // (the region is this wave's own: LDS operations of one wave complete in order)
+        const int64_t colq = n0 + wn * 64 + l16 * 4;
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+          const int lrow = ps * 4 + lr4;
+          const int64_t row = b0 + wm * 64 + m * 32 + lrow;
+          const f32x4v v = *reinterpret_cast<const f32x4v*>(tw + lrow * TLD + l16 * 4);
+          if (row < B) {
+            float* dst = S + row * ldS + colq;
+            if (colq + 3 < N) {
+              if (EPI == EPI_NONE && MI_FS_NT) __builtin_nontemporal_store(v, reinterpret_cast<f32x4v*>(dst));
+              else *reinterpret_cast<f32x4v*>(dst) = v;
+            } else {  // the catalogue ends inside these four columns
+              if (colq + 0 < N) dst[0] = v.x;
+              if (colq + 1 < N) dst[1] = v.y;
+              if (colq + 2 < N) dst[2] = v.z;
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();  // the reads are issued before the next half overwrites the region
+      }
+      return;
+    }
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
