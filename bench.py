@@ -222,7 +222,7 @@ def pmc_traffic(kernel, args):
         if d.get("shape") != shape:
             continue
         for k, v in d.get("pmc_per_launch", {}).items():
-            if k.startswith(kernel.split("<")[0]) and "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            if k == kernel and "FETCH_SIZE" in v and "WRITE_SIZE" in v:  # (the exact instantiation: the rows / lookup modes are other kernels)
                 per_launch = (2.0 * v["FETCH_SIZE"]["mean"] + v["WRITE_SIZE"]["mean"]) * 1024.0
                 best = (per_launch / max(1, int(v.get("batches_per_launch", 1))), os.path.relpath(f, ROOT))
     return best
