@@ -64,14 +64,16 @@ def test_argument_validation_of_the_widened_entry_points(lib):
     ws = lib.mi_oov_score_topk_masked_workspace(4096, 50_000, 64, 20)                        # lists + 4096 x 782 mask words
     assert ws >= lib.mi_oov_score_topk_workspace(4096, 50_000, 20) + 4096 * 782 * 8
     assert lib.mi_oov_score_topk_masked_workspace(4096, 50_000, 32, 20) == ws                # narrower rows: taken too
-    assert lib.mi_oov_score_topk_masked_workspace(4096, 50_000, 65, 20) == 0                 # D > 64: not taken
+    assert lib.mi_oov_score_topk_masked_workspace(4096, 50_000, 129, 20) == 0                # D > 128: not taken
+    assert lib.mi_oov_score_topk_masked_workspace(4096, 50_000, 65, 20) == ws                # (sized for two k-halves whatever D)
     assert lib.mi_oov_score_topk_masked_workspace(4096, 1000, 64, 20) == 0                   # catalogue < 128 k
-    assert lib.mi_oov_score_topk_masked(None, 4, None, 50_000, 65, 20, 0, None, None, None, None, None, None) == -2
+    assert lib.mi_oov_score_topk_masked(None, 4, None, 50_000, 129, 20, 0, None, None, None, None, None, None) == -2
     assert lib.mi_oov_score_topk_masked(None, 4, None, 50_000, 64, 20, 0, None, None, None, None, None, None) == -1
     assert lib.mi_oov_score_topk_masked(None, 0, None, 50_000, 64, 20, 0, None, None, None, None, None, None) == 0
     assert lib.mi_oov_topk_catalogue_bytes(50_000, 64) >= 50_000 * 128 + 512 * 4            # bf16 rows + partial norm maxima
-    assert lib.mi_oov_topk_catalogue_bytes(50_000, 32) == lib.mi_oov_topk_catalogue_bytes(50_000, 64) and lib.mi_oov_topk_catalogue_bytes(50_000, 65) == 0
-    assert lib.mi_oov_topk_catalogue_prepare(None, 50_000, 65, None, None) == -2
+    assert lib.mi_oov_topk_catalogue_bytes(50_000, 32) == lib.mi_oov_topk_catalogue_bytes(50_000, 64) and lib.mi_oov_topk_catalogue_bytes(50_000, 129) == 0
+    assert lib.mi_oov_topk_catalogue_bytes(50_000, 65) == lib.mi_oov_topk_catalogue_bytes(50_000, 128) >= 50_000 * 256  # two k-halves
+    assert lib.mi_oov_topk_catalogue_prepare(None, 50_000, 129, None, None) == -2
     assert lib.mi_oov_topk_catalogue_prepare(None, 50_000, 64, None, None) == -1
     assert lib.mi_oov_score_topk_prepared(None, 4, None, 50_000, 64, 20, 0, None, None, None, None, None, None, None) == -1
     assert lib.mi_oov_score_topk_prepared(None, 4, None, 1000, 64, 20, 0, None, None, None, None, None, None, None) == -2
