@@ -1,0 +1,454 @@
+// Linear layers of the hash nets on the bf16 matrix cores at f32 accuracy ("split-bf16").
+//
+//   Y = act(X W^T + bias)      (R/inductive/dh_embedder.py:70-89, feat_dh_embedder.py:108-127, dnn_embedder.py:65-90)
+//
+// The f32 matrix instruction (v_mfma_f32_32x32x2_f32, mi_oov_linear_act) runs at 1/16 of the bf16 one's rate, and the
+// 1024-512-512-512-64 net of dhe is 142 GFLOP per 65536 lookups: 1.28 ms at 70 % of the f32 matrix peak.  Here every
+// f32 operand is held as THREE bf16 values h + m + l (round-to-nearest pieces of the running remainder: 3 x 8 = 24
+// significand bits, so h + m + l is the f32 value exactly) and six of the nine cross products are accumulated in f32 on
+// v_mfma_f32_32x32x16_bf16 -- l*h, h*l, m*m, m*h, h*m, h*h; the three left out (m*l, l*m, l*l) are below 2^-24 of
+// |x||w| each.  Every bf16 x bf16 product is exact in f32, so the result differs from the exact dot product by the
+// accumulator's roundings only, like the f32 chain's (measured against f64: the same error as the f32 kernel's or
+// smaller, tests/test_gpu_parity.py::test_linear_x3_*).  It is NOT the oracle's summation order: parity is within a
+// tolerance written in the test, not bit for bit -- mi_oov_linear_act stays the bit-exact form (training uses it).
+//
+// Kernel: a workgroup of WM x WN waves computes a (64 WM) x (32 NB WN) tile, each wave 64 x (32 NB) of it (2 x NB
+// accumulators of 32 x 32).  K is walked 16 at a time through a double-buffered LDS stage (one barrier per stage):
+//   X  : f32 rows straight from the producer -- split into the three planes while staging (6 VALU operations per
+//        element, v_cvt_pk_bf16_f32), so no layer has to write anything but plain f32;
+//   W  : split ONCE per call by linear_x3_split_kernel into [K/16][N padded][3 planes][16] bf16 -- a stage of a
+//        workgroup is one contiguous piece of it.
+// LDS row = the three planes of 16 k side by side + 16 B of padding (112 B): the 16 lanes of a ds_read_b128 phase hit
+// 16 different 16-byte bank groups.  Per 16 k a wave reads (2 + NB) x 3 fragments for 2 NB x 6 matrix instructions.
+#include "common.hpp"
+
+namespace mi_oov {
+
+typedef __bf16 l3_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 l3_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float l3_f32x2 __attribute__((ext_vector_type(2)));
+typedef float l3_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned int l3_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kL3Row = 56;    // bf16 elements per LDS row: 3 x 16 + 8 of padding (112 B)
+constexpr int kL3NPad = 256;  // rows of the split weights are padded to a multiple of this (any tile shape fits)
+
+__host__ __device__ constexpr int64_t l3_np(int64_t N) { return (N + kL3NPad - 1) / kL3NPad * kL3NPad; }
+__host__ __device__ constexpr int64_t l3_chunks(int64_t K) { return (K + 15) / 16; }
+
+// Two f32 -> their three bf16 planes, packed (low half = the first value).  An infinite or NaN value keeps itself in h
+// and zeros below (inf - inf would poison m and l); a finite value above the largest bf16 rounds to inf in h.
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+  const l3_bf16x2 hb = __builtin_convertvector(l3_f32x2{x0, x1}, l3_bf16x2);
+  h = __builtin_bit_cast(uint32_t, hb);
+  const float h0 = __uint_as_float(h << 16), h1 = __uint_as_float(h & 0xFFFF0000u);
+  float r0 = x0 - h0, r1 = x1 - h1;
+  r0 = (__builtin_fabsf(h0) == __builtin_inff() || h0 != h0) ? 0.f : r0;
+  r1 = (__builtin_fabsf(h1) == __builtin_inff() || h1 != h1) ? 0.f : r1;
+  const l3_bf16x2 mb = __builtin_convertvector(l3_f32x2{r0, r1}, l3_bf16x2);
+  m = __builtin_bit_cast(uint32_t, mb);
+  const float m0 = __uint_as_float(m << 16), m1 = __uint_as_float(m & 0xFFFF0000u);
+  const l3_bf16x2 lb = __builtin_convertvector(l3_f32x2{r0 - m0, r1 - m1}, l3_bf16x2);
+  l = __builtin_bit_cast(uint32_t, lb);
+}
+
+__device__ __forceinline__ void split3_x8(const float (&x)[8], l3_u32x4& h, l3_u32x4& m, l3_u32x4& l) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    uint32_t a, b, c;
+    split3_pair(x[2 * i], x[2 * i + 1], a, b, c);
+    h[i] = a, m[i] = b, l[i] = c;
+  }
+}
+
+// 8 consecutive k of one row (zeros beyond the matrix)
+template <bool VEC>
+__device__ __forceinline__ void load8(const float* __restrict__ A, int64_t row, int64_t rows, int64_t K, int64_t k0, float (&x)[8]) {
+  if (row < rows && VEC && k0 + 8 <= K) {
+    const float4 a = *reinterpret_cast<const float4*>(A + row * K + k0);
+    const float4 b = *reinterpret_cast<const float4*>(A + row * K + k0 + 4);
+    x[0] = a.x, x[1] = a.y, x[2] = a.z, x[3] = a.w, x[4] = b.x, x[5] = b.y, x[6] = b.z, x[7] = b.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (row < rows && k0 + i < K) ? A[row * K + k0 + i] : 0.f;
+  }
+}
+
+// W f32[N,K] -> split [K/16][Np][3][16 + pad] bf16: a row of a chunk is the LDS row as it stands (7 units of 16 bytes:
+// unit (chunk * Np + n) * 7 + plane * 2 + half, the seventh = padding), so a stage of a workgroup is one contiguous
+// piece that an LDS-DMA copies without a register in between.
+__global__ __launch_bounds__(kBlock) void linear_x3_split_kernel(const float* __restrict__ W, int64_t N, int64_t K,
+                                                                 l3_u32x4* __restrict__ out) {
+  const int64_t Np = l3_np(N), units = l3_chunks(K) * Np * 2;
+  for (int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; u < units; u += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int half = static_cast<int>(u & 1);
+    const int64_t n = (u >> 1) % Np, chunk = (u >> 1) / Np;
+    float x[8];
+    load8<false>(W, n, N, K, chunk * 16 + half * 8, x);
+    l3_u32x4 h, m, l;
+    split3_x8(x, h, m, l);
+    l3_u32x4* dst = out + (chunk * Np + n) * 7 + half;
+    dst[0] = h, dst[2] = m, dst[4] = l;
+    if (half == 0) dst[6] = l3_u32x4{0u, 0u, 0u, 0u};
+  }
+}
+
+template <int ACT>
+__device__ __forceinline__ float l3_act(float v) {
+  if (ACT == MI_OOV_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // nn.GELU(): erf form
+  if (ACT == MI_OOV_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  return v;
+}
+
+template <int WM, int WN, int NB, int ACT, bool VEC>
+__global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __restrict__ X, int64_t B, int64_t K,
+                                                                 const l3_u32x4* __restrict__ Wp, int64_t N,
+                                                                 const float* __restrict__ bias, float* __restrict__ Y,
+                                                                 int n_nblk, int n_mblk) {
+  constexpr int T = 64 * WM * WN, BMt = 64 * WM, BNt = 32 * NB * WN;
+  constexpr int XU = (BMt * 2 + T - 1) / T;  // 8-float units of X per thread and stage
+  constexpr int WU = (BNt * 6 + T - 1) / T;  // 16-byte units of the split W per thread and stage
+  constexpr int kStage = (BMt + BNt) * kL3Row;  // bf16 elements
+  extern __shared__ __attribute__((aligned(16))) unsigned short l3_lds[];
+
+  // Workgroups that share rows of X (the n-blocks of one m-block) sit next to each other on ONE XCD (consecutive
+  // workgroup ids go round the eight XCDs): the X tile comes out of HBM / the Infinity Cache once per L2.
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int nb_i = slot % n_nblk, mb_i = (slot / n_nblk) * 8 + xcd;
+  if (mb_i >= n_mblk) return;
+  const int64_t b0 = static_cast<int64_t>(mb_i) * BMt, n0 = static_cast<int64_t>(nb_i) * BNt;
+  const int64_t Np = l3_np(N);
+  const int nst = static_cast<int>(l3_chunks(K));
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WN, wn = wv % WN;
+  const int i32 = lane & 31, hh = lane >> 5;
+
+  l3_f32x16 acc[2][NB];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  float xr[XU][8];
+  l3_u32x4 wr[WU];
+  auto gload = [&](int s) {
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+      const int u = tid + T * j;
+      if (BMt * 2 % T == 0 || u < BMt * 2) load8<VEC>(X, b0 + (u >> 1), B, K, static_cast<int64_t>(s) * 16 + (u & 1) * 8, xr[j]);
+    }
+    const l3_u32x4* src = Wp + (static_cast<int64_t>(s) * Np + n0) * 7;
+#pragma unroll
+    for (int j = 0; j < WU; ++j) {
+      const int u = tid + T * j;
+      if (BNt * 6 % T == 0 || u < BNt * 6) wr[j] = src[u + u / 6];
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned short* sX = l3_lds + buf * kStage;
+    unsigned short* sW = sX + BMt * kL3Row;
+#pragma unroll
+    for (int j = 0; j < XU; ++j) {
+      const int u = tid + T * j;
+      if (BMt * 2 % T == 0 || u < BMt * 2) {
+        l3_u32x4 h, m, l;
+        split3_x8(xr[j], h, m, l);
+        unsigned short* d = sX + (u >> 1) * kL3Row + (u & 1) * 8;
+        *reinterpret_cast<l3_u32x4*>(d) = h;
+        *reinterpret_cast<l3_u32x4*>(d + 16) = m;
+        *reinterpret_cast<l3_u32x4*>(d + 32) = l;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < WU; ++j) {
+      const int u = tid + T * j;
+      if (BNt * 6 % T == 0 || u < BNt * 6) *reinterpret_cast<l3_u32x4*>(sW + (u / 6) * kL3Row + (u % 6) * 8) = wr[j];
+    }
+  };
+  auto frag = [&](const unsigned short* base, int row, int plane) {
+    return __builtin_bit_cast(l3_bf16x8, *reinterpret_cast<const l3_u32x4*>(base + row * kL3Row + plane * 16 + hh * 8));
+  };
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int s = 0; s < nst; ++s) {
+    if (s + 1 < nst) gload(s + 1);
+    const unsigned short* sX = l3_lds + (s & 1) * kStage;
+    const unsigned short* sW = sX + BMt * kL3Row;
+    l3_bf16x8 a[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[m][p] = frag(sX, wm * 64 + m * 32 + i32, p);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      l3_bf16x8 b[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[p] = frag(sW, wn * 32 * NB + n * 32 + i32, p);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        // small terms first
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b[0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[2], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[1], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[1], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[0], acc[m][n], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nst) lstore((s + 1) & 1);
+    __syncthreads();
+  }
+
+  // C/D map of the 32x32 shapes: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int64_t col = n0 + wn * 32 * NB + n * 32 + i32;
+    const float bcol = col < N ? bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < B && col < N) Y[row * N + col] = l3_act<ACT>(acc[m][n][r] + bcol);
+      }
+  }
+}
+
+// ---- the fast form: K % 16 == 0, X 16-byte aligned --------------------------------------------------------------------
+// 8 waves, a 256 x 256 tile (each wave 64 x 128: 8 accumulators, 48 matrix instructions per 16 k), one workgroup per CU,
+// two waves per SIMD.  Bytes that reach a CU per matrix instruction are what bounds a tile (L2 serves ~30 B/clk/CU with
+// every CU reading): 16 KB of X + 28 KB of W per 16 k and 384 instructions = 14 B/clk/CU (a 128 x 256 tile: 23).
+//   W : LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no register in between) TWO stages ahead into a
+//       ring of three stage images -- the split weights are stored as the LDS image;
+//   X : one register set per thread (8 floats = 16 k of half a... of one row): split and written into the NEXT stage's
+//       image (ring of two) while the matrix instructions of this stage run, then re-issued at once for the stage after.
+// One raw s_barrier per stage; the waits are counted by hand (the DMA is not in the compiler's bookkeeping): before the
+// barrier of stage s everything but this wave's loads for stage s + 2 has landed.
+constexpr int kFastM = 256, kFastN = 256, kFastNB = 4, kFastT = 512;
+constexpr int kFastWStage = kFastN * kL3Row * 2;  // bytes of a W stage image (28 672 = 28 DMA pieces of 1 KiB)
+constexpr int kFastXStage = kFastM * kL3Row * 2;
+constexpr int kFastLds = 3 * kFastWStage + 2 * kFastXStage;  // 143 360 B
+constexpr int kFastPieces = kFastWStage / 1024;
+
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+
+template <int ACT>
+__global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __restrict__ X, int64_t B, int64_t K,
+                                                               const l3_u32x4* __restrict__ Wp, int64_t N,
+                                                               const float* __restrict__ bias, float* __restrict__ Y,
+                                                               int n_nblk, int n_mblk) {
+  constexpr int NB = kFastNB;
+  extern __shared__ __attribute__((aligned(16))) unsigned short l3_lds[];  // [3][W stage][2][X stage]
+  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+  const int nb_i = slot % n_nblk, mb_i = (slot / n_nblk) * 8 + xcd;
+  if (mb_i >= n_mblk) return;
+  const int64_t b0 = static_cast<int64_t>(mb_i) * kFastM, n0 = static_cast<int64_t>(nb_i) * kFastN;
+  const int64_t Np = l3_np(N);
+  const int nst = static_cast<int>(K / 16);
+
+  const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wv >> 1, wn = wv & 1;
+  const int i32 = lane & 31, hh = lane >> 5;
+  const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned short*)l3_lds));
+
+  l3_f32x16 acc[2][NB];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+  // X: row tid / 2 of the tile (rows beyond B: the last row again -- computed, never stored), k half tid % 2
+  const int64_t xrow = (b0 + (tid >> 1) < B) ? b0 + (tid >> 1) : B - 1;
+  const float* xsrc = X + xrow * K + (tid & 1) * 8;
+  unsigned short* xdst = l3_lds + 3 * (kFastWStage / 2) + (tid >> 1) * kL3Row + (tid & 1) * 8;
+  // W: piece wv + 8 j of a stage image (pieces 0 .. 27)
+  const char* wsrc = reinterpret_cast<const char*>(Wp) + n0 * (kL3Row * 2) + wv * 1024 + lane * 16;
+  const int64_t wstep = Np * (kL3Row * 2);
+
+  auto dma_w = [&](int s) {
+    const uint32_t dst = lds_base + static_cast<uint32_t>(s % 3) * kFastWStage + wv * 1024;
+    const char* src = wsrc + static_cast<int64_t>(s) * wstep;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < 3 || wv < kFastPieces - 24) glds16(src + j * 8192, dst + j * 8192);
+  };
+  float4 xa, xb;
+  auto load_x = [&](int s) {
+    xa = *reinterpret_cast<const float4*>(xsrc + static_cast<int64_t>(s) * 16);
+    xb = *reinterpret_cast<const float4*>(xsrc + static_cast<int64_t>(s) * 16 + 4);
+  };
+  auto store_x = [&](int s) {
+    const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+    l3_u32x4 h, m, l;
+    split3_x8(x, h, m, l);
+    unsigned short* d = xdst + (s & 1) * (kFastXStage / 2);
+    *reinterpret_cast<l3_u32x4*>(d) = h;
+    *reinterpret_cast<l3_u32x4*>(d + 16) = m;
+    *reinterpret_cast<l3_u32x4*>(d + 32) = l;
+  };
+  auto frag = [&](const unsigned short* base, int row, int plane) {
+    return __builtin_bit_cast(l3_bf16x8, *reinterpret_cast<const l3_u32x4*>(base + row * kL3Row + plane * 16 + hh * 8));
+  };
+
+  dma_w(0);
+  if (nst > 1) dma_w(1);
+  load_x(0);
+  store_x(0);
+  if (nst > 1) load_x(1);
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int s = 0; s < nst; ++s) {
+    const bool more2 = s + 2 < nst;
+    if (more2) dma_w(s + 2);
+    const unsigned short* sW = l3_lds + (s % 3) * (kFastWStage / 2);
+    const unsigned short* sX = l3_lds + 3 * (kFastWStage / 2) + (s & 1) * (kFastXStage / 2);
+    l3_bf16x8 a[2][3], b[2][3];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) a[m][p] = frag(sX, wm * 64 + m * 32 + i32, p);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) b[0][p] = frag(sW, wn * 128 + i32, p);
+#pragma unroll
+    for (int n = 0; n < NB; ++n) {
+      if (n + 1 < NB) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) b[(n + 1) & 1][p] = frag(sW, wn * 128 + (n + 1) * 32 + i32, p);
+      }
+      if (n == 1 && s + 1 < nst) {
+        store_x(s + 1);
+        if (more2) load_x(s + 2);
+      }
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const l3_bf16x8* bb = b[n & 1];
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], bb[0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[2], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bb[1], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bb[0], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[1], acc[m][n], 0, 0, 0);
+        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[0], acc[m][n], 0, 0, 0);
+      }
+    }
+    // everything older than this stage's own loads (W of stage s + 2: 3 or 4 pieces, X of stage s + 2: 2 loads) has
+    // landed: W of stage s + 1 among it.  In the last two stages nothing younger was issued: drain.
+    if (more2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
+    const int64_t col = n0 + wn * 128 + n * 32 + i32;
+    const float bcol = col < N ? bias[col] : 0.f;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (row < B && col < N) Y[row * N + col] = l3_act<ACT>(acc[m][n][r] + bcol);
+      }
+  }
+}
+
+template <int ACT>
+static int launch_x3_fast(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N, float* Y, hipStream_t st) {
+  const int64_t n_mblk = (B + kFastM - 1) / kFastM, n_nblk = (N + kFastN - 1) / kFastN;
+  const int64_t grid = (n_mblk + 7) / 8 * 8 * n_nblk;
+  if (grid > 0x7FFFFFFF) return MI_OOV_ERR_SHAPE;
+  auto k = linear_x3_fast_kernel<ACT>;
+  if (int rc = set_lds(k, kFastLds)) return rc;
+  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(kFastT), kFastLds, st, X, B, K, static_cast<const l3_u32x4*>(wsplit), N, bias, Y,
+                     static_cast<int>(n_nblk), static_cast<int>(n_mblk));
+  return check_launch();
+}
+
+template <int WM, int WN, int NB, int ACT, bool VEC>
+static int launch_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N, float* Y, hipStream_t st) {
+  constexpr int T = 64 * WM * WN, BMt = 64 * WM, BNt = 32 * NB * WN;
+  const int64_t n_mblk = (B + BMt - 1) / BMt, n_nblk = (N + BNt - 1) / BNt;
+  const int64_t grid = (n_mblk + 7) / 8 * 8 * n_nblk;
+  if (grid > 0x7FFFFFFF || n_mblk > 0x7FFFFFFF) return MI_OOV_ERR_SHAPE;
+  const size_t lds = 2 * static_cast<size_t>(BMt + BNt) * kL3Row * sizeof(unsigned short);
+  auto k = linear_x3_kernel<WM, WN, NB, ACT, VEC>;
+  if (int rc = set_lds(k, lds)) return rc;
+  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(T), lds, st, X, B, K, static_cast<const l3_u32x4*>(wsplit), N, bias, Y,
+                     static_cast<int>(n_nblk), static_cast<int>(n_mblk));
+  return check_launch();
+}
+
+template <int WM, int WN, int NB>
+static int launch_x3_act(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N, int act, float* Y, hipStream_t st) {
+  const bool vec = (K % 4 == 0) && aligned16(X);
+#define MI_L3(A)                                                                                   \
+  return vec ? launch_x3<WM, WN, NB, A, true>(X, B, K, wsplit, bias, N, Y, st)                     \
+             : launch_x3<WM, WN, NB, A, false>(X, B, K, wsplit, bias, N, Y, st);
+  switch (act) {
+    case MI_OOV_ACT_NONE: MI_L3(MI_OOV_ACT_NONE)
+    case MI_OOV_ACT_GELU: MI_L3(MI_OOV_ACT_GELU)
+    default: MI_L3(MI_OOV_ACT_SIGMOID)
+  }
+#undef MI_L3
+}
+
+}  // namespace mi_oov
+
+using namespace mi_oov;
+
+extern "C" int64_t mi_oov_linear_x3_weights_bytes(int64_t N_out, int64_t K) {
+  if (N_out <= 0 || K <= 0) return MI_OOV_ERR_SHAPE;
+  return l3_chunks(K) * l3_np(N_out) * 112;
+}
+
+extern "C" int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream) {
+  if (N_out <= 0 || K <= 0) return MI_OOV_ERR_SHAPE;
+  if (!W || !wsplit) return MI_OOV_ERR_NULL;
+  if (!aligned16(wsplit)) return MI_OOV_ERR_ALIGN;
+  const int64_t units = l3_chunks(K) * l3_np(N_out) * 2;
+  const int64_t grid = (units + kBlock - 1) / kBlock;
+  hipLaunchKernelGGL(linear_x3_split_kernel, dim3(static_cast<unsigned>(grid < kMaxGrid ? grid : kMaxGrid)), dim3(kBlock), 0,
+                     static_cast<hipStream_t>(stream), W, N_out, K, static_cast<l3_u32x4*>(wsplit));
+  return check_launch();
+}
+
+extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N_out,
+                                int act, float* Y, void* stream) {
+  if (B < 0 || K <= 0 || N_out <= 0) return MI_OOV_ERR_SHAPE;
+  if (act < 0 || act > 2) return MI_OOV_ERR_KIND;
+  if (B == 0) return MI_OOV_OK;
+  if (!X || !wsplit || !bias || !Y) return MI_OOV_ERR_NULL;
+  if (!aligned16(wsplit)) return MI_OOV_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  static const int shape = static_cast<int>(env_knob("MI_OOV_X3_SHAPE", 0, 0, 4));
+  // the pipelined 256 x 256 form: K a multiple of 16 (no tail chunk), rows of X 16-byte aligned, outputs wider than 128
+  if ((shape == 0 || shape == 4) && K % 16 == 0 && aligned16(X) && N_out > 128 && B >= 1) {
+    switch (act) {
+      case MI_OOV_ACT_NONE: return launch_x3_fast<MI_OOV_ACT_NONE>(X, B, K, wsplit, bias, N_out, Y, st);
+      case MI_OOV_ACT_GELU: return launch_x3_fast<MI_OOV_ACT_GELU>(X, B, K, wsplit, bias, N_out, Y, st);
+      default: return launch_x3_fast<MI_OOV_ACT_SIGMOID>(X, B, K, wsplit, bias, N_out, Y, st);
+    }
+  }
+  // narrow outputs (the last layer of the nets, 64 wide): a 128 x 64 tile; otherwise 128 x 256
+  if (N_out <= 64 && shape == 0) return launch_x3_act<2, 2, 1>(X, B, K, wsplit, bias, N_out, act, Y, st);
+  if (N_out <= 128 && shape == 0) return launch_x3_act<2, 2, 2>(X, B, K, wsplit, bias, N_out, act, Y, st);
+  switch (shape) {
+    case 1: return launch_x3_act<2, 2, 2>(X, B, K, wsplit, bias, N_out, act, Y, st);
+    case 2: return launch_x3_act<4, 2, 4>(X, B, K, wsplit, bias, N_out, act, Y, st);
+    case 3: return launch_x3_act<2, 2, 1>(X, B, K, wsplit, bias, N_out, act, Y, st);
+    default: return launch_x3_act<2, 2, 4>(X, B, K, wsplit, bias, N_out, act, Y, st);
+  }
+}

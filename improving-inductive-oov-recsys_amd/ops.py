@@ -957,6 +957,53 @@ def linear_act(X, W, bias, act=None):
     return Y
 
 
+class LinearX3Weights:
+    """A Linear layer's weight split into its three bf16 planes for `linear_act_x3` (mi_oov_linear_x3_prepare): made
+    once and re-made when the weight tensor was written to since (torch's version counter, as `LshTable`; after a write
+    through `.data` call `invalidate()`)."""
+
+    __slots__ = ("weight", "split", "version")
+
+    def __init__(self, weight):
+        self.weight, self.split, self.version = weight, None, None
+
+    def invalidate(self):
+        self.version = None
+
+    def get(self):
+        w = self.weight
+        if self.split is None or self.version != w._version or self.split.device != w.device:
+            src = _f32(w, "W")
+            n, k = src.shape
+            nbytes = int(C.lib().mi_oov_linear_x3_weights_bytes(n, k))
+            if nbytes <= 0:
+                raise ValueError(f"unsupported weight shape {tuple(src.shape)}")
+            if self.split is None or self.split.numel() != nbytes or self.split.device != w.device:
+                self.split = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            with C.on_device(src):
+                rc = C.lib().mi_oov_linear_x3_prepare(C.ptr(src), n, k, C.ptr(self.split), C.stream_of(src))
+            C.check(rc, "mi_oov_linear_x3_prepare")
+            self.version = w._version
+        return self.split
+
+
+def linear_act_x3(X, W, bias, act=None, weights=None):
+    """act(X @ W.T + bias) on the bf16 matrix cores at f32 accuracy (mi_oov_linear_x3: every operand as three bf16
+    planes, six products accumulated in f32; csrc/linear3.hip).  The inference form of the hash nets' layers
+    (dh_embedder.py:70-89): within an f32 accumulation's error of `linear_act`, not bit-identical to it.  `weights`: a
+    `LinearX3Weights` of W to reuse its split."""
+    X, W, bias = _f32(X, "X"), _f32(W, "W"), _f32(bias, "bias")
+    if X.shape[1] != W.shape[1] or bias.numel() != W.shape[0]:
+        raise ValueError(f"shape mismatch: X {tuple(X.shape)}, W {tuple(W.shape)}, bias {tuple(bias.shape)}")
+    split = (weights if weights is not None else LinearX3Weights(W)).get()
+    Y = torch.empty((X.shape[0], W.shape[0]), dtype=torch.float32, device=X.device)
+    with C.on_device(X):
+        rc = C.lib().mi_oov_linear_x3(C.ptr(X), X.shape[0], X.shape[1], C.ptr(split), C.ptr(bias), W.shape[0], ACTS[act],
+                                      C.ptr(Y), C.stream_of(X))
+    C.check(rc, "mi_oov_linear_x3")
+    return Y
+
+
 def _hash_net_layers(net):
     """[(Linear, act name or None), ...] of an nn.Sequential of Linear / GELU (erf form) / Sigmoid."""
     mods, layers, i = list(net), [], 0

@@ -341,6 +341,23 @@ enum { MI_OOV_ACT_NONE = 0, MI_OOV_ACT_GELU = 1, MI_OOV_ACT_SIGMOID = 2 };
 int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, const float* bias,
                       int64_t N_out, int act, float* Y, void* stream);
 
+/* The same layer on the bf16 matrix cores at f32 accuracy (csrc/linear3.hip; the inference form of the hash nets,
+ * dh_embedder.py:140-170 -> 70-89).  Every f32 operand is held as three bf16 values h + m + l (= the f32 value exactly)
+ * and six of the nine cross products are accumulated in f32 on v_mfma_f32_32x32x16_bf16; the three left out are below
+ * 2^-24 |x||w| each.  Error against the exact dot product: that of an f32 accumulation (not larger than the f32 chain's
+ * of mi_oov_linear_act, measured), but NOT the oracle's summation order -- parity is within the tolerance written in
+ * tests/test_gpu_parity.py::test_linear_x3_vs_oracle, not bit for bit.  An operand above the largest bf16 (3.39e38)
+ * counts as infinite.
+ *   mi_oov_linear_x3_weights_bytes(N_out, K)   bytes of the split weights (three planes, rows padded to 256, K to 16)
+ *   mi_oov_linear_x3_prepare(W, N_out, K, wsplit, stream)     W f32[N_out,K] -> wsplit (16-byte aligned); once per
+ *                                                             weight update (a few microseconds)
+ *   mi_oov_linear_x3(X, B, K, wsplit, bias, N_out, act, Y, stream)   Y f32[B,N_out] = act(X W^T + bias); X is split
+ *                                                             inside the kernel while it is staged.                   */
+int64_t mi_oov_linear_x3_weights_bytes(int64_t N_out, int64_t K);
+int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream);
+int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias,
+                     int64_t N_out, int act, float* Y, void* stream);
+
 /* Training of the hash nets on this library's GEMM (csrc/mlp.hip): what torch autograd does for the reference's
  * nn.Sequential(Linear, GELU, ..., Linear, Sigmoid) (dh_embedder.py:70-89,191-217, dnn_embedder.py:65-109).
  *   forward   Z = mi_oov_linear_act(X, W, b, MI_OOV_ACT_NONE);  Y = mi_oov_act_forward(Z, act)      (Z is kept)

@@ -84,6 +84,13 @@ def main():
             x = ops.linear_act(x, w, b_, "gelu" if j < 3 else "sigmoid")
         return x
 
+    x3w = [ops.LinearX3Weights(w) for w in Ws]
+
+    def mlp_x3(x):
+        for j, (w, b_) in enumerate(zip(Ws, bs)):
+            x = ops.linear_act_x3(x, w, b_, "gelu" if j < 3 else "sigmoid", x3w[j])
+        return x
+
     bits8 = (torch.rand((B, H), generator=g, device=dev) < 0.5).to(torch.uint8)
     bits8[:, 0] = 1
     idx9 = torch.randint(0, 9, (8, B), generator=g, device=dev)
@@ -111,6 +118,9 @@ def main():
         "full_sort_scores B=4096 N=50000": (lambda i: ops.full_sort_scores(U, E), Bs * Ns, 4, 2 * D),
         "score_topk k=20 B=4096 N=50000": (lambda i: ops.score_topk(U, E, 20, 1), Bs * Ns, 0, 2 * D),
         "dhe MLP 1024-512-512-512-64 (4 x linear_act)": (lambda i: mlp(hashes), B, 0, 2 * (1024 * 512 + 2 * 512 * 512 + 512 * 64)),
+        "dhe MLP 1024-512-512-512-64 (4 x linear_x3, split bf16)": (lambda i: mlp_x3(hashes), B, 0, 2 * (1024 * 512 + 2 * 512 * 512 + 512 * 64)),
+        "linear_x3 65536 x 1024 -> 512 (gelu)": (lambda i: ops.linear_act_x3(hashes, Ws[0], bs[0], "gelu", x3w[0]), B, 0, 2 * 1024 * 512),
+        "linear_act 65536 x 1024 -> 512 (gelu, f32 MFMA)": (lambda i: ops.linear_act(hashes, Ws[0], bs[0], "gelu"), B, 0, 2 * 1024 * 512),
         "lsh_embed_backward H=8 (bucket-table grad)": (lambda i: ops.lsh_embed_backward(bits8, users[i % 8]), B, H + 4 * D, 0),
         "slsh_embed_backward nb=9": (lambda i: ops.slsh_embed_backward(idx9[i % 8], users[i % 8], 9), B, 8 + 4 * D, 0),
         "scatter_add_rows into 10M x 64 (gather backward)": (lambda i: ops.scatter_add_rows(ids[i], users[i % 8], N, out=gtab), B, 8 + 12 * D, 0),
@@ -196,7 +206,7 @@ def main():
             cases[f"score_topk sweep k={k_} B={b_} N={n_}"] = (lambda i, U_=U_, E_=E_, k_=k_: ops.score_topk(U_, E_, k_, 1), b_ * n_, 0, 2 * D)
     with torch.no_grad():
         for name, (fn, units, bpu, fpu) in cases.items():
-            if args.only and args.only not in name:
+            if args.only and not any(o in name for o in args.only.split(",")):
                 continue
             us = timeit(fn, args.iters if units < 10 ** 8 else 5)
             print(json.dumps({"case": name, "us_per_launch": round(us, 2), "units_per_launch": units,
