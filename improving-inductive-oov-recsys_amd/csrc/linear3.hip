@@ -36,15 +36,14 @@ constexpr int kL3NPad = 256;  // rows of the split weights are padded to a multi
 __host__ __device__ constexpr int64_t l3_np(int64_t N) { return (N + kL3NPad - 1) / kL3NPad * kL3NPad; }
 __host__ __device__ constexpr int64_t l3_chunks(int64_t K) { return (K + 15) / 16; }
 
-// Two f32 -> their three bf16 planes, packed (low half = the first value).  An infinite or NaN value keeps itself in h
-// and zeros below (inf - inf would poison m and l); a finite value above the largest bf16 rounds to inf in h.
+// Two f32 -> their three bf16 planes, packed (low half = the first value).  Finite values only: an infinite operand (or
+// a finite one above the largest bf16, 3.39e38, which rounds to inf in h) leaves inf - inf = NaN in the lower planes, so
+// where the f32 product would hold +-inf or NaN this one holds NaN -- non-finite in, non-finite out.
 __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
   const l3_bf16x2 hb = __builtin_convertvector(l3_f32x2{x0, x1}, l3_bf16x2);
   h = __builtin_bit_cast(uint32_t, hb);
   const float h0 = __uint_as_float(h << 16), h1 = __uint_as_float(h & 0xFFFF0000u);
-  float r0 = x0 - h0, r1 = x1 - h1;
-  r0 = (__builtin_fabsf(h0) == __builtin_inff() || h0 != h0) ? 0.f : r0;
-  r1 = (__builtin_fabsf(h1) == __builtin_inff() || h1 != h1) ? 0.f : r1;
+  const float r0 = x0 - h0, r1 = x1 - h1;
   const l3_bf16x2 mb = __builtin_convertvector(l3_f32x2{r0, r1}, l3_bf16x2);
   m = __builtin_bit_cast(uint32_t, mb);
   const float m0 = __uint_as_float(m << 16), m1 = __uint_as_float(m & 0xFFFF0000u);
@@ -95,9 +94,33 @@ __global__ __launch_bounds__(kBlock) void linear_x3_split_kernel(const float* __
 
 template <int ACT>
 __device__ __forceinline__ float l3_act(float v) {
-  if (ACT == MI_OOV_ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));  // nn.GELU(): erf form
-  if (ACT == MI_OOV_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));
+  if (ACT == MI_OOV_ACT_SIGMOID) return 1.0f / (1.0f + expf(-v));  // (GELU: l3_gelu2 below)
   return v;
+}
+
+// nn.GELU() (erf form) of two values, 0.5 v (1 + erf(v / sqrt 2)), for the tiles' epilogues: the device library's erff is
+// two polynomial branches that a wave of mixed arguments executes both of (~35 instructions per value; a 256 x 256 tile
+// has 128 values per lane and nothing else runs on the CU meanwhile).  Here erfc(t) = 2^(-t Q(t)) on t = min(|v| / sqrt 2, 4),
+// Q of degree 8 (weighted minimax fit, tools/fit_gelu.py), one v_exp_f32, packed f32 arithmetic: |erf error| <= 1.0e-7, and
+// over v in [-8, 8] the result is within 2.5e-7 (8.1e-8 max(|v|, 1)) of the exact GELU -- the reference's own expression
+// evaluated in f32 with a perfect erf: 4.5e-7 (1.1e-7 max(|v|, 1)); its 1 + erf cancels for negative v.
+typedef float l3_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ l3_f2 l3_gelu2(l3_f2 v) {
+  const l3_f2 t = __builtin_elementwise_min(__builtin_elementwise_abs(v * 0.70710678118654752440f), l3_f2{4.f, 4.f});
+  l3_f2 q = l3_f2{1.160470219e-05f, 1.160470219e-05f};  // -Q: the exponent comes out negated
+  q = __builtin_elementwise_fma(q, t, l3_f2{-1.529632864e-04f, -1.529632864e-04f});
+  q = __builtin_elementwise_fma(q, t, l3_f2{8.482300327e-04f, 8.482300327e-04f});
+  q = __builtin_elementwise_fma(q, t, l3_f2{-2.274776343e-03f, -2.274776343e-03f});
+  q = __builtin_elementwise_fma(q, t, l3_f2{8.479427197e-05f, 8.479427197e-05f});
+  q = __builtin_elementwise_fma(q, t, l3_f2{2.772448398e-02f, 2.772448398e-02f});
+  q = __builtin_elementwise_fma(q, t, l3_f2{-1.483079195e-01f, -1.483079195e-01f});
+  q = __builtin_elementwise_fma(q, t, l3_f2{-9.184429049e-01f, -9.184429049e-01f});
+  q = __builtin_elementwise_fma(q, t, l3_f2{-1.627907276e+00f, -1.627907276e+00f});
+  const l3_f2 a = t * q;
+  const l3_f2 e = l3_f2{__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};  // erfc(t)
+  const l3_f2 h = (v * 0.5f) * e;
+  const l3_f2 pos = v - h;  // v > 0: 0.5 v (2 - erfc t)
+  return l3_f2{v.x > 0.f ? pos.x : h.x, v.y > 0.f ? pos.y : h.y};
 }
 
 template <int WM, int WN, int NB, int ACT, bool VEC>
@@ -212,9 +235,13 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < B && col < N) Y[row * N + col] = l3_act<ACT>(acc[m][n][r] + bcol);
+      for (int r = 0; r < 16; r += 2) {
+        l3_f2 y = l3_f2{acc[m][n][r] + bcol, acc[m][n][r + 1] + bcol};
+        if (ACT == MI_OOV_ACT_GELU) y = l3_gelu2(y);
+        if (ACT == MI_OOV_ACT_SIGMOID) y = l3_f2{l3_act<ACT>(y.x), l3_act<ACT>(y.y)};
+        const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;  // and row + 1
+        if (row < B && col < N) Y[row * N + col] = y.x;
+        if (row + 1 < B && col < N) Y[(row + 1) * N + col] = y.y;
       }
   }
 }
@@ -229,6 +256,9 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
 //       image (ring of two) while the matrix instructions of this stage run, then re-issued at once for the stage after.
 // One raw s_barrier per stage; the waits are counted by hand (the DMA is not in the compiler's bookkeeping): before the
 // barrier of stage s everything but this wave's loads for stage s + 2 has landed.
+#ifndef L3_KO_MFMA
+#define L3_KO_MFMA 0
+#endif
 constexpr int kFastM = 256, kFastN = 256, kFastNB = 4, kFastT = 512;
 constexpr int kFastWStage = kFastN * kL3Row * 2;  // bytes of a W stage image (28 672 = 28 DMA pieces of 1 KiB)
 constexpr int kFastXStage = kFastM * kL3Row * 2;
@@ -250,51 +280,58 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
                                                                int n_nblk, int n_mblk) {
   constexpr int NB = kFastNB;
   extern __shared__ __attribute__((aligned(16))) unsigned short l3_lds[];  // [3][W stage][2][X stage]
-  const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
-  const int nb_i = slot % n_nblk, mb_i = (slot / n_nblk) * 8 + xcd;
-  if (mb_i >= n_mblk) return;
-  const int64_t b0 = static_cast<int64_t>(mb_i) * kFastM, n0 = static_cast<int64_t>(nb_i) * kFastN;
   const int64_t Np = l3_np(N);
-  const int nst = static_cast<int>(K / 16);
+  const int nst = static_cast<int>(K / 16);  // >= 2 (host)
+  const int total = (n_mblk + 7) / 8 * 8 * n_nblk, step = gridDim.x;  // step % 8 == 0: a workgroup's tiles stay on its XCD
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 1, wn = wv & 1;
   const int i32 = lane & 31, hh = lane >> 5;
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned short*)l3_lds));
 
-  l3_f32x16 acc[2][NB];
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int n = 0; n < NB; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
-
-  // X: row tid / 2 of the tile (rows beyond B: the last row again -- computed, never stored), k half tid % 2
-  const int64_t xrow = (b0 + (tid >> 1) < B) ? b0 + (tid >> 1) : B - 1;
-  const float* xsrc = X + xrow * K + (tid & 1) * 8;
-  unsigned short* xdst = l3_lds + 3 * (kFastWStage / 2) + (tid >> 1) * kL3Row + (tid & 1) * 8;
-  // W: piece wv + 8 j of a stage image (pieces 0 .. 27)
-  const char* wsrc = reinterpret_cast<const char*>(Wp) + n0 * (kL3Row * 2) + wv * 1024 + lane * 16;
+  // Tiles: id = slot * 8 + xcd; the n-blocks of one m-block are consecutive slots of ONE XCD (consecutive workgroup
+  // ids go round the eight XCDs), so the X rows they share come out of HBM / the Infinity Cache once per L2.  A
+  // workgroup walks ids blockIdx.x, + gridDim.x, ... (persistent: one workgroup per CU) and treats its tiles as ONE
+  // stream of stages -- the loads of the next tile's first two stages are issued during the last two of this one, the
+  // accumulators are stored in between, nothing restarts.
+  struct Tile { int64_t b0, n0; const float* xsrc; const char* wsrc; };
   const int64_t wstep = Np * (kL3Row * 2);
+  auto valid = [&](int id) { return id < total && ((id >> 3) / n_nblk) * 8 + (id & 7) < n_mblk; };
+  auto next_valid = [&](int id) { while (id < total && !valid(id)) id += step; return id; };
+  auto decode = [&](int id) {
+    Tile t;
+    const int slot = id >> 3;
+    t.b0 = static_cast<int64_t>((slot / n_nblk) * 8 + (id & 7)) * kFastM;
+    t.n0 = static_cast<int64_t>(slot % n_nblk) * kFastN;
+    const int64_t xrow = (t.b0 + (tid >> 1) < B) ? t.b0 + (tid >> 1) : B - 1;  // rows beyond B: the last row again (never stored)
+    t.xsrc = X + xrow * K + (tid & 1) * 8;
+    t.wsrc = reinterpret_cast<const char*>(Wp) + t.n0 * (kL3Row * 2) + wv * 1024 + lane * 16;
+    return t;
+  };
+  int id = next_valid(blockIdx.x);
+  if (id >= total) return;
+  Tile cur = decode(id);
+  int nid = next_valid(id + step);
+  Tile nxt = decode(nid < total ? nid : id);
 
-  auto dma_w = [&](int s) {
-    const uint32_t dst = lds_base + static_cast<uint32_t>(s % 3) * kFastWStage + wv * 1024;
-    const char* src = wsrc + static_cast<int64_t>(s) * wstep;
+  unsigned short* xdst = l3_lds + 3 * (kFastWStage / 2) + (tid >> 1) * kL3Row + (tid & 1) * 8;
+  auto dma_w = [&](const Tile& t, int s, int g) {  // stage s of tile t = stage g of the stream: W ring slot g % 3
+    const uint32_t dst = lds_base + static_cast<uint32_t>(g % 3) * kFastWStage + wv * 1024;
+    const char* src = t.wsrc + static_cast<int64_t>(s) * wstep;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if (j < 3 || wv < kFastPieces - 24) glds16(src + j * 8192, dst + j * 8192);
   };
   float4 xa, xb;
-  auto load_x = [&](int s) {
-    xa = *reinterpret_cast<const float4*>(xsrc + static_cast<int64_t>(s) * 16);
-    xb = *reinterpret_cast<const float4*>(xsrc + static_cast<int64_t>(s) * 16 + 4);
+  auto load_x = [&](const Tile& t, int s) {
+    xa = *reinterpret_cast<const float4*>(t.xsrc + static_cast<int64_t>(s) * 16);
+    xb = *reinterpret_cast<const float4*>(t.xsrc + static_cast<int64_t>(s) * 16 + 4);
   };
-  auto store_x = [&](int s) {
+  auto store_x = [&](int g) {
     const float x[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
     l3_u32x4 h, m, l;
     split3_x8(x, h, m, l);
-    unsigned short* d = xdst + (s & 1) * (kFastXStage / 2);
+    unsigned short* d = xdst + (g & 1) * (kFastXStage / 2);
     *reinterpret_cast<l3_u32x4*>(d) = h;
     *reinterpret_cast<l3_u32x4*>(d + 16) = m;
     *reinterpret_cast<l3_u32x4*>(d + 32) = l;
@@ -303,73 +340,114 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
     return __builtin_bit_cast(l3_bf16x8, *reinterpret_cast<const l3_u32x4*>(base + row * kL3Row + plane * 16 + hh * 8));
   };
 
-  dma_w(0);
-  if (nst > 1) dma_w(1);
-  load_x(0);
+  int g = 0;  // stage of the stream
+  dma_w(cur, 0, 0);
+  dma_w(cur, 1, 1);
+  load_x(cur, 0);
   store_x(0);
-  if (nst > 1) load_x(1);
+  load_x(cur, 1);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  for (int s = 0; s < nst; ++s) {
-    const bool more2 = s + 2 < nst;
-    if (more2) dma_w(s + 2);
-    const unsigned short* sW = l3_lds + (s % 3) * (kFastWStage / 2);
-    const unsigned short* sX = l3_lds + 3 * (kFastWStage / 2) + (s & 1) * (kFastXStage / 2);
-    l3_bf16x8 a[2][3], b[2][3];
+  while (true) {
+    const bool has_next = nid < total;
+    l3_f32x16 acc[2][NB];
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[m][p] = frag(sX, wm * 64 + m * 32 + i32, p);
+      for (int n = 0; n < NB; ++n)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) b[0][p] = frag(sW, wn * 128 + i32, p);
+        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    for (int s = 0; s < nst; ++s, ++g) {
+      // stage g + 2 of the stream: stage s + 2 of this tile, or stage s + 2 - nst of the next one
+      const bool wrap2 = s + 2 >= nst, more2 = !wrap2 || has_next;
+      const bool wrap1 = s + 1 >= nst, more1 = !wrap1 || has_next;
+#ifndef L3_KO_DMA
+      if (more2) dma_w(wrap2 ? nxt : cur, wrap2 ? s + 2 - nst : s + 2, g + 2);
+#endif
+      const unsigned short* sW = l3_lds + (g % 3) * (kFastWStage / 2);
+      const unsigned short* sX = l3_lds + 3 * (kFastWStage / 2) + (g & 1) * (kFastXStage / 2);
+      l3_bf16x8 a[2][3], b[2][3];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[m][p] = frag(sX, wm * 64 + m * 32 + i32, p);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) b[0][p] = frag(sW, wn * 128 + i32, p);
+#pragma unroll
+      for (int n = 0; n < NB; ++n) {
+        if (n + 1 < NB) {
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[(n + 1) & 1][p] = frag(sW, wn * 128 + (n + 1) * 32 + i32, p);
+        }
+#ifndef L3_KO_X
+        if (n == 1 && more1) {  // the registers hold stage g + 1: split it into the other X image, re-issue for stage g + 2
+#ifndef L3_KO_CVT
+          store_x(g + 1);
+#endif
+          if (more2) load_x(wrap2 ? nxt : cur, wrap2 ? s + 2 - nst : s + 2);
+        }
+#endif
+#pragma unroll
+        for (int m = 0; m < (L3_KO_MFMA ? 0 : 2); ++m) {
+          const l3_bf16x8* bb = b[n & 1];
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], bb[0], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[2], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bb[1], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bb[0], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[1], acc[m][n], 0, 0, 0);
+          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[0], acc[m][n], 0, 0, 0);
+        }
+      }
+      // Everything older than this stage's own loads (W of stage g + 2: 3 or 4 pieces, X of stage g + 2: 2 loads) has
+      // landed: W of stage g + 1 among it (and, after a tile's end, the stores of its accumulators: the vector memory
+      // counter retires in order).  Nothing younger was issued in the stream's last two stages: drain.
+      if (more2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+
+    // C/D map of the 32x32 shapes: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll
     for (int n = 0; n < NB; ++n) {
-      if (n + 1 < NB) {
+      const int64_t col = cur.n0 + wn * 128 + n * 32 + i32;
+      const float bcol = col < N ? bias[col] : 0.f;
 #pragma unroll
-        for (int p = 0; p < 3; ++p) b[(n + 1) & 1][p] = frag(sW, wn * 128 + (n + 1) * 32 + i32, p);
-      }
-      if (n == 1 && s + 1 < nst) {
-        store_x(s + 1);
-        if (more2) load_x(s + 2);
-      }
+      for (int m = 0; m < 2; ++m)
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const l3_bf16x8* bb = b[n & 1];
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], bb[0], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[2], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bb[1], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bb[0], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[1], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[0], acc[m][n], 0, 0, 0);
-      }
+        for (int r = 0; r < 16; r += 2) {
+          l3_f2 y = l3_f2{acc[m][n][r] + bcol, acc[m][n][r + 1] + bcol};
+          if (ACT == MI_OOV_ACT_GELU) y = l3_gelu2(y);
+          if (ACT == MI_OOV_ACT_SIGMOID) y = l3_f2{l3_act<ACT>(y.x), l3_act<ACT>(y.y)};
+          const int64_t row = cur.b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;  // and row + 1
+#if defined(L3_KO_STORE)
+          if (row < B && col < N && y.x == 12345.678f) Y[row * N + col] = y.x;
+#else
+          if (row < B && col < N) Y[row * N + col] = y.x;
+          if (row + 1 < B && col < N) Y[(row + 1) * N + col] = y.y;
+#endif
+        }
     }
-    // everything older than this stage's own loads (W of stage s + 2: 3 or 4 pieces, X of stage s + 2: 2 loads) has
-    // landed: W of stage s + 1 among it.  In the last two stages nothing younger was issued: drain.
-    if (more2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-  }
-
-#pragma unroll
-  for (int n = 0; n < NB; ++n) {
-    const int64_t col = n0 + wn * 128 + n * 32 + i32;
-    const float bcol = col < N ? bias[col] : 0.f;
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-        if (row < B && col < N) Y[row * N + col] = l3_act<ACT>(acc[m][n][r] + bcol);
-      }
+    if (!has_next) break;
+    id = nid;
+    cur = nxt;
+    nid = next_valid(id + step);
+    nxt = decode(nid < total ? nid : id);
   }
 }
 
 template <int ACT>
 static int launch_x3_fast(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N, float* Y, hipStream_t st) {
   const int64_t n_mblk = (B + kFastM - 1) / kFastM, n_nblk = (N + kFastN - 1) / kFastN;
-  const int64_t grid = (n_mblk + 7) / 8 * 8 * n_nblk;
-  if (grid > 0x7FFFFFFF) return MI_OOV_ERR_SHAPE;
+  const int64_t total = (n_mblk + 7) / 8 * 8 * n_nblk;
+  if (total > 0x7FFFFFFF) return MI_OOV_ERR_SHAPE;
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+    return n / 8 * 8;
+  }();
+  const int64_t grid = total < cus ? total : cus;  // one workgroup per CU (143 KB of LDS each); total % 8 == 0
   auto k = linear_x3_fast_kernel<ACT>;
   if (int rc = set_lds(k, kFastLds)) return rc;
   hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(kFastT), kFastLds, st, X, B, K, static_cast<const l3_u32x4*>(wsplit), N, bias, Y,
@@ -435,7 +513,7 @@ extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void
   hipStream_t st = static_cast<hipStream_t>(stream);
   static const int shape = static_cast<int>(env_knob("MI_OOV_X3_SHAPE", 0, 0, 4));
   // the pipelined 256 x 256 form: K a multiple of 16 (no tail chunk), rows of X 16-byte aligned, outputs wider than 128
-  if ((shape == 0 || shape == 4) && K % 16 == 0 && aligned16(X) && N_out > 128 && B >= 1) {
+  if ((shape == 0 || shape == 4) && K % 16 == 0 && K >= 32 && aligned16(X) && N_out > 128) {
     switch (act) {
       case MI_OOV_ACT_NONE: return launch_x3_fast<MI_OOV_ACT_NONE>(X, B, K, wsplit, bias, N_out, Y, st);
       case MI_OOV_ACT_GELU: return launch_x3_fast<MI_OOV_ACT_GELU>(X, B, K, wsplit, bias, N_out, Y, st);

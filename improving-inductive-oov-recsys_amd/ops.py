@@ -7,6 +7,9 @@ is itself made of this library's kernels (deterministic bucket reductions, mi_oo
 GEMM + mi_oov_transpose + mi_oov_act_backward for the hash nets and the full-sort scores): torch autograd links
 the pieces and computes nothing.  Nothing here ever computes on the CPU.
 """
+import os
+import weakref
+
 import torch
 
 from . import _cabi as C
@@ -962,16 +965,19 @@ class LinearX3Weights:
     once and re-made when the weight tensor was written to since (torch's version counter, as `LshTable`; after a write
     through `.data` call `invalidate()`)."""
 
-    __slots__ = ("weight", "split", "version")
+    __slots__ = ("_weight", "split", "version")
 
     def __init__(self, weight):
-        self.weight, self.split, self.version = weight, None, None
+        self._weight = weakref.ref(weight)  # (weak: hash_net_forward keys its cache of these by the weight tensor)
+        self.split, self.version = None, None
 
     def invalidate(self):
         self.version = None
 
     def get(self):
-        w = self.weight
+        w = self._weight()
+        if w is None:
+            raise RuntimeError("the weight tensor of this LinearX3Weights is gone")
         if self.split is None or self.version != w._version or self.split.device != w.device:
             src = _f32(w, "W")
             n, k = src.shape
@@ -1021,12 +1027,36 @@ def _hash_net_layers(net):
     return layers
 
 
+# Batches from this many rows on take the split-bf16 layers in `hash_net_forward` (below it the f32 kernel's launch is as
+# quick and bit-identical to the oracle's chain).  MI_OOV_LINEAR_X3=0 keeps every batch on the f32 kernel, =1 puts
+# every batch on the split one.
+_X3_MIN_ROWS = 1024
+_x3_weights = weakref.WeakKeyDictionary()  # Linear.weight -> LinearX3Weights
+
+
+def _x3_wanted(rows):
+    mode = os.environ.get("MI_OOV_LINEAR_X3", "")
+    if mode == "0":
+        return False
+    return mode == "1" or rows >= _X3_MIN_ROWS
+
+
 def hash_net_forward(net, x):
-    """Run an nn.Sequential of Linear / GELU / Sigmoid (the reference's *_hash_net) through
-    mi_oov_linear_act, fusing each activation into the producing layer's epilogue.  Inference form; under autograd
-    `hash_net_train` keeps the pre-activations and supplies the backward on the same GEMM kernel."""
+    """Run an nn.Sequential of Linear / GELU / Sigmoid (the reference's *_hash_net, dh_embedder.py:70-89) with each
+    activation fused into the producing layer's epilogue.  Inference form: batches of `_X3_MIN_ROWS` rows or more run
+    on the bf16 matrix cores at f32 accuracy (`linear_act_x3`; the weights' three-plane split is kept per weight tensor
+    and re-made when the tensor's version counter moves), smaller ones on the f32 matrix instruction (`linear_act`,
+    bit-identical to the oracle's chain).  Under autograd `hash_net_train` keeps the pre-activations and supplies the
+    backward on the f32 GEMM kernel."""
+    x3 = _x3_wanted(x.shape[0])
     for lin, act in _hash_net_layers(net):
-        x = linear_act(x, lin.weight, lin.bias, act)
+        if x3:
+            w = _x3_weights.get(lin.weight)
+            if w is None:
+                w = _x3_weights[lin.weight] = LinearX3Weights(lin.weight)
+            x = linear_act_x3(x, lin.weight, lin.bias, act, w)
+        else:
+            x = linear_act(x, lin.weight, lin.bias, act)
     return x
 
 

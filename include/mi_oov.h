@@ -346,8 +346,8 @@ int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, cons
  * and six of the nine cross products are accumulated in f32 on v_mfma_f32_32x32x16_bf16; the three left out are below
  * 2^-24 |x||w| each.  Error against the exact dot product: that of an f32 accumulation (not larger than the f32 chain's
  * of mi_oov_linear_act, measured), but NOT the oracle's summation order -- parity is within the tolerance written in
- * tests/test_gpu_parity.py::test_linear_x3_vs_oracle, not bit for bit.  An operand above the largest bf16 (3.39e38)
- * counts as infinite.
+ * tests/test_gpu_parity.py::test_linear_x3_vs_oracle, not bit for bit.  Finite operands only: where an
+ * operand is infinite, NaN or above the largest bf16 (3.39e38) the result is NaN (the f32 product: +-inf or NaN).
  *   mi_oov_linear_x3_weights_bytes(N_out, K)   bytes of the split weights (three planes, rows padded to 256, K to 16)
  *   mi_oov_linear_x3_prepare(W, N_out, K, wsplit, stream)     W f32[N_out,K] -> wsplit (16-byte aligned); once per
  *                                                             weight update (a few microseconds)

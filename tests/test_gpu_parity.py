@@ -268,6 +268,86 @@ def test_linear_act_vs_oracle(B, K, N_out, oracle, ops, dev):
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
 
 
+# mi_oov_linear_x3: the same layer on the bf16 matrix cores, every operand as three bf16 planes.  NOT the oracle's summation
+# order, so parity is a tolerance: with u = 2^-24 (half an f32 ulp) the f32 chain's own error against the exact value is
+# bounded by K u sum|x||w| and is ~sqrt(K) u of it in practice; the split form drops three cross terms below u |x||w| each and
+# otherwise rounds only in the f32 accumulator.  Bound asserted: 8 u (sum_k |x_k||w_k| + |b|) against the ORACLE (both sides'
+# error together; measured: 2.3e-7 = 4 u at K = 1024), and against an f64 product the split form may not be further off than
+# twice the f32 kernel.
+X3_SHAPES = [(300, 1024, 512),   # the pipelined 256 x 256 form (K % 16 == 0, N_out > 128): two row blocks, ragged
+             (2100, 512, 512),   # nine row blocks: the XCD remap leaves seven slots of the last round empty
+             (513, 512, 64),     # narrow output: 128 x 64 tiles
+             (257, 70, 130),     # K with a tail chunk, N_out ragged
+             (64, 22, 512),      # dnn embedder's first layer (22 feature columns)
+             (5, 1030, 33),      # K % 4 != 0: scalar loads
+             (1, 16, 1)]
+
+
+@pytest.mark.parametrize("B,K,N_out", X3_SHAPES)
+def test_linear_x3_vs_oracle(B, K, N_out, oracle, ops, dev):
+    rng = np.random.default_rng(B + K + N_out)
+    X = (rng.random((B, K)) * 2 - 1).astype(np.float32)
+    X[0, : min(K, 5)] = [1e-30, -3e4, 0.0, 2.0 ** -100, 1e20][: min(K, 5)]  # small, large and zero operands
+    W = (rng.standard_normal((N_out, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N_out).astype(np.float32)
+    want = oracle.linear_act(X, W, b, 0)
+    den = np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)
+    u = 2.0 ** -24
+    got = ops.linear_act_x3(T(X, dev), T(W, dev), T(b, dev), None).cpu().numpy()
+    assert np.all(np.abs(got.astype(np.float64) - want) <= 8 * u * den)
+    truth = X.astype(np.float64) @ W.astype(np.float64).T + b
+    e_x3, e_f32 = np.abs(got - truth) / den, np.abs(want - truth) / den
+    assert e_x3.max() <= 2 * e_f32.max() + 2 * u and np.sqrt((e_x3 ** 2).mean()) <= 2 * np.sqrt((e_f32 ** 2).mean()) + u
+    for name, act in (("gelu", 1), ("sigmoid", 2)):  # both activations are 1.13-Lipschitz at most
+        got = ops.linear_act_x3(T(X, dev), T(W, dev), T(b, dev), name).cpu().numpy()
+        w_act = oracle.linear_act(X, W, b, act)
+        assert np.all(np.abs(got.astype(np.float64) - w_act) <= 10 * u * den + 2e-6 * np.abs(w_act) + 1e-7), name
+
+
+def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
+    """Non-finite operands give non-finite results exactly where the f32 product does (NaN where that holds +-inf: the lower
+    planes of an infinite value are inf - inf); the split weights follow the weight tensor's version counter."""
+    rng = np.random.default_rng(9)
+    X = rng.standard_normal((130, 64)).astype(np.float32)
+    W = rng.standard_normal((200, 64)).astype(np.float32)
+    b = np.zeros(200, np.float32)
+    X[3, 7], X[5, 0], X[9, 1] = np.inf, np.nan, -np.inf
+    got = ops.linear_act_x3(T(X, dev), T(W, dev), T(b, dev), None).cpu().numpy()
+    want = oracle.linear_act(X, W, b, 0)
+    assert np.array_equal(np.isfinite(got), np.isfinite(want)) and not np.isfinite(want[[3, 5, 9]]).any() and np.isfinite(want[10:]).all()
+    Wt, Xt, bt = T(W, dev), T(X[10:], dev), T(b, dev)
+    cache = ops.LinearX3Weights(Wt)
+    y0 = ops.linear_act_x3(Xt, Wt, bt, None, cache)
+    first = cache.get()
+    assert cache.get() is first and cache.version == Wt._version
+    with torch.no_grad():
+        Wt.mul_(2.0)
+    y1 = ops.linear_act_x3(Xt, Wt, bt, None, cache)  # re-split: an exact doubling
+    assert torch.equal(y1, 2 * y0)
+    Wt.data.mul_(0.5)  # a write through .data moves no counter: invalidate() by hand
+    cache.invalidate()
+    assert torch.equal(ops.linear_act_x3(Xt, Wt, bt, None, cache), y0)
+
+
+def test_hash_net_forward_takes_the_split_layers_from_1024_rows(ops, dev, monkeypatch):
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(48, 512), torch.nn.GELU(), torch.nn.Linear(512, 64), torch.nn.Sigmoid()).to(dev)
+    calls = {"x3": 0, "f32": 0}
+    real_x3, real_f32 = ops.linear_act_x3, ops.linear_act
+    monkeypatch.setattr(ops, "linear_act_x3", lambda *a, **k: (calls.__setitem__("x3", calls["x3"] + 1), real_x3(*a, **k))[1])
+    monkeypatch.setattr(ops, "linear_act", lambda *a, **k: (calls.__setitem__("f32", calls["f32"] + 1), real_f32(*a, **k))[1])
+    x = torch.rand((1500, 48), device=dev) * 2 - 1
+    with torch.no_grad():
+        big, small, ref = ops.hash_net_forward(net, x), ops.hash_net_forward(net, x[:100]), net(x)
+    assert calls == {"x3": 2, "f32": 2}
+    assert torch.allclose(big, ref, rtol=1e-5, atol=1e-6) and torch.allclose(small, ref[:100], rtol=1e-5, atol=1e-6)
+    monkeypatch.setenv("MI_OOV_LINEAR_X3", "0")
+    with torch.no_grad():
+        exact = ops.hash_net_forward(net, x)
+    assert calls == {"x3": 2, "f32": 4} and torch.equal(exact[:100], small)
+    assert (exact - big).abs().max().item() <= 1e-6
+
+
 def test_topk_edge_cases(oracle, ops, dev):
     rng = np.random.default_rng(3)
     U = rng.standard_normal((17, 8), dtype=np.float32)

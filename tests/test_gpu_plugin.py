@@ -104,9 +104,11 @@ def test_slsh_embedder_class(mi, golden, dev):
     assert np.array_equal(model.user_oov_buckets.weight.grad[:, 0].cpu().numpy(), want)
 
 
-def test_dhe_embedder_class(mi, golden, dev, tmp_path, monkeypatch):
+@pytest.mark.parametrize("x3", ["0", "1"])  # the f32 matrix instruction / the split-bf16 layers (what batches >= 1024 rows take)
+def test_dhe_embedder_class(mi, golden, dev, tmp_path, monkeypatch, x3):
     z, s = golden("dhe.npz"), golden("siphash.json")
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("MI_OOV_LINEAR_X3", x3)
     os.makedirs("hash_keys")
     json.dump(s["dhe_keys"], open("hash_keys/16.hashes", "w"))  # the reference's key file protocol
     ft = mi.FeatureTable({"id": torch.arange(64), "f": torch.zeros(64)})
@@ -119,7 +121,7 @@ def test_dhe_embedder_class(mi, golden, dev, tmp_path, monkeypatch):
     ids = T(z["ids"], dev)
     with torch.no_grad():
         hashes = emb._hash_ids(ids)
-        pre = emb.item_hash_net[:-1](hashes)
+        pre = mi.ops.hash_net_forward(emb.item_hash_net[:-1], hashes)
         out = emb.embed_item_ids(ids, None)
     assert np.array_equal(hashes.cpu().numpy(), z["hashes"])  # bit-exact integer work
     # raw hashes (~1e7) feed the first Linear un-normalised: compare pre-sigmoid with a GEMM-order tolerance
@@ -666,7 +668,8 @@ def test_driver_evaluate_queues_its_batches(mi, dev):
     assert "overall" in res["queued"][0] and "new_users" in res["queued"][0]
 
 
-def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkeypatch):
+@pytest.mark.parametrize("x3", ["0", "1"])  # the f32 matrix instruction / the split-bf16 layers (K + F = 46 columns: a tail chunk)
+def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkeypatch, x3):
     """'fdhe' pinned on the REAL FeatDeepHashEmbedder (tests/golden/make_golden_fdhe.py; feat_dh_embedder.py:86-210): the
     feature matrices the constructor builds (per-column L2 normalisation), the hash matrix of the UN-stripped ids
     (identical integers), the MLP input (hashes ++ feature row of the STRIPPED id), pre-sigmoid activations within the
@@ -675,6 +678,8 @@ def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkey
     z = golden("fdhe.npz")
     K, D, L, n = (int(v) for v in z["dims"])
     monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("MI_OOV_LINEAR_X3", x3)
+    linear = mi.ops.linear_act_x3 if x3 == "1" else mi.ops.linear_act
     os.makedirs("hash_keys")
     json.dump([bytes(k).hex() for k in z["keys"]], open(f"hash_keys/{K}.hashes", "w"))  # the reference's key file protocol
     ft_u = mi.FeatureTable({"user_id": torch.arange(n), "age": torch.from_numpy(z["user_age"]), "vec": torch.from_numpy(z["user_vec"])})
@@ -704,7 +709,7 @@ def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkey
                 pre = x
                 layers = mi.ops._hash_net_layers(net)
                 for j, (lin, act) in enumerate(layers):  # this library's GEMM, the last activation left off
-                    pre = mi.ops.linear_act(pre, lin.weight, lin.bias, act if j + 1 < len(layers) else None)
+                    pre = linear(pre, lin.weight, lin.bias, act if j + 1 < len(layers) else None)
             assert torch.equal(ids, keep)  # fdhe strips a COPY (feat_dh_embedder.py:182-185)
             assert np.array_equal(hashes.cpu().numpy(), z[f"{mode}_{side}_hashes"])
             assert np.allclose(x.cpu().numpy(), z[f"{mode}_{side}_input"], rtol=1e-6, atol=1e-7)
