@@ -999,7 +999,10 @@ def linear_act_x3(X, W, bias, act=None, weights=None):
     (dh_embedder.py:70-89): within an f32 accumulation's error of `linear_act`, not bit-identical to it.  `weights`: a
     `LinearX3Weights` of W to reuse its split."""
     X, W, bias = _f32(X, "X"), _f32(W, "W"), _f32(bias, "bias")
-    if X.shape[1] != W.shape[1] or bias.numel() != W.shape[0]:
+    K = W.shape[1]
+    # X may carry the columns up to the next multiple of 16 (finite values: they meet the zero weights the split pads
+    # with) -- rows of a multiple of 16 floats take the pipelined kernel, see `hash_net_forward`
+    if (X.shape[1] != K and X.shape[1] != -(-K // 16) * 16) or bias.numel() != W.shape[0]:
         raise ValueError(f"shape mismatch: X {tuple(X.shape)}, W {tuple(W.shape)}, bias {tuple(bias.shape)}")
     split = (weights if weights is not None else LinearX3Weights(W)).get()
     Y = torch.empty((X.shape[0], W.shape[0]), dtype=torch.float32, device=X.device)
@@ -1031,7 +1034,15 @@ def _hash_net_layers(net):
 # quick and bit-identical to the oracle's chain).  MI_OOV_LINEAR_X3=0 keeps every batch on the f32 kernel, =1 puts
 # every batch on the split one.
 _X3_MIN_ROWS = 1024
-_x3_weights = weakref.WeakKeyDictionary()  # Linear.weight -> LinearX3Weights
+_x3_weights = {}  # id(Linear.weight) -> LinearX3Weights (which holds the tensor weakly; dropped when the tensor dies)
+
+
+def _x3_weights_of(weight):
+    w = _x3_weights.get(id(weight))
+    if w is None or w._weight() is not weight:
+        w = _x3_weights[id(weight)] = LinearX3Weights(weight)
+        weakref.finalize(weight, _x3_weights.pop, id(weight), None)
+    return w
 
 
 def _x3_wanted(rows):
@@ -1045,16 +1056,16 @@ def hash_net_forward(net, x):
     """Run an nn.Sequential of Linear / GELU / Sigmoid (the reference's *_hash_net, dh_embedder.py:70-89) with each
     activation fused into the producing layer's epilogue.  Inference form: batches of `_X3_MIN_ROWS` rows or more run
     on the bf16 matrix cores at f32 accuracy (`linear_act_x3`; the weights' three-plane split is kept per weight tensor
-    and re-made when the tensor's version counter moves), smaller ones on the f32 matrix instruction (`linear_act`,
+    and re-made when the tensor's version counter moves; an input whose width is not a multiple of 16 is padded with
+    zero columns once), smaller ones on the f32 matrix instruction (`linear_act`,
     bit-identical to the oracle's chain).  Under autograd `hash_net_train` keeps the pre-activations and supplies the
     backward on the f32 GEMM kernel."""
     x3 = _x3_wanted(x.shape[0])
     for lin, act in _hash_net_layers(net):
         if x3:
-            w = _x3_weights.get(lin.weight)
-            if w is None:
-                w = _x3_weights[lin.weight] = LinearX3Weights(lin.weight)
-            x = linear_act_x3(x, lin.weight, lin.bias, act, w)
+            if x.shape[1] % 16:  # (fdhe: K hashes + F feature columns) zero columns up to a multiple of 16: the pipelined kernel
+                x = torch.nn.functional.pad(x, (0, -x.shape[1] % 16))
+            x = linear_act_x3(x, lin.weight, lin.bias, act, _x3_weights_of(lin.weight))
         else:
             x = linear_act(x, lin.weight, lin.bias, act)
     return x

@@ -352,7 +352,11 @@ int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, cons
  *   mi_oov_linear_x3_prepare(W, N_out, K, wsplit, stream)     W f32[N_out,K] -> wsplit (16-byte aligned); once per
  *                                                             weight update (a few microseconds)
  *   mi_oov_linear_x3(X, B, K, wsplit, bias, N_out, act, Y, stream)   Y f32[B,N_out] = act(X W^T + bias); X is split
- *                                                             inside the kernel while it is staged.                   */
+ *                                                             inside the kernel while it is staged.
+ * K here is the row length of X: the K the weights were prepared with, or that rounded up to a multiple of 16 -- the
+ * columns beyond the weights' K meet the zeros the split is padded with (they must hold finite values).  Rows of a
+ * multiple of 16 floats, 16-byte aligned, K >= 32 and N_out > 128 take the pipelined 256 x 256 kernel (one persistent
+ * workgroup per CU, weights by LDS-DMA); everything else a generic tile kernel of the same arithmetic.                 */
 int64_t mi_oov_linear_x3_weights_bytes(int64_t N_out, int64_t K);
 int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream);
 int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias,

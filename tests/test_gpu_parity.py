@@ -304,6 +304,35 @@ def test_linear_x3_vs_oracle(B, K, N_out, oracle, ops, dev):
         assert np.all(np.abs(got.astype(np.float64) - w_act) <= 10 * u * den + 2e-6 * np.abs(w_act) + 1e-7), name
 
 
+def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev):
+    """(a) An input padded to a multiple of 16 columns (what hash_net_forward hands over for fdhe's K + F columns) gives the
+    pipelined kernel the same arithmetic: bit-identical to the generic kernel on the unpadded rows.  (b) BASELINE's dhe
+    shape, 65536 x 1024 -> 512: every row block agrees with the f32 kernel within the bound of test_linear_x3_vs_oracle,
+    and the result does not depend on how the batch is cut (rows of a 65536-row call == the same rows in a 4096-row call)."""
+    rng = np.random.default_rng(77)
+    B, K, N_out = 700, 1046, 300
+    X = (rng.random((B, K)) * 2 - 1).astype(np.float32)
+    W = (rng.standard_normal((N_out, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N_out).astype(np.float32)
+    Xt, Wt, bt = T(X, dev), T(W, dev), T(b, dev)
+    Xpad = torch.nn.functional.pad(Xt, (0, -K % 16))
+    plain, padded = ops.linear_act_x3(Xt, Wt, bt, "gelu"), ops.linear_act_x3(Xpad, Wt, bt, "gelu")
+    assert torch.equal(plain, padded)
+    with pytest.raises(ValueError):
+        ops.linear_act_x3(torch.nn.functional.pad(Xt, (0, 1)), Wt, bt, None)
+    g = torch.Generator(device=dev).manual_seed(5)
+    B, K, N_out = 65536, 1024, 512
+    Xb = torch.rand((B, K), generator=g, device=dev) * 2 - 1
+    Wb = torch.randn((N_out, K), generator=g, device=dev) / 32
+    bb = torch.randn((N_out,), generator=g, device=dev)
+    y = ops.linear_act_x3(Xb, Wb, bb, None)
+    ref = ops.linear_act(Xb, Wb, bb, None)  # the bit-exact kernel (pinned on the oracle at small sizes)
+    den = Xb.abs() @ Wb.abs().T + bb.abs()
+    assert bool(((y - ref).abs() <= 8 * 2.0 ** -24 * den).all())
+    part = ops.linear_act_x3(Xb[61440:], Wb, bb, None)
+    assert torch.equal(part, y[61440:])
+
+
 def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
     """Non-finite operands give non-finite results exactly where the f32 product does (NaN where that holds +-inf: the lower
     planes of an infinite value are inf - inf); the split weights follow the weight tensor's version counter."""
