@@ -437,16 +437,21 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
   }
 }
 
-template <int ACT>
-static int launch_x3_fast(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N, float* Y, hipStream_t st) {
-  const int64_t n_mblk = (B + kFastM - 1) / kFastM, n_nblk = (N + kFastN - 1) / kFastN;
-  const int64_t total = (n_mblk + 7) / 8 * 8 * n_nblk;
-  if (total > 0x7FFFFFFF) return MI_OOV_ERR_SHAPE;
+static int l3_cus() {  // compute units of the current device, rounded down to a multiple of 8 (the XCDs)
   static const int cus = [] {
     int dev = 0, n = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
     return n / 8 * 8;
   }();
+  return cus;
+}
+
+template <int ACT>
+static int launch_x3_fast(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N, float* Y, hipStream_t st) {
+  const int64_t n_mblk = (B + kFastM - 1) / kFastM, n_nblk = (N + kFastN - 1) / kFastN;
+  const int64_t total = (n_mblk + 7) / 8 * 8 * n_nblk;
+  if (total > 0x7FFFFFFF) return MI_OOV_ERR_SHAPE;
+  const int cus = l3_cus();
   const int64_t grid = total < cus ? total : cus;  // one workgroup per CU (143 KB of LDS each); total % 8 == 0
   auto k = linear_x3_fast_kernel<ACT>;
   if (int rc = set_lds(k, kFastLds)) return rc;
@@ -511,9 +516,16 @@ extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void
   if (!X || !wsplit || !bias || !Y) return MI_OOV_ERR_NULL;
   if (!aligned16(wsplit)) return MI_OOV_ERR_ALIGN;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  static const int shape = static_cast<int>(env_knob("MI_OOV_X3_SHAPE", 0, 0, 4));
+  // developer knob, read per call (the tests force the pipelined kernel onto small shapes with it): 0 = by shape,
+  // 1 / 2 / 3 = the generic kernel with 128 x 128 / 256 x 256 / 128 x 64 tiles, 4 = the pipelined kernel where it applies.
+  // Every form does the same arithmetic in the same order: results do not depend on it.
+  const int shape = static_cast<int>(env_knob("MI_OOV_X3_SHAPE", 0, 0, 4));
   // the pipelined 256 x 256 form: K a multiple of 16 (no tail chunk), rows of X 16-byte aligned, outputs wider than 128
-  if ((shape == 0 || shape == 4) && K % 16 == 0 && K >= 32 && aligned16(X) && N_out > 128) {
+  // ... when its 256 x 256 tiles fill more than half of the CUs: a tile is 122 us of one CU at K = 1024 however few
+  // there are, so smaller batches are quicker as four times as many 128 x 128 tiles (65536 x 1024 -> 512, us by rows,
+  // pipelined / 128 x 128: 4096 126 / 76, 16384 136 / 117, 24576 153 / 184, 65536 337 / 433)
+  const int64_t tiles256 = ((B + kFastM - 1) / kFastM) * ((N_out + kFastN - 1) / kFastN);
+  if ((shape == 4 || (shape == 0 && tiles256 > l3_cus() / 2)) && K % 16 == 0 && K >= 32 && aligned16(X) && N_out > 128) {
     switch (act) {
       case MI_OOV_ACT_NONE: return launch_x3_fast<MI_OOV_ACT_NONE>(X, B, K, wsplit, bias, N_out, Y, st);
       case MI_OOV_ACT_GELU: return launch_x3_fast<MI_OOV_ACT_GELU>(X, B, K, wsplit, bias, N_out, Y, st);
@@ -522,7 +534,7 @@ extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void
   }
   // narrow outputs (the last layer of the nets, 64 wide): a 128 x 64 tile; otherwise 128 x 256
   if (N_out <= 64 && shape == 0) return launch_x3_act<2, 2, 1>(X, B, K, wsplit, bias, N_out, act, Y, st);
-  if (N_out <= 128 && shape == 0) return launch_x3_act<2, 2, 2>(X, B, K, wsplit, bias, N_out, act, Y, st);
+  if ((N_out <= 128 || tiles256 <= l3_cus() / 2) && shape == 0) return launch_x3_act<2, 2, 2>(X, B, K, wsplit, bias, N_out, act, Y, st);
   switch (shape) {
     case 1: return launch_x3_act<2, 2, 2>(X, B, K, wsplit, bias, N_out, act, Y, st);
     case 2: return launch_x3_act<4, 2, 4>(X, B, K, wsplit, bias, N_out, act, Y, st);

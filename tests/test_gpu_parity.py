@@ -276,6 +276,8 @@ def test_linear_act_vs_oracle(B, K, N_out, oracle, ops, dev):
 # twice the f32 kernel.
 X3_SHAPES = [(300, 1024, 512),   # the pipelined 256 x 256 form (K % 16 == 0, N_out > 128): two row blocks, ragged
              (2100, 512, 512),   # nine row blocks: the XCD remap leaves seven slots of the last round empty
+             (700, 64, 300),     # four stages per tile, the last n-block ragged
+             (40, 32, 129),      # two stages: the shortest stream the pipelined kernel takes
              (513, 512, 64),     # narrow output: 128 x 64 tiles
              (257, 70, 130),     # K with a tail chunk, N_out ragged
              (64, 22, 512),      # dnn embedder's first layer (22 feature columns)
@@ -283,8 +285,12 @@ X3_SHAPES = [(300, 1024, 512),   # the pipelined 256 x 256 form (K % 16 == 0, N_
              (1, 16, 1)]
 
 
+@pytest.mark.parametrize("form", ["0", "4"])  # MI_OOV_X3_SHAPE: by shape (small batches: 128 x 128 tiles) / the pipelined kernel wherever it applies
 @pytest.mark.parametrize("B,K,N_out", X3_SHAPES)
-def test_linear_x3_vs_oracle(B, K, N_out, oracle, ops, dev):
+def test_linear_x3_vs_oracle(B, K, N_out, form, oracle, ops, dev, monkeypatch):
+    if form == "4" and not (K % 16 == 0 and K >= 32 and N_out > 128):
+        pytest.skip("shape outside the pipelined kernel")
+    monkeypatch.setenv("MI_OOV_X3_SHAPE", form)
     rng = np.random.default_rng(B + K + N_out)
     X = (rng.random((B, K)) * 2 - 1).astype(np.float32)
     X[0, : min(K, 5)] = [1e-30, -3e4, 0.0, 2.0 ** -100, 1e20][: min(K, 5)]  # small, large and zero operands
@@ -304,7 +310,7 @@ def test_linear_x3_vs_oracle(B, K, N_out, oracle, ops, dev):
         assert np.all(np.abs(got.astype(np.float64) - w_act) <= 10 * u * den + 2e-6 * np.abs(w_act) + 1e-7), name
 
 
-def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev):
+def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev, monkeypatch):
     """(a) An input padded to a multiple of 16 columns (what hash_net_forward hands over for fdhe's K + F columns) gives the
     pipelined kernel the same arithmetic: bit-identical to the generic kernel on the unpadded rows.  (b) BASELINE's dhe
     shape, 65536 x 1024 -> 512: every row block agrees with the f32 kernel within the bound of test_linear_x3_vs_oracle,
@@ -316,7 +322,10 @@ def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev):
     b = rng.standard_normal(N_out).astype(np.float32)
     Xt, Wt, bt = T(X, dev), T(W, dev), T(b, dev)
     Xpad = torch.nn.functional.pad(Xt, (0, -K % 16))
-    plain, padded = ops.linear_act_x3(Xt, Wt, bt, "gelu"), ops.linear_act_x3(Xpad, Wt, bt, "gelu")
+    plain = ops.linear_act_x3(Xt, Wt, bt, "gelu")
+    monkeypatch.setenv("MI_OOV_X3_SHAPE", "4")  # (by shape a batch this small takes 128 x 128 tiles)
+    padded = ops.linear_act_x3(Xpad, Wt, bt, "gelu")
+    monkeypatch.delenv("MI_OOV_X3_SHAPE")
     assert torch.equal(plain, padded)
     with pytest.raises(ValueError):
         ops.linear_act_x3(torch.nn.functional.pad(Xt, (0, 1)), Wt, bt, None)

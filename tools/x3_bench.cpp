@@ -58,8 +58,9 @@ int main(int argc, char** argv) {
   unsigned long long* cs;
   CK(hipMalloc(&X, B * K * 4)); CK(hipMalloc(&W, N * K * 4)); CK(hipMalloc(&bias, N * 4)); CK(hipMalloc(&Y, B * N * 4));
   CK(hipMalloc(&ws, wbytes(N, K))); CK(hipMalloc(&cs, 8));
-  fill_f32<<<2048, 256>>>(X, B * K, 1, 1.0f);
-  fill_f32<<<256, 256>>>(W, N * K, 2, 0.03f);
+  const float zs = getenv("XB_ZERO") ? 0.f : 1.f;  // zero operands: what the matrix pipe does when no bit toggles
+  fill_f32<<<2048, 256>>>(X, B * K, 1, 1.0f * zs);
+  fill_f32<<<256, 256>>>(W, N * K, 2, 0.03f * zs);
   fill_f32<<<1, 256>>>(bias, N, 3, 0.1f);
   CK(hipDeviceSynchronize());
   hipEvent_t e0, e1;
