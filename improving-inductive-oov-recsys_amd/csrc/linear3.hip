@@ -73,9 +73,9 @@ __device__ __forceinline__ void load8(const float* __restrict__ A, int64_t row, 
   }
 }
 
-// W f32[N,K] -> split [K/16][Np][3][16 + pad] bf16: a row of a chunk is the LDS row as it stands (7 units of 16 bytes:
-// unit (chunk * Np + n) * 7 + plane * 2 + half, the seventh = padding), so a stage of a workgroup is one contiguous
-// piece that an LDS-DMA copies without a register in between.
+// W f32[N,K] -> split [K/16][Np][3][16] bf16: a row of a chunk is the pipelined kernel's LDS row as it stands (6 units of
+// 16 bytes: unit (chunk * Np + n) * 6 + plane * 2 + half), so a stage of a workgroup is one contiguous piece that an
+// LDS-DMA copies without a register in between.
 __global__ __launch_bounds__(kBlock) void linear_x3_split_kernel(const float* __restrict__ W, int64_t N, int64_t K,
                                                                  l3_u32x4* __restrict__ out) {
   const int64_t Np = l3_np(N), units = l3_chunks(K) * Np * 2;
@@ -86,9 +86,8 @@ __global__ __launch_bounds__(kBlock) void linear_x3_split_kernel(const float* __
     load8<false>(W, n, N, K, chunk * 16 + half * 8, x);
     l3_u32x4 h, m, l;
     split3_x8(x, h, m, l);
-    l3_u32x4* dst = out + (chunk * Np + n) * 7 + half;
+    l3_u32x4* dst = out + (chunk * Np + n) * 6 + half;
     dst[0] = h, dst[2] = m, dst[4] = l;
-    if (half == 0) dst[6] = l3_u32x4{0u, 0u, 0u, 0u};
   }
 }
 
@@ -163,11 +162,11 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
       const int u = tid + T * j;
       if (BMt * 2 % T == 0 || u < BMt * 2) load8<VEC>(X, b0 + (u >> 1), B, K, static_cast<int64_t>(s) * 16 + (u & 1) * 8, xr[j]);
     }
-    const l3_u32x4* src = Wp + (static_cast<int64_t>(s) * Np + n0) * 7;
+    const l3_u32x4* src = Wp + (static_cast<int64_t>(s) * Np + n0) * 6;
 #pragma unroll
     for (int j = 0; j < WU; ++j) {
       const int u = tid + T * j;
-      if (BNt * 6 % T == 0 || u < BNt * 6) wr[j] = src[u + u / 6];
+      if (BNt * 6 % T == 0 || u < BNt * 6) wr[j] = src[u];
     }
   };
   auto lstore = [&](int buf) {
@@ -246,24 +245,32 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
   }
 }
 
-// ---- the fast form: K % 16 == 0, X 16-byte aligned --------------------------------------------------------------------
-// 8 waves, a 256 x 256 tile (each wave 64 x 128: 8 accumulators, 48 matrix instructions per 16 k), one workgroup per CU,
-// two waves per SIMD.  Bytes that reach a CU per matrix instruction are what bounds a tile (L2 serves ~30 B/clk/CU with
-// every CU reading): 16 KB of X + 28 KB of W per 16 k and 384 instructions = 14 B/clk/CU (a 128 x 256 tile: 23).
+// ---- the pipelined form: K % 16 == 0, X 16-byte aligned ----------------------------------------------------------------
+// 8 waves, a 256 x 256 tile (each wave 64 x 128), one persistent workgroup per CU, two waves per SIMD.  Bytes that
+// reach a CU per matrix instruction are what bounds a tile (an XCD's L2 serves ~30 B/clk/CU with every CU reading):
+// 16 KB of X + 24 KB of W per 16 k = 13 B/clk/CU (a 128 x 256 tile: 21).
 //   W : LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no register in between) TWO stages ahead into a
-//       ring of three stage images -- the split weights are stored as the LDS image;
-//   X : one register set per thread (8 floats = 16 k of half a... of one row): split and written into the NEXT stage's
-//       image (ring of two) while the matrix instructions of this stage run, then re-issued at once for the stage after.
+//       ring of three stage images -- the split weights are stored as the LDS image (24 pieces per stage, 3 per wave);
+//   X : one register set per thread (8 floats = half of one row's 16 k): split and written into the NEXT stage's image
+//       (ring of two) while the matrix instructions of this stage run, then re-issued at once for the stage after.
 // One raw s_barrier per stage; the waits are counted by hand (the DMA is not in the compiler's bookkeeping): before the
 // barrier of stage s everything but this wave's loads for stage s + 2 has landed.
-#ifndef L3_KO_MFMA
-#define L3_KO_MFMA 0
-#endif
-constexpr int kFastM = 256, kFastN = 256, kFastNB = 4, kFastT = 512;
-constexpr int kFastWStage = kFastN * kL3Row * 2;  // bytes of a W stage image (28 672 = 28 DMA pieces of 1 KiB)
-constexpr int kFastXStage = kFastM * kL3Row * 2;
-constexpr int kFastLds = 3 * kFastWStage + 2 * kFastXStage;  // 143 360 B
-constexpr int kFastPieces = kFastWStage / 1024;
+//
+// The matrix instruction is v_mfma_f32_16x16x32_bf16 with TWO planes side by side in its 32 k: for 16 k of the operands
+//   [x_h | x_l] . [w_l | w_h] = x_h w_l + x_l w_h      [x_h | x_m] . [w_m | w_h] = x_h w_m + x_m w_h
+//   [x_h | x_m] . [w_h | w_m] = x_h w_h + x_m w_m
+// -- the same six products in three instructions of the 16 x 16 shape.  With every CU multiplying random operands the
+// chip's clock gives way (power), and it gives way less for this shape: 2.1 PFLOP/s against 1.8 for 32x32x16 in a bare
+// register loop (tools/mfma_power.cpp; both 2.46 on zeros).  Lane l of a fragment holds row l & 15, k half (l >> 4) & 1
+// of plane-of-the-pair l >> 5: one ds_read_b128 at row * 96 + plane * 32 + half * 16 -- 96-byte rows (no padding) are
+// conflict-free for the lane groups of that read.  The product is taken transposed (W rows as the A operand), so a
+// lane ends with four CONSECUTIVE output columns of one row: 16-byte stores.
+constexpr int kFastM = 256, kFastN = 256, kFastT = 512;
+constexpr int kFastRow = 48;                      // bf16 elements per LDS / image row: 3 planes x 16 k
+constexpr int kFastWStage = kFastN * kFastRow * 2;  // bytes of a W stage image (24 576 = 24 DMA pieces of 1 KiB)
+constexpr int kFastXStage = kFastM * kFastRow * 2;
+constexpr int kFastLds = 3 * kFastWStage + 2 * kFastXStage;  // 122 880 B
+typedef float l3_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
@@ -273,12 +280,11 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
                : "memory");
 }
 
-template <int ACT>
+template <int ACT, bool VEC4>
 __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __restrict__ X, int64_t B, int64_t K,
                                                                const l3_u32x4* __restrict__ Wp, int64_t N,
                                                                const float* __restrict__ bias, float* __restrict__ Y,
                                                                int n_nblk, int n_mblk) {
-  constexpr int NB = kFastNB;
   extern __shared__ __attribute__((aligned(16))) unsigned short l3_lds[];  // [3][W stage][2][X stage]
   const int64_t Np = l3_np(N);
   const int nst = static_cast<int>(K / 16);  // >= 2 (host)
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
 
   const int tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 1, wn = wv & 1;
-  const int i32 = lane & 31, hh = lane >> 5;
+  const int r16 = lane & 15, kh = (lane >> 4) & 1, ps = lane >> 5, q4 = lane >> 4;
   const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) unsigned short*)l3_lds));
 
   // Tiles: id = slot * 8 + xcd; the n-blocks of one m-block are consecutive slots of ONE XCD (consecutive workgroup
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
   // stream of stages -- the loads of the next tile's first two stages are issued during the last two of this one, the
   // accumulators are stored in between, nothing restarts.
   struct Tile { int64_t b0, n0; const float* xsrc; const char* wsrc; };
-  const int64_t wstep = Np * (kL3Row * 2);
+  const int64_t wstep = Np * (kFastRow * 2);
   auto valid = [&](int id) { return id < total && ((id >> 3) / n_nblk) * 8 + (id & 7) < n_mblk; };
   auto next_valid = [&](int id) { while (id < total && !valid(id)) id += step; return id; };
   auto decode = [&](int id) {
@@ -305,7 +311,7 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
     t.n0 = static_cast<int64_t>(slot % n_nblk) * kFastN;
     const int64_t xrow = (t.b0 + (tid >> 1) < B) ? t.b0 + (tid >> 1) : B - 1;  // rows beyond B: the last row again (never stored)
     t.xsrc = X + xrow * K + (tid & 1) * 8;
-    t.wsrc = reinterpret_cast<const char*>(Wp) + t.n0 * (kL3Row * 2) + wv * 1024 + lane * 16;
+    t.wsrc = reinterpret_cast<const char*>(Wp) + t.n0 * (kFastRow * 2) + wv * 1024 + lane * 16;
     return t;
   };
   int id = next_valid(blockIdx.x);
@@ -314,13 +320,15 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
   int nid = next_valid(id + step);
   Tile nxt = decode(nid < total ? nid : id);
 
-  unsigned short* xdst = l3_lds + 3 * (kFastWStage / 2) + (tid >> 1) * kL3Row + (tid & 1) * 8;
+  unsigned short* xdst = l3_lds + 3 * (kFastWStage / 2) + (tid >> 1) * kFastRow + (tid & 1) * 8;
   auto dma_w = [&](const Tile& t, int s, int g) {  // stage s of tile t = stage g of the stream: W ring slot g % 3
     const uint32_t dst = lds_base + static_cast<uint32_t>(g % 3) * kFastWStage + wv * 1024;
     const char* src = t.wsrc + static_cast<int64_t>(s) * wstep;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (j < 3 || wv < kFastPieces - 24) glds16(src + j * 8192, dst + j * 8192);
+    for (int j = 0; j < 3; ++j) glds16(src + j * 8192, dst + j * 8192);  // pieces wv, wv + 8, wv + 16 of the image's 24
+  };
+  auto dma_w_piece = [&](const Tile& t, int s, int g, int j) {
+    glds16(t.wsrc + static_cast<int64_t>(s) * wstep + j * 8192, lds_base + static_cast<uint32_t>(g % 3) * kFastWStage + wv * 1024 + j * 8192);
   };
   float4 xa, xb;
   auto load_x = [&](const Tile& t, int s) {
@@ -336,8 +344,9 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
     *reinterpret_cast<l3_u32x4*>(d + 16) = m;
     *reinterpret_cast<l3_u32x4*>(d + 32) = l;
   };
-  auto frag = [&](const unsigned short* base, int row, int plane) {
-    return __builtin_bit_cast(l3_bf16x8, *reinterpret_cast<const l3_u32x4*>(base + row * kL3Row + plane * 16 + hh * 8));
+  // fragment of 16 rows x [plane p0 | plane p1]: lane (r16, kh, ps) reads 8 k of plane (ps ? p1 : p0)
+  auto frag = [&](const unsigned short* base, int row0, int p0, int p1) {
+    return __builtin_bit_cast(l3_bf16x8, *reinterpret_cast<const l3_u32x4*>(base + (row0 + r16) * kFastRow + (ps ? p1 : p0) * 16 + kh * 8));
   };
 
   int g = 0;  // stage of the stream
@@ -351,83 +360,103 @@ __global__ __launch_bounds__(kFastT) void linear_x3_fast_kernel(const float* __r
 
   while (true) {
     const bool has_next = nid < total;
-    l3_f32x16 acc[2][NB];
+    l3_f32x4 acc[8][4];  // [n-block of 16 columns][m-block of 16 rows]
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int n = 0; n < 8; ++n)
 #pragma unroll
-      for (int n = 0; n < NB; ++n)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+      for (int m = 0; m < 4; ++m) acc[n][m] = l3_f32x4{0.f, 0.f, 0.f, 0.f};
 
     for (int s = 0; s < nst; ++s, ++g) {
       // stage g + 2 of the stream: stage s + 2 of this tile, or stage s + 2 - nst of the next one
       const bool wrap2 = s + 2 >= nst, more2 = !wrap2 || has_next;
       const bool wrap1 = s + 1 >= nst, more1 = !wrap1 || has_next;
-#ifndef L3_KO_DMA
-      if (more2) dma_w(wrap2 ? nxt : cur, wrap2 ? s + 2 - nst : s + 2, g + 2);
-#endif
+      const Tile& t2 = wrap2 ? nxt : cur;
+      const int s2 = wrap2 ? s + 2 - nst : s + 2;
       const unsigned short* sW = l3_lds + (g % 3) * (kFastWStage / 2);
       const unsigned short* sX = l3_lds + 3 * (kFastWStage / 2) + (g & 1) * (kFastXStage / 2);
-      l3_bf16x8 a[2][3], b[2][3];
+      l3_bf16x8 xhm[4], xhl[4], w[2][3];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int m = 0; m < 4; ++m) {
+        xhm[m] = frag(sX, wm * 64 + m * 16, 0, 1);
+        xhl[m] = frag(sX, wm * 64 + m * 16, 0, 2);
+      }
+      auto read_w = [&](int n, l3_bf16x8 (&d)[3]) {
+        d[0] = frag(sW, wn * 128 + n * 16, 2, 0);  // [w_l | w_h]
+        d[1] = frag(sW, wn * 128 + n * 16, 1, 0);  // [w_m | w_h]
+        d[2] = frag(sW, wn * 128 + n * 16, 0, 1);  // [w_h | w_m]
+      };
+      read_w(0, w[0]);
+      l3_u32x4 ch, cm, cl;  // the split of stage g + 1's X, made two pairs at a time between the matrix instructions
+      const float cx[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
-        for (int p = 0; p < 3; ++p) a[m][p] = frag(sX, wm * 64 + m * 32 + i32, p);
+      for (int n = 0; n < 8; ++n) {
+        // The stage's one barrier sits behind n-block 4, not at its end: by then the next stage's X image is written and
+        // this wave's W pieces for it (issued behind the barrier of the stage before) have landed, so the barrier
+        // publishes stage g + 1 -- and the last matrix instruction of a stage runs straight into the next stage's
+        // fragment reads, the two waves of a SIMD free to drift apart there.  Behind it: the DMA of W two stages ahead
+        // (its ring slot was last read in stage g - 1, which every wave has left once it is past this barrier).
+        // sched_barrier(0) pins the pieces between the n-blocks: left to itself the compiler makes one block of the
+        // ~60 vector instructions of the split, during which neither wave of the SIMD issues a matrix instruction.
+        __builtin_amdgcn_sched_barrier(0);
+        if (n + 1 < 8) read_w(n + 1, w[(n + 1) & 1]);
+        if (more1 && (n == 1 || n == 2)) {
 #pragma unroll
-      for (int p = 0; p < 3; ++p) b[0][p] = frag(sW, wn * 128 + i32, p);
-#pragma unroll
-      for (int n = 0; n < NB; ++n) {
-        if (n + 1 < NB) {
-#pragma unroll
-          for (int p = 0; p < 3; ++p) b[(n + 1) & 1][p] = frag(sW, wn * 128 + (n + 1) * 32 + i32, p);
+          for (int i = (n - 1) * 2; i < (n - 1) * 2 + 2; ++i) {
+            uint32_t a, b, c;
+            split3_pair(cx[2 * i], cx[2 * i + 1], a, b, c);
+            ch[i] = a, cm[i] = b, cl[i] = c;
+          }
         }
-#ifndef L3_KO_X
-        if (n == 1 && more1) {  // the registers hold stage g + 1: split it into the other X image, re-issue for stage g + 2
-#ifndef L3_KO_CVT
-          store_x(g + 1);
-#endif
-          if (more2) load_x(wrap2 ? nxt : cur, wrap2 ? s + 2 - nst : s + 2);
+        if (more1 && n == 3) {
+          unsigned short* d = xdst + ((g + 1) & 1) * (kFastXStage / 2);
+          *reinterpret_cast<l3_u32x4*>(d) = ch;
+          *reinterpret_cast<l3_u32x4*>(d + 16) = cm;
+          *reinterpret_cast<l3_u32x4*>(d + 32) = cl;
+          if (more2) load_x(t2, s2);
         }
-#endif
+        if (n == 5) {
+          if (more2) asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");  // (younger: the two X loads just issued)
+          else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+        }
+        if (more2 && n >= 5) dma_w_piece(t2, s2, g + 2, n - 5);
+        __builtin_amdgcn_sched_barrier(0);
+        const l3_bf16x8* ww = w[n & 1];
 #pragma unroll
-        for (int m = 0; m < (L3_KO_MFMA ? 0 : 2); ++m) {
-          const l3_bf16x8* bb = b[n & 1];
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], bb[0], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[2], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bb[1], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], bb[0], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[1], acc[m][n], 0, 0, 0);
-          acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], bb[0], acc[m][n], 0, 0, 0);
+        for (int m = 0; m < 4; ++m) {  // small terms first
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ww[0], xhl[m], acc[n][m], 0, 0, 0);
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ww[1], xhm[m], acc[n][m], 0, 0, 0);
+          acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ww[2], xhm[m], acc[n][m], 0, 0, 0);
         }
       }
-      // Everything older than this stage's own loads (W of stage g + 2: 3 or 4 pieces, X of stage g + 2: 2 loads) has
-      // landed: W of stage g + 1 among it (and, after a tile's end, the stores of its accumulators: the vector memory
-      // counter retires in order).  Nothing younger was issued in the stream's last two stages: drain.
-      if (more2) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
     }
 
-    // C/D map of the 32x32 shapes: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // C/D map of the 16x16 shapes, product taken transposed: lane (r16, q4) holds X row r16 of its m-block and the
+    // four output columns 4 q4 .. 4 q4 + 3 of its n-block
 #pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      const int64_t col = cur.n0 + wn * 128 + n * 32 + i32;
-      const float bcol = col < N ? bias[col] : 0.f;
+    for (int n = 0; n < 8; ++n) {
+      const int64_t col = cur.n0 + wn * 128 + n * 16 + q4 * 4;
+      float bc[4];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+      for (int r = 0; r < 4; ++r) bc[r] = (col + r < N) ? bias[col + r] : 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          l3_f2 y = l3_f2{acc[m][n][r] + bcol, acc[m][n][r + 1] + bcol};
-          if (ACT == MI_OOV_ACT_GELU) y = l3_gelu2(y);
-          if (ACT == MI_OOV_ACT_SIGMOID) y = l3_f2{l3_act<ACT>(y.x), l3_act<ACT>(y.y)};
-          const int64_t row = cur.b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;  // and row + 1
-#if defined(L3_KO_STORE)
-          if (row < B && col < N && y.x == 12345.678f) Y[row * N + col] = y.x;
-#else
-          if (row < B && col < N) Y[row * N + col] = y.x;
-          if (row + 1 < B && col < N) Y[(row + 1) * N + col] = y.y;
-#endif
+      for (int m = 0; m < 4; ++m) {
+        const int64_t row = cur.b0 + wm * 64 + m * 16 + r16;
+        l3_f2 y0 = l3_f2{acc[n][m][0] + bc[0], acc[n][m][1] + bc[1]}, y1 = l3_f2{acc[n][m][2] + bc[2], acc[n][m][3] + bc[3]};
+        if (ACT == MI_OOV_ACT_GELU) y0 = l3_gelu2(y0), y1 = l3_gelu2(y1);
+        if (ACT == MI_OOV_ACT_SIGMOID) y0 = l3_f2{l3_act<ACT>(y0.x), l3_act<ACT>(y0.y)}, y1 = l3_f2{l3_act<ACT>(y1.x), l3_act<ACT>(y1.y)};
+        if (row < B) {
+          float* dst = Y + row * N + col;
+          if (VEC4 && col + 3 < N) {
+            *reinterpret_cast<l3_f32x4*>(dst) = l3_f32x4{y0.x, y0.y, y1.x, y1.y};
+          } else {
+            if (col + 0 < N) dst[0] = y0.x;
+            if (col + 1 < N) dst[1] = y0.y;
+            if (col + 2 < N) dst[2] = y1.x;
+            if (col + 3 < N) dst[3] = y1.y;
+          }
         }
+      }
     }
     if (!has_next) break;
     id = nid;
@@ -453,7 +482,8 @@ static int launch_x3_fast(const float* X, int64_t B, int64_t K, const void* wspl
   if (total > 0x7FFFFFFF) return MI_OOV_ERR_SHAPE;
   const int cus = l3_cus();
   const int64_t grid = total < cus ? total : cus;  // one workgroup per CU (143 KB of LDS each); total % 8 == 0
-  auto k = linear_x3_fast_kernel<ACT>;
+  const bool vec4 = (N % 4 == 0) && aligned16(Y);  // rows of Y 16-byte aligned: one store per four columns
+  auto k = vec4 ? linear_x3_fast_kernel<ACT, true> : linear_x3_fast_kernel<ACT, false>;
   if (int rc = set_lds(k, kFastLds)) return rc;
   hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(kFastT), kFastLds, st, X, B, K, static_cast<const l3_u32x4*>(wsplit), N, bias, Y,
                      static_cast<int>(n_nblk), static_cast<int>(n_mblk));
@@ -494,7 +524,7 @@ using namespace mi_oov;
 
 extern "C" int64_t mi_oov_linear_x3_weights_bytes(int64_t N_out, int64_t K) {
   if (N_out <= 0 || K <= 0) return MI_OOV_ERR_SHAPE;
-  return l3_chunks(K) * l3_np(N_out) * 112;
+  return l3_chunks(K) * l3_np(N_out) * 96;
 }
 
 extern "C" int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream) {
@@ -518,7 +548,8 @@ extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void
   hipStream_t st = static_cast<hipStream_t>(stream);
   // developer knob, read per call (the tests force the pipelined kernel onto small shapes with it): 0 = by shape,
   // 1 / 2 / 3 = the generic kernel with 128 x 128 / 256 x 256 / 128 x 64 tiles, 4 = the pipelined kernel where it applies.
-  // Every form does the same arithmetic in the same order: results do not depend on it.
+  // The generic forms agree bit for bit; the pipelined kernel pairs the six products differently inside a 16-k step
+  // (two planes per matrix instruction), so it agrees with them within the accumulator's roundings only.
   const int shape = static_cast<int>(env_knob("MI_OOV_X3_SHAPE", 0, 0, 4));
   // the pipelined 256 x 256 form: K a multiple of 16 (no tail chunk), rows of X 16-byte aligned, outputs wider than 128
   // ... when its 256 x 256 tiles fill more than half of the CUs: a tile is 122 us of one CU at K = 1024 however few

@@ -311,22 +311,25 @@ def test_linear_x3_vs_oracle(B, K, N_out, form, oracle, ops, dev, monkeypatch):
 
 
 def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev, monkeypatch):
-    """(a) An input padded to a multiple of 16 columns (what hash_net_forward hands over for fdhe's K + F columns) gives the
-    pipelined kernel the same arithmetic: bit-identical to the generic kernel on the unpadded rows.  (b) BASELINE's dhe
-    shape, 65536 x 1024 -> 512: every row block agrees with the f32 kernel within the bound of test_linear_x3_vs_oracle,
-    and the result does not depend on how the batch is cut (rows of a 65536-row call == the same rows in a 4096-row call)."""
+    """(a) An input padded to a multiple of 16 columns (what hash_net_forward hands over for fdhe's K + F columns) goes
+    through the pipelined kernel: within the bound of test_linear_x3_vs_oracle of the generic kernel on the unpadded rows
+    (the two pair the six products differently inside a 16-k step), and whatever finite values the padding columns hold
+    -- they meet zero weights -- the result is the same bit for bit.  (b) BASELINE's dhe shape, 65536 x 1024 -> 512: every
+    row agrees with the f32 kernel within that bound, and the result does not depend on where a row sits in the batch
+    (rows of a 65536-row call == the same rows as a 32768-row call: the persistent workgroups walk other tiles)."""
     rng = np.random.default_rng(77)
     B, K, N_out = 700, 1046, 300
     X = (rng.random((B, K)) * 2 - 1).astype(np.float32)
     W = (rng.standard_normal((N_out, K)) / np.sqrt(K)).astype(np.float32)
     b = rng.standard_normal(N_out).astype(np.float32)
     Xt, Wt, bt = T(X, dev), T(W, dev), T(b, dev)
-    Xpad = torch.nn.functional.pad(Xt, (0, -K % 16))
-    plain = ops.linear_act_x3(Xt, Wt, bt, "gelu")
+    den = Xt.abs() @ Wt.abs().T + bt.abs()
+    plain = ops.linear_act_x3(Xt, Wt, bt, None)  # K % 4 != 0: the generic kernel
     monkeypatch.setenv("MI_OOV_X3_SHAPE", "4")  # (by shape a batch this small takes 128 x 128 tiles)
-    padded = ops.linear_act_x3(Xpad, Wt, bt, "gelu")
+    padded = ops.linear_act_x3(torch.nn.functional.pad(Xt, (0, -K % 16)), Wt, bt, None)
+    sevens = ops.linear_act_x3(torch.nn.functional.pad(Xt, (0, -K % 16), value=7.0), Wt, bt, None)
     monkeypatch.delenv("MI_OOV_X3_SHAPE")
-    assert torch.equal(plain, padded)
+    assert bool(((plain - padded).abs() <= 8 * 2.0 ** -24 * den).all()) and torch.equal(padded, sevens)
     with pytest.raises(ValueError):
         ops.linear_act_x3(torch.nn.functional.pad(Xt, (0, 1)), Wt, bt, None)
     g = torch.Generator(device=dev).manual_seed(5)
@@ -338,8 +341,8 @@ def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev, monkeypatch):
     ref = ops.linear_act(Xb, Wb, bb, None)  # the bit-exact kernel (pinned on the oracle at small sizes)
     den = Xb.abs() @ Wb.abs().T + bb.abs()
     assert bool(((y - ref).abs() <= 8 * 2.0 ** -24 * den).all())
-    part = ops.linear_act_x3(Xb[61440:], Wb, bb, None)
-    assert torch.equal(part, y[61440:])
+    part = ops.linear_act_x3(Xb[32768:], Wb, bb, None)
+    assert torch.equal(part, y[32768:])
 
 
 def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
