@@ -13,9 +13,18 @@ struct u64p {
   uint32_t lo, hi;
 };
 __device__ __forceinline__ u64p mk(uint64_t v) { return {static_cast<uint32_t>(v), static_cast<uint32_t>(v >> 32)}; }
+// The carry pair is written out: as a uint64_t sum the compiler picks v_lshl_add_u64, whose operands must sit in aligned
+// register pairs -- after every rotate by 32 (the rename) it then MOVES both halves back into place: 48 v_mov and 15
+// v_perm of the 252 vector instructions a hash took.  Round 3: ~205 per hash, 360 -> 350 us per 65536 x 1024 hashes --
+// the moves were cheap; what is left is 62 carry adds + 61 v_alignbit + 72 v_xor per hash at the vector issue rate
+// (67 M hashes x 205 / 64 lanes / 1024 SIMDs x 4 cycles = 341 us at 2.4 GHz).
 __device__ __forceinline__ u64p add64(u64p a, u64p b) {
-  const uint64_t r = ((static_cast<uint64_t>(a.hi) << 32) | a.lo) + ((static_cast<uint64_t>(b.hi) << 32) | b.lo);
-  return mk(r);
+  u64p r;
+  asm("v_add_co_u32 %0, vcc, %2, %4\n\tv_addc_co_u32 %1, vcc, %3, %5, vcc"
+      : "=&v"(r.lo), "=v"(r.hi)
+      : "v"(a.lo), "v"(a.hi), "v"(b.lo), "v"(b.hi)
+      : "vcc");
+  return r;
 }
 __device__ __forceinline__ u64p xor64(u64p a, u64p b) { return {a.lo ^ b.lo, a.hi ^ b.hi}; }
 template <int R>  // 0 < R < 32
@@ -25,12 +34,16 @@ __device__ __forceinline__ u64p rotl(u64p x) {
 }
 __device__ __forceinline__ u64p rotl32(u64p x) { return {x.hi, x.lo}; }
 
-#define MI_SIPROUND                \
+// one SipRound = the key-only quarter (v0 += v1; v1 <<<= 13; v1 ^= v0; v0 <<<= 32) + the rest
+#define MI_SIPROUND_HEAD           \
   do {                             \
     v0 = add64(v0, v1);            \
     v1 = rotl<13>(v1);             \
     v1 = xor64(v1, v0);            \
     v0 = rotl32(v0);               \
+  } while (0)
+#define MI_SIPROUND_REST           \
+  do {                             \
     v2 = add64(v2, v3);            \
     v3 = rotl<16>(v3);             \
     v3 = xor64(v3, v2);            \
@@ -42,16 +55,32 @@ __device__ __forceinline__ u64p rotl32(u64p x) { return {x.hi, x.lo}; }
     v1 = xor64(v1, v2);            \
     v2 = rotl32(v2);               \
   } while (0)
+#define MI_SIPROUND                \
+  do {                             \
+    MI_SIPROUND_HEAD;              \
+    MI_SIPROUND_REST;              \
+  } while (0)
 
-// SipHash-2-4 of the 8-byte little-endian encoding of m under key (k0,k1); returns the low dword
-// of the 64-bit hash (all the path needs: `% 16777216`).
-__device__ __forceinline__ uint32_t siphash24_lo(u64p k0, u64p k1, u64p m) {
+// What of a hash depends on the key alone: the four initial lanes k ^ "somepseudorandomlygeneratedbytes" and the first
+// quarter of round 1 (the message enters through v3 only, and v3 is not touched before the second quarter).  Made once
+// per key and workgroup (8 dwords per key in LDS), it takes 14 of the ~210 vector instructions off every hash.
+struct SipKey {
+  u64p v0, v1, v2, v3;
+};
+__device__ __forceinline__ SipKey sip_key_state(u64p k0, u64p k1) {
   u64p v0 = xor64(k0, mk(0x736f6d6570736575ULL));
   u64p v1 = xor64(k1, mk(0x646f72616e646f6dULL));
-  u64p v2 = xor64(k0, mk(0x6c7967656e657261ULL));
-  u64p v3 = xor64(k1, mk(0x7465646279746573ULL));
-  v3 = xor64(v3, m);
-  MI_SIPROUND;
+  const u64p v2 = xor64(k0, mk(0x6c7967656e657261ULL));
+  const u64p v3 = xor64(k1, mk(0x7465646279746573ULL));
+  MI_SIPROUND_HEAD;
+  return {v0, v1, v2, v3};
+}
+
+// SipHash-2-4 of the 8-byte little-endian encoding of m under the key whose state is ks; returns the low dword
+// of the 64-bit hash (all the path needs: `% 16777216`).
+__device__ __forceinline__ uint32_t siphash24_lo(const SipKey& ks, u64p m) {
+  u64p v0 = ks.v0, v1 = ks.v1, v2 = ks.v2, v3 = xor64(ks.v3, m);
+  MI_SIPROUND_REST;
   MI_SIPROUND;
   v0 = xor64(v0, m);
   const u64p last = mk(8ULL << 56);  // message length 8, no tail bytes
@@ -74,10 +103,14 @@ template <bool KEYS_IN_LDS>
 __global__ __launch_bounds__(kBlock) void siphash_kernel(const int64_t* __restrict__ ids, int64_t B,
                                                          const uint8_t* __restrict__ keys, int K, int log2kp,
                                                          uint32_t mask, float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t skeys[];
-  const uint32_t* kp = reinterpret_cast<const uint32_t*>(keys);  // little-endian host & device
+  extern __shared__ __attribute__((aligned(16))) uint32_t skeys[];  // [K][8]: the key states (sip_key_state)
+  const uint32_t* kp = reinterpret_cast<const uint32_t*>(keys);    // little-endian host & device
   if (KEYS_IN_LDS) {
-    for (int i = threadIdx.x; i < 4 * K; i += kBlock) skeys[i] = kp[i];
+    for (int j = threadIdx.x; j < K; j += kBlock) {
+      const SipKey ks = sip_key_state({kp[4 * j], kp[4 * j + 1]}, {kp[4 * j + 2], kp[4 * j + 3]});
+      *reinterpret_cast<uint4*>(skeys + 8 * j) = make_uint4(ks.v0.lo, ks.v0.hi, ks.v1.lo, ks.v1.hi);
+      *reinterpret_cast<uint4*>(skeys + 8 * j + 4) = make_uint4(ks.v2.lo, ks.v2.hi, ks.v3.lo, ks.v3.hi);
+    }
     __syncthreads();
   }
   const int KP = 1 << log2kp;
@@ -88,9 +121,14 @@ __global__ __launch_bounds__(kBlock) void siphash_kernel(const int64_t* __restri
        b += static_cast<int64_t>(gridDim.x) * slots) {
     const u64p m = mk(static_cast<uint64_t>(ids[b]));
     for (int j = jl; j < K; j += KP) {
-      const uint32_t* kj = KEYS_IN_LDS ? skeys + 4 * j : kp + 4 * j;
-      const u64p k0 = {kj[0], kj[1]}, k1 = {kj[2], kj[3]};
-      const uint32_t h = siphash24_lo(k0, k1, m);
+      SipKey ks;
+      if (KEYS_IN_LDS) {
+        const uint4 a = *reinterpret_cast<const uint4*>(skeys + 8 * j), c = *reinterpret_cast<const uint4*>(skeys + 8 * j + 4);
+        ks = {{a.x, a.y}, {a.z, a.w}, {c.x, c.y}, {c.z, c.w}};
+      } else {
+        ks = sip_key_state({kp[4 * j], kp[4 * j + 1]}, {kp[4 * j + 2], kp[4 * j + 3]});
+      }
+      const uint32_t h = siphash24_lo(ks, m);
       out[b * K + j] = static_cast<float>(h & mask);  // < 2^24: exact in f32
     }
   }
@@ -185,8 +223,8 @@ extern "C" int mi_oov_siphash24_mod(const int64_t* ids, int64_t B, const uint8_t
   const int slots = kBlock >> log2kp;
   const int64_t per_block = static_cast<int64_t>(slots) * (K > 256 ? 1 : 4);
   const int grid = grid_for(B, per_block);
-  const size_t lds = static_cast<size_t>(K) * 16;
-  if (lds <= 48 * 1024) {
+  const size_t lds = static_cast<size_t>(K) * 32;
+  if (lds <= 64 * 1024) {
     hipLaunchKernelGGL(siphash_kernel<true>, dim3(grid), dim3(kBlock), lds, st, ids, B, keys, static_cast<int>(K),
                        log2kp, mod - 1, out);
   } else {
