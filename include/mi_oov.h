@@ -391,7 +391,9 @@ int mi_oov_score_topk(const float* U, int64_t B, const float* E, int64_t N, int6
  * torch.topk; here segment s (one user of the batch) owns candidates [seg_ptr[s], seg_ptr[s+1]) given as
  * (scores[i], cols[i]) and the dense matrix never exists.  Best k (<= 256) candidates with col_lo <= column <
  * col_hi, larger score first, NaN highest, ties -> earlier candidate; (-inf, -1) where fewer than k qualify.
- *   scores f32[M], cols i64[M], seg_ptr i64[S+1] -> vals f32[S,k], idx i64[S,k] (item columns).              */
+ *   scores f32[M], cols i64[M], seg_ptr i64[S+1] -> vals f32[S,k], idx i64[S,k] (item columns).
+ * Columns are item ids (>= 0).  With the whole range (col_lo <= 0 and col_hi >= 2^62) only the winners' columns
+ * are read: 4 instead of 12 bytes per candidate.                                                                 */
 int mi_oov_segment_topk(const float* scores, const int64_t* cols, const int64_t* seg_ptr, int64_t S, int64_t k,
                         int64_t col_lo, int64_t col_hi, float* vals, int64_t* idx, void* stream);
 

@@ -124,7 +124,8 @@ def main():
         "lsh_embed_backward H=8 (bucket-table grad)": (lambda i: ops.lsh_embed_backward(bits8, users[i % 8]), B, H + 4 * D, 0),
         "slsh_embed_backward nb=9": (lambda i: ops.slsh_embed_backward(idx9[i % 8], users[i % 8], 9), B, 8 + 4 * D, 0),
         "scatter_add_rows into 10M x 64 (gather backward)": (lambda i: ops.scatter_add_rows(ids[i], users[i % 8], N, out=gtab), B, 8 + 12 * D, 0),
-        "segment_topk 4096 users x 1506 candidates k=20": (lambda i: ops.segment_topk(seg_scores, seg_cols, seg_ptr, 20), seg_scores.numel(), 12, 0),
+        "segment_topk 4096 users x 1506 candidates k=20": (lambda i: ops.segment_topk(seg_scores, seg_cols, seg_ptr, 20), seg_scores.numel(), 4, 0),
+        "segment_topk 4096 users x 1506 candidates k=20, columns [1, 5M) only": (lambda i: ops.segment_topk(seg_scores, seg_cols, seg_ptr, 20, 1, N // 2), seg_scores.numel(), 12, 0),
     }
     # round 2: the persistent launch and the two ends of the sharded exchange (1 M lookups = 16 batches per call)
     BIG = 16 * B
