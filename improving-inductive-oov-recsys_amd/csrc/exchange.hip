@@ -190,6 +190,19 @@ __global__ __launch_bounds__(256) void bucket_by_owner_kernel(const int64_t* __r
   }
 }
 
+// Unused entries of a segment are -1 (the owner's kernel answers them with a 0xFF code without touching its table).
+// Written AFTER the bucketing, and only where nothing was placed -- positions counts[w] .. cap of segment w (grid.y = w):
+// with ids spread evenly and cap = 1.25 x the expected share that is a fifth of the buffer, and no byte of it is written
+// twice.  (Round 2 cleared the whole buffer first: hipMemsetAsync's fill kernel, 5.4 us for the 10.5 MB of a 20-batch
+// exchange, one more launch in a chain whose gaps -- 77 of 266 us on one GPU -- are host launch latency.)
+__global__ __launch_bounds__(256) void fill_segment_tails_kernel(int64_t* __restrict__ send, const int32_t* __restrict__ counts,
+                                                                int64_t cap) {
+  const int w = blockIdx.y;  // segment
+  const int64_t from = counts[w];
+  int64_t* seg = send + static_cast<int64_t>(w) * cap;
+  for (int64_t p = from + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; p < cap; p += static_cast<int64_t>(gridDim.x) * 256) seg[p] = -1;
+}
+
 // Requester side: codes u8[M,H] as they came back, slot i32[B] -> emb f32[B,D] and / or score f32[B].
 // A 16-lane row owns a lookup; lane l holds 4-float chunks l, l+16, ... of the output row (the canonical order of
 // DESIGN.md section 4): acc = fmaf(bit_h, W[h][d], acc) for h = 0..H-1 from +0, one IEEE division by the exact count,
@@ -281,13 +294,17 @@ extern "C" int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_r
   if (world * cap > (int64_t(1) << 31) - 1) return MI_OOV_ERR_SHAPE;  // slots are int32
   if (!send || !counts) return MI_OOV_ERR_NULL;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // unused entries of a segment are -1: the owner's kernel answers them with a 0xFF code without touching its table
-  if (hipMemsetAsync(send, 0xFF, static_cast<size_t>(world * cap) * sizeof(int64_t), st) != hipSuccess ||
-      hipMemsetAsync(counts, 0, static_cast<size_t>(world) * sizeof(int32_t), st) != hipSuccess) {
+  if (hipMemsetAsync(counts, 0, static_cast<size_t>(world) * sizeof(int32_t), st) != hipSuccess) {
     g_last_hip_error = static_cast<int>(hipGetLastError());
     return MI_OOV_ERR_LAUNCH;
   }
-  if (B == 0) return MI_OOV_OK;
+  const int64_t fill_units = (cap + 255) / 256;  // (a segment's tail is walked by at most 2048 / world workgroups)
+  const int64_t fill_max = kMaxGrid / world > 0 ? kMaxGrid / world : 1;
+  const dim3 fill_grid(static_cast<unsigned>(fill_units < fill_max ? fill_units : fill_max), static_cast<unsigned>(world));
+  if (B == 0) {
+    hipLaunchKernelGGL(fill_segment_tails_kernel, fill_grid, dim3(256), 0, st, send, counts, cap);
+    return check_launch();
+  }
   if (!ids || !slot) return MI_OOV_ERR_NULL;
   // chunks of a multiple of 1024 lookups, at most ~512 workgroups: <= 512 reservations per owner counter (an
   // atomic on one address costs ~11 ns at the memory side whoever issues it)
@@ -300,6 +317,8 @@ extern "C" int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_r
   else
     hipLaunchKernelGGL(bucket_by_owner_kernel, dim3(grid), dim3(256), 2 * world * sizeof(int32_t), st, ids, B, n_rows,
                        rows_per_rank, static_cast<int>(world), cap, chunk, send, slot, counts, overflow);
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(fill_segment_tails_kernel, fill_grid, dim3(256), 0, st, send, counts, cap);
   return check_launch();
 }
 
