@@ -78,8 +78,8 @@ def test_argument_validation_of_the_widened_entry_points(lib):
     assert lib.mi_oov_score_topk_prepared(None, 4, None, 50_000, 64, 20, 0, None, None, None, None, None, None, None) == -1
     assert lib.mi_oov_score_topk_prepared(None, 4, None, 1000, 64, 20, 0, None, None, None, None, None, None, None) == -2
     assert lib.mi_oov_linear_act(None, 4, 16, None, None, 8, 7, None, None) in (-2, -3)       # unknown activation
-    assert lib.mi_oov_linear_x3_weights_bytes(512, 1024) == 64 * 512 * 112                    # [K/16][N -> 256s][3 x 32 B + 16]
-    assert lib.mi_oov_linear_x3_weights_bytes(33, 70) == 5 * 256 * 112 and lib.mi_oov_linear_x3_weights_bytes(0, 16) == -2
+    assert lib.mi_oov_linear_x3_weights_bytes(512, 1024) == 64 * 512 * 96                     # [K/16][N -> 256s][3 planes x 32 B]
+    assert lib.mi_oov_linear_x3_weights_bytes(33, 70) == 5 * 256 * 96 and lib.mi_oov_linear_x3_weights_bytes(0, 16) == -2
     assert lib.mi_oov_linear_x3_prepare(None, 512, 1024, None, None) == -1 and lib.mi_oov_linear_x3_prepare(None, 512, 0, None, None) == -2
     assert lib.mi_oov_linear_x3(None, 4, 16, None, None, 8, 7, None, None) == -3              # unknown activation
     assert lib.mi_oov_linear_x3(None, 4, 16, None, None, 8, 1, None, None) == -1 and lib.mi_oov_linear_x3(None, 0, 16, None, None, 8, 1, None, None) == 0
