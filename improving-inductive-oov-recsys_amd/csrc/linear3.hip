@@ -30,7 +30,6 @@ typedef float l3_f32x2 __attribute__((ext_vector_type(2)));
 typedef float l3_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int l3_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kL3Row = 56;    // bf16 elements per LDS row: 3 x 16 + 8 of padding (112 B)
 constexpr int kL3NPad = 256;  // rows of the split weights are padded to a multiple of this (any tile shape fits)
 
 __host__ __device__ constexpr int64_t l3_np(int64_t N) { return (N + kL3NPad - 1) / kL3NPad * kL3NPad; }
@@ -122,6 +121,14 @@ __device__ __forceinline__ l3_f2 l3_gelu2(l3_f2 v) {
   return l3_f2{v.x > 0.f ? pos.x : h.x, v.y > 0.f ? pos.y : h.y};
 }
 
+// The generic tile kernel: any K (zero-padded to 16), any alignment, (64 WM) x (32 NB WN) tiles, both operands staged
+// through registers into a double-buffered LDS stage (one barrier per stage).  The SAME arithmetic as the pipelined
+// kernel below, in the same order -- v_mfma_f32_16x16x32_bf16 with two planes side by side in its 32 k, three
+// instructions per 16 x 16 output block and 16 k, product taken transposed -- so the two agree bit for bit and a result
+// does not depend on which of them a call's shape selects.
+typedef float l3_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int kL3Row = 48;  // bf16 elements per LDS row: 3 planes x 16 k (96 B: conflict-free for the 16x16x32 fragment reads)
+
 template <int WM, int WN, int NB, int ACT, bool VEC>
 __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __restrict__ X, int64_t B, int64_t K,
                                                                  const l3_u32x4* __restrict__ Wp, int64_t N,
@@ -131,6 +138,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
   constexpr int XU = (BMt * 2 + T - 1) / T;  // 8-float units of X per thread and stage
   constexpr int WU = (BNt * 6 + T - 1) / T;  // 16-byte units of the split W per thread and stage
   constexpr int kStage = (BMt + BNt) * kL3Row;  // bf16 elements
+  constexpr int NQ = 2 * NB;                    // 16-column blocks of a wave
   extern __shared__ __attribute__((aligned(16))) unsigned short l3_lds[];
 
   // Workgroups that share rows of X (the n-blocks of one m-block) sit next to each other on ONE XCD (consecutive
@@ -144,15 +152,13 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WN, wn = wv % WN;
-  const int i32 = lane & 31, hh = lane >> 5;
+  const int r16 = lane & 15, kh = (lane >> 4) & 1, ps = lane >> 5, q4 = lane >> 4;
 
-  l3_f32x16 acc[2][NB];
+  l3_f32x4 acc[NQ][4];  // [16-column block][16-row block]
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int n = 0; n < NQ; ++n)
 #pragma unroll
-    for (int n = 0; n < NB; ++n)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+    for (int m = 0; m < 4; ++m) acc[n][m] = l3_f32x4{0.f, 0.f, 0.f, 0.f};
 
   float xr[XU][8];
   l3_u32x4 wr[WU];
@@ -187,11 +193,12 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
 #pragma unroll
     for (int j = 0; j < WU; ++j) {
       const int u = tid + T * j;
-      if (BNt * 6 % T == 0 || u < BNt * 6) *reinterpret_cast<l3_u32x4*>(sW + (u / 6) * kL3Row + (u % 6) * 8) = wr[j];
+      if (BNt * 6 % T == 0 || u < BNt * 6) *reinterpret_cast<l3_u32x4*>(sW + u * 8) = wr[j];  // (the image's rows are the LDS rows)
     }
   };
-  auto frag = [&](const unsigned short* base, int row, int plane) {
-    return __builtin_bit_cast(l3_bf16x8, *reinterpret_cast<const l3_u32x4*>(base + row * kL3Row + plane * 16 + hh * 8));
+  // fragment of 16 rows x [plane p0 | plane p1]: lane (r16, kh, ps) reads 8 k of plane (ps ? p1 : p0)
+  auto frag = [&](const unsigned short* base, int row0, int p0, int p1) {
+    return __builtin_bit_cast(l3_bf16x8, *reinterpret_cast<const l3_u32x4*>(base + (row0 + r16) * kL3Row + (ps ? p1 : p0) * 16 + kh * 8));
   };
 
   gload(0);
@@ -201,47 +208,55 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
     if (s + 1 < nst) gload(s + 1);
     const unsigned short* sX = l3_lds + (s & 1) * kStage;
     const unsigned short* sW = sX + BMt * kL3Row;
-    l3_bf16x8 a[2][3];
+    l3_bf16x8 xhm[4], xhl[4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < 4; ++m) {
+      xhm[m] = frag(sX, wm * 64 + m * 16, 0, 1);
+      xhl[m] = frag(sX, wm * 64 + m * 16, 0, 2);
+    }
 #pragma unroll
-      for (int p = 0; p < 3; ++p) a[m][p] = frag(sX, wm * 64 + m * 32 + i32, p);
+    for (int n = 0; n < NQ; ++n) {
+      const l3_bf16x8 wlh = frag(sW, wn * 32 * NB + n * 16, 2, 0);  // [w_l | w_h]
+      const l3_bf16x8 wmh = frag(sW, wn * 32 * NB + n * 16, 1, 0);  // [w_m | w_h]
+      const l3_bf16x8 whm = frag(sW, wn * 32 * NB + n * 16, 0, 1);  // [w_h | w_m]
 #pragma unroll
-    for (int n = 0; n < NB; ++n) {
-      l3_bf16x8 b[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) b[p] = frag(sW, wn * 32 * NB + n * 32 + i32, p);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        // small terms first
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][2], b[0], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[2], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[1], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][1], b[0], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[1], acc[m][n], 0, 0, 0);
-        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[m][0], b[0], acc[m][n], 0, 0, 0);
+      for (int m = 0; m < 4; ++m) {  // small terms first
+        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlh, xhl[m], acc[n][m], 0, 0, 0);
+        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wmh, xhm[m], acc[n][m], 0, 0, 0);
+        acc[n][m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whm, xhm[m], acc[n][m], 0, 0, 0);
       }
     }
     if (s + 1 < nst) lstore((s + 1) & 1);
     __syncthreads();
   }
 
-  // C/D map of the 32x32 shapes: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  // C/D map of the 16x16 shapes, product taken transposed: lane (r16, q4) holds X row r16 of its m-block and the
+  // four output columns 4 q4 .. 4 q4 + 3 of its n-block
+  const bool vec4 = (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(Y) & 15u) == 0);
 #pragma unroll
-  for (int n = 0; n < NB; ++n) {
-    const int64_t col = n0 + wn * 32 * NB + n * 32 + i32;
-    const float bcol = col < N ? bias[col] : 0.f;
+  for (int n = 0; n < NQ; ++n) {
+    const int64_t col = n0 + wn * 32 * NB + n * 16 + q4 * 4;
+    float bc[4];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int r = 0; r < 4; ++r) bc[r] = (col + r < N) ? bias[col + r] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        l3_f2 y = l3_f2{acc[m][n][r] + bcol, acc[m][n][r + 1] + bcol};
-        if (ACT == MI_OOV_ACT_GELU) y = l3_gelu2(y);
-        if (ACT == MI_OOV_ACT_SIGMOID) y = l3_f2{l3_act<ACT>(y.x), l3_act<ACT>(y.y)};
-        const int64_t row = b0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;  // and row + 1
-        if (row < B && col < N) Y[row * N + col] = y.x;
-        if (row + 1 < B && col < N) Y[(row + 1) * N + col] = y.y;
+    for (int m = 0; m < 4; ++m) {
+      const int64_t row = b0 + wm * 64 + m * 16 + r16;
+      l3_f2 y0 = l3_f2{acc[n][m][0] + bc[0], acc[n][m][1] + bc[1]}, y1 = l3_f2{acc[n][m][2] + bc[2], acc[n][m][3] + bc[3]};
+      if (ACT == MI_OOV_ACT_GELU) y0 = l3_gelu2(y0), y1 = l3_gelu2(y1);
+      if (ACT == MI_OOV_ACT_SIGMOID) y0 = l3_f2{l3_act<ACT>(y0.x), l3_act<ACT>(y0.y)}, y1 = l3_f2{l3_act<ACT>(y1.x), l3_act<ACT>(y1.y)};
+      if (row < B) {
+        float* dst = Y + row * N + col;
+        if (vec4 && col + 3 < N) {
+          *reinterpret_cast<l3_f32x4*>(dst) = l3_f32x4{y0.x, y0.y, y1.x, y1.y};
+        } else {
+          if (col + 0 < N) dst[0] = y0.x;
+          if (col + 1 < N) dst[1] = y0.y;
+          if (col + 2 < N) dst[2] = y1.x;
+          if (col + 3 < N) dst[3] = y1.y;
+        }
       }
+    }
   }
 }
 
@@ -270,7 +285,6 @@ constexpr int kFastRow = 48;                      // bf16 elements per LDS / ima
 constexpr int kFastWStage = kFastN * kFastRow * 2;  // bytes of a W stage image (24 576 = 24 DMA pieces of 1 KiB)
 constexpr int kFastXStage = kFastM * kFastRow * 2;
 constexpr int kFastLds = 3 * kFastWStage + 2 * kFastXStage;  // 122 880 B
-typedef float l3_f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
@@ -548,8 +562,7 @@ extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void
   hipStream_t st = static_cast<hipStream_t>(stream);
   // developer knob, read per call (the tests force the pipelined kernel onto small shapes with it): 0 = by shape,
   // 1 / 2 / 3 = the generic kernel with 128 x 128 / 256 x 256 / 128 x 64 tiles, 4 = the pipelined kernel where it applies.
-  // The generic forms agree bit for bit; the pipelined kernel pairs the six products differently inside a 16-k step
-  // (two planes per matrix instruction), so it agrees with them within the accumulator's roundings only.
+  // Every form does the same arithmetic in the same order: results do not depend on it.
   const int shape = static_cast<int>(env_knob("MI_OOV_X3_SHAPE", 0, 0, 4));
   // the pipelined 256 x 256 form: K a multiple of 16 (no tail chunk), rows of X 16-byte aligned, outputs wider than 128
   // ... when its 256 x 256 tiles fill more than half of the CUs: a tile is 122 us of one CU at K = 1024 however few

@@ -1030,10 +1030,10 @@ def _hash_net_layers(net):
     return layers
 
 
-# Batches from this many rows on take the split-bf16 layers in `hash_net_forward` (below it the f32 kernel's launch is as
-# quick and bit-identical to the oracle's chain).  MI_OOV_LINEAR_X3=0 keeps every batch on the f32 kernel, =1 puts
-# every batch on the split one.
-_X3_MIN_ROWS = 1024
+# `hash_net_forward` runs every batch on the split-bf16 layers: they are quicker than the f32 matrix instruction at every
+# size (65536 x 1024 -> 512: 324 vs 587 us, 1024 rows: 56 vs 91, 64 rows: 65 vs 86) and every tile form does the same
+# arithmetic in the same order, so a row's result does not depend on the batch it sits in.  MI_OOV_LINEAR_X3=0 puts
+# inference on the f32 kernel (`linear_act`, bit-identical to the oracle's chain; what training uses).
 _x3_weights = {}  # id(Linear.weight) -> LinearX3Weights (which holds the tensor weakly; dropped when the tensor dies)
 
 
@@ -1045,22 +1045,19 @@ def _x3_weights_of(weight):
     return w
 
 
-def _x3_wanted(rows):
-    mode = os.environ.get("MI_OOV_LINEAR_X3", "")
-    if mode == "0":
-        return False
-    return mode == "1" or rows >= _X3_MIN_ROWS
+def _x3_wanted():
+    return os.environ.get("MI_OOV_LINEAR_X3", "") != "0"
 
 
 def hash_net_forward(net, x):
     """Run an nn.Sequential of Linear / GELU / Sigmoid (the reference's *_hash_net, dh_embedder.py:70-89) with each
-    activation fused into the producing layer's epilogue.  Inference form: batches of `_X3_MIN_ROWS` rows or more run
-    on the bf16 matrix cores at f32 accuracy (`linear_act_x3`; the weights' three-plane split is kept per weight tensor
-    and re-made when the tensor's version counter moves; an input whose width is not a multiple of 16 is padded with
-    zero columns once), smaller ones on the f32 matrix instruction (`linear_act`,
-    bit-identical to the oracle's chain).  Under autograd `hash_net_train` keeps the pre-activations and supplies the
-    backward on the f32 GEMM kernel."""
-    x3 = _x3_wanted(x.shape[0])
+    activation fused into the producing layer's epilogue.  Inference form: the layers run on the bf16 matrix cores at
+    f32 accuracy (`linear_act_x3`; the weights' three-plane split is kept per weight tensor and re-made when the tensor's
+    version counter moves; an input whose width is not a multiple of 16 is padded with zero columns once).  Within an
+    f32 accumulation's error of the f32 product, not the oracle's summation order; MI_OOV_LINEAR_X3=0 selects the
+    bit-exact f32 kernel instead.  Under autograd `hash_net_train` keeps the pre-activations and supplies the backward
+    on the f32 GEMM kernel."""
+    x3 = _x3_wanted()
     for lin, act in _hash_net_layers(net):
         if x3:
             if x.shape[1] % 16:  # (fdhe: K hashes + F feature columns) zero columns up to a multiple of 16: the pipelined kernel

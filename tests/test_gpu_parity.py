@@ -312,9 +312,8 @@ def test_linear_x3_vs_oracle(B, K, N_out, form, oracle, ops, dev, monkeypatch):
 
 def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev, monkeypatch):
     """(a) An input padded to a multiple of 16 columns (what hash_net_forward hands over for fdhe's K + F columns) goes
-    through the pipelined kernel: within the bound of test_linear_x3_vs_oracle of the generic kernel on the unpadded rows
-    (the two pair the six products differently inside a 16-k step), and whatever finite values the padding columns hold
-    -- they meet zero weights -- the result is the same bit for bit.  (b) BASELINE's dhe shape, 65536 x 1024 -> 512: every
+    through the pipelined kernel: bit-identical to the generic kernel on the unpadded rows (the same arithmetic in the same
+    order), whatever finite values the padding columns hold -- they meet zero weights.  (b) BASELINE's dhe shape, 65536 x 1024 -> 512: every
     row agrees with the f32 kernel within that bound, and the result does not depend on where a row sits in the batch
     (rows of a 65536-row call == the same rows as a 32768-row call: the persistent workgroups walk other tiles)."""
     rng = np.random.default_rng(77)
@@ -329,7 +328,8 @@ def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev, monkeypatch):
     padded = ops.linear_act_x3(torch.nn.functional.pad(Xt, (0, -K % 16)), Wt, bt, None)
     sevens = ops.linear_act_x3(torch.nn.functional.pad(Xt, (0, -K % 16), value=7.0), Wt, bt, None)
     monkeypatch.delenv("MI_OOV_X3_SHAPE")
-    assert bool(((plain - padded).abs() <= 8 * 2.0 ** -24 * den).all()) and torch.equal(padded, sevens)
+    assert torch.equal(plain, padded) and torch.equal(padded, sevens)  # (the two kernels do the same arithmetic in the same order)
+    assert bool(((plain - ops.linear_act(Xt, Wt, bt, None)).abs() <= 8 * 2.0 ** -24 * den).all())
     with pytest.raises(ValueError):
         ops.linear_act_x3(torch.nn.functional.pad(Xt, (0, 1)), Wt, bt, None)
     g = torch.Generator(device=dev).manual_seed(5)
@@ -370,23 +370,27 @@ def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
     assert torch.equal(ops.linear_act_x3(Xt, Wt, bt, None, cache), y0)
 
 
-def test_hash_net_forward_takes_the_split_layers_from_1024_rows(ops, dev, monkeypatch):
+def test_hash_net_forward_runs_the_split_layers_whatever_the_batch(ops, dev, monkeypatch):
+    """Inference runs on mi_oov_linear_x3 at every batch size, and a row's result does not depend on the batch it sits in
+    (1500 rows: 128 x 128 tiles; the same rows inside a 40000-row batch: the pipelined 256 x 256 kernel for the wide layer);
+    MI_OOV_LINEAR_X3=0 selects the f32 kernel."""
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(48, 512), torch.nn.GELU(), torch.nn.Linear(512, 64), torch.nn.Sigmoid()).to(dev)
     calls = {"x3": 0, "f32": 0}
     real_x3, real_f32 = ops.linear_act_x3, ops.linear_act
     monkeypatch.setattr(ops, "linear_act_x3", lambda *a, **k: (calls.__setitem__("x3", calls["x3"] + 1), real_x3(*a, **k))[1])
     monkeypatch.setattr(ops, "linear_act", lambda *a, **k: (calls.__setitem__("f32", calls["f32"] + 1), real_f32(*a, **k))[1])
-    x = torch.rand((1500, 48), device=dev) * 2 - 1
+    x = torch.rand((40000, 48), device=dev) * 2 - 1
     with torch.no_grad():
-        big, small, ref = ops.hash_net_forward(net, x), ops.hash_net_forward(net, x[:100]), net(x)
-    assert calls == {"x3": 2, "f32": 2}
-    assert torch.allclose(big, ref, rtol=1e-5, atol=1e-6) and torch.allclose(small, ref[:100], rtol=1e-5, atol=1e-6)
+        big, mid, small, ref = ops.hash_net_forward(net, x), ops.hash_net_forward(net, x[:1500]), ops.hash_net_forward(net, x[:7]), net(x)
+    assert calls == {"x3": 6, "f32": 0}
+    assert torch.allclose(big, ref, rtol=1e-5, atol=1e-6)
+    assert torch.equal(mid, big[:1500]) and torch.equal(small, big[:7])
     monkeypatch.setenv("MI_OOV_LINEAR_X3", "0")
     with torch.no_grad():
-        exact = ops.hash_net_forward(net, x)
-    assert calls == {"x3": 2, "f32": 4} and torch.equal(exact[:100], small)
-    assert (exact - big).abs().max().item() <= 1e-6
+        exact = ops.hash_net_forward(net, x[:1500])
+    assert calls == {"x3": 6, "f32": 2}
+    assert (exact - mid).abs().max().item() <= 1e-6
 
 
 def test_topk_edge_cases(oracle, ops, dev):

@@ -104,7 +104,7 @@ def test_slsh_embedder_class(mi, golden, dev):
     assert np.array_equal(model.user_oov_buckets.weight.grad[:, 0].cpu().numpy(), want)
 
 
-@pytest.mark.parametrize("x3", ["0", "1"])  # the f32 matrix instruction / the split-bf16 layers (what batches >= 1024 rows take)
+@pytest.mark.parametrize("x3", ["0", "1"])  # the f32 matrix instruction (MI_OOV_LINEAR_X3=0) / the split-bf16 layers (what inference runs)
 def test_dhe_embedder_class(mi, golden, dev, tmp_path, monkeypatch, x3):
     z, s = golden("dhe.npz"), golden("siphash.json")
     monkeypatch.chdir(tmp_path)

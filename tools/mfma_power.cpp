@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -36,6 +37,24 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int zero) {
     float s = 0;
     for (int i = 0; i < 8; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
     out[t] = s;
+  } else if (SHAPE == 2) {
+    f32x4 acc[32];
+    f16x8 ah[4], bh[4];  // the same random bits read as f16: sign, exponent 0x0F/0x0E-ish, random mantissa
+    for (int i = 0; i < 4; ++i) {
+      u32x4 ua = __builtin_bit_cast(u32x4, a[i]), ub = __builtin_bit_cast(u32x4, b[i]);
+      for (int j = 0; j < 4; ++j) { ua[j] = (ua[j] & 0x83FF83FFu) | 0x3C003C00u; ub[j] = (ub[j] & 0x83FF83FFu) | 0x3C003C00u; if (zero) { ua[j] = 0; ub[j] = 0; } }
+      ah[i] = __builtin_bit_cast(f16x8, ua); bh[i] = __builtin_bit_cast(f16x8, ub);
+    }
+    for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int i = 0; i < 32; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[(i + j) & 3], bh[((i >> 2) + j) & 3], acc[i], 0, 0, 0);
+    }
+    float s = 0;
+    for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
+    out[t] = s;
   } else {
     f32x4 acc[32];
     for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
@@ -43,7 +62,7 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int zero) {
 #pragma unroll
       for (int i = 0; i < 32; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + j) & 3], b[(i >> 2 + j) & 3], acc[i], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[(i + j) & 3], b[((i >> 2) + j) & 3], acc[i], 0, 0, 0);
     }
     float s = 0;
     for (int i = 0; i < 32; ++i) for (int r = 0; r < 4; ++r) s += acc[i][r];
@@ -57,17 +76,17 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
   for (int zero = 0; zero < 2; ++zero)
-    for (int shape = 0; shape < 2; ++shape) {
+    for (int shape = 0; shape < 3; ++shape) {
       for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        if (shape == 0) k<0><<<wgs, 256>>>(out, iters, zero); else k<1><<<wgs, 256>>>(out, iters, zero);
+        if (shape == 0) k<0><<<wgs, 256>>>(out, iters, zero); else if (shape == 1) k<1><<<wgs, 256>>>(out, iters, zero); else k<2><<<wgs, 256>>>(out, iters, zero);
         hipEventRecord(e1);
         hipEventSynchronize(e1);
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         // per wave and iteration: shape 0: 32 MFMAs x 32768 flop; shape 1: 64 MFMAs x 16384 flop: the same
         const double flop = (double)wgs * 4 * iters * 32 * 32768.0;
-        if (rep == 2) printf("%s operands, %s: %.3f ms  %.0f TFLOP/s\n", zero ? "zero  " : "random", shape ? "16x16x32" : "32x32x16", ms, flop / ms / 1e9);
+        if (rep == 2) printf("%s operands, %s: %.3f ms  %.0f TFLOP/s\n", zero ? "zero  " : "random", shape == 0 ? "bf16 32x32x16" : shape == 1 ? "bf16 16x16x32" : "f16  16x16x32", ms, flop / ms / 1e9);
       }
     }
   return 0;
