@@ -73,6 +73,8 @@ _SIGNATURES = {
     "mi_oov_linear_x3_weights_bytes": (_i64, [_i64, _i64]),
     "mi_oov_linear_x3_prepare": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "mi_oov_linear_x3": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
+    "mi_oov_linear_x3_splitk_workspace": (_i64, [_i64, _i64, _i64]),
+    "mi_oov_linear_x3_splitk": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, ctypes.c_int, _vp, _i64, _vp, _vp]),
     "mi_oov_act_forward": (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp]),
     "mi_oov_act_backward": (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
     "mi_oov_transpose": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),

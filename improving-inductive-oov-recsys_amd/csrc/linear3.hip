@@ -133,7 +133,7 @@ template <int WM, int WN, int NB, int ACT, bool VEC>
 __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __restrict__ X, int64_t B, int64_t K,
                                                                  const l3_u32x4* __restrict__ Wp, int64_t N,
                                                                  const float* __restrict__ bias, float* __restrict__ Y,
-                                                                 int n_nblk, int n_mblk) {
+                                                                 int n_nblk, int n_mblk, int ksplit) {
   constexpr int T = 64 * WM * WN, BMt = 64 * WM, BNt = 32 * NB * WN;
   constexpr int XU = (BMt * 2 + T - 1) / T;  // 8-float units of X per thread and stage
   constexpr int WU = (BNt * 6 + T - 1) / T;  // 16-byte units of the split W per thread and stage
@@ -148,7 +148,14 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
   if (mb_i >= n_mblk) return;
   const int64_t b0 = static_cast<int64_t>(mb_i) * BMt, n0 = static_cast<int64_t>(nb_i) * BNt;
   const int64_t Np = l3_np(N);
-  const int nst = static_cast<int>(l3_chunks(K));
+  // split K (training's dW = dZ^T X: a few output tiles, K = the batch): workgroup (x, y) takes the y-th share of the
+  // 16-k stages and leaves its sums, no bias, no activation, in slab y of Y = the workspace [ksplit][B][N];
+  // linear_x3_reduce_kernel adds the slabs in order.  ksplit = 1: the whole K, Y the output.
+  const int nst_all = static_cast<int>(l3_chunks(K));
+  const int per = (nst_all + ksplit - 1) / ksplit;
+  const int st0 = static_cast<int>(blockIdx.y) * per;
+  const int nst = (st0 + per < nst_all) ? st0 + per : nst_all;  // stages [st0, nst)
+  if (ksplit > 1) Y += static_cast<int64_t>(blockIdx.y) * B * N;
 
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WN, wn = wv % WN;
@@ -201,10 +208,12 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
     return __builtin_bit_cast(l3_bf16x8, *reinterpret_cast<const l3_u32x4*>(base + (row0 + r16) * kL3Row + (ps ? p1 : p0) * 16 + kh * 8));
   };
 
-  gload(0);
-  lstore(0);
+  if (st0 < nst) {
+    gload(st0);
+    lstore(st0 & 1);
+  }
   __syncthreads();
-  for (int s = 0; s < nst; ++s) {
+  for (int s = st0; s < nst; ++s) {
     if (s + 1 < nst) gload(s + 1);
     const unsigned short* sX = l3_lds + (s & 1) * kStage;
     const unsigned short* sW = sX + BMt * kL3Row;
@@ -238,7 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN) void linear_x3_kernel(const float* __
     const int64_t col = n0 + wn * 32 * NB + n * 16 + q4 * 4;
     float bc[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) bc[r] = (col + r < N) ? bias[col + r] : 0.f;
+    for (int r = 0; r < 4; ++r) bc[r] = (ksplit == 1 && col + r < N) ? bias[col + r] : 0.f;
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int64_t row = b0 + wm * 64 + m * 16 + r16;
@@ -505,17 +514,37 @@ static int launch_x3_fast(const float* X, int64_t B, int64_t K, const void* wspl
 }
 
 template <int WM, int WN, int NB, int ACT, bool VEC>
-static int launch_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N, float* Y, hipStream_t st) {
+static int launch_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N, float* Y, hipStream_t st,
+                     int ksplit = 1) {
   constexpr int T = 64 * WM * WN, BMt = 64 * WM, BNt = 32 * NB * WN;
   const int64_t n_mblk = (B + BMt - 1) / BMt, n_nblk = (N + BNt - 1) / BNt;
   const int64_t grid = (n_mblk + 7) / 8 * 8 * n_nblk;
-  if (grid > 0x7FFFFFFF || n_mblk > 0x7FFFFFFF) return MI_OOV_ERR_SHAPE;
+  if (grid > 0x7FFFFFFF || n_mblk > 0x7FFFFFFF || ksplit < 1 || ksplit > 65535) return MI_OOV_ERR_SHAPE;
   const size_t lds = 2 * static_cast<size_t>(BMt + BNt) * kL3Row * sizeof(unsigned short);
   auto k = linear_x3_kernel<WM, WN, NB, ACT, VEC>;
   if (int rc = set_lds(k, lds)) return rc;
-  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid)), dim3(T), lds, st, X, B, K, static_cast<const l3_u32x4*>(wsplit), N, bias, Y,
-                     static_cast<int>(n_nblk), static_cast<int>(n_mblk));
+  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(grid), static_cast<unsigned>(ksplit)), dim3(T), lds, st, X, B, K,
+                     static_cast<const l3_u32x4*>(wsplit), N, bias, Y, static_cast<int>(n_nblk), static_cast<int>(n_mblk), ksplit);
   return check_launch();
+}
+
+// Y = act(slab 0 + slab 1 + ... (in this order) + bias): the second half of a split-K product
+template <int ACT>
+__global__ __launch_bounds__(kBlock) void linear_x3_reduce_kernel(const float* __restrict__ part, int ksplit, int64_t total, int64_t N,
+                                                                  const float* __restrict__ bias, float* __restrict__ Y) {
+  for (int64_t i = (static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x) * 2; i < total; i += static_cast<int64_t>(gridDim.x) * kBlock * 2) {
+    const bool two = i + 1 < total;
+    l3_f2 v = l3_f2{0.f, 0.f};
+    for (int z = 0; z < ksplit; ++z) {
+      const float* p = part + static_cast<int64_t>(z) * total + i;
+      v = v + l3_f2{p[0], two ? p[1] : 0.f};
+    }
+    v = v + l3_f2{bias[i % N], two ? bias[(i + 1) % N] : 0.f};
+    if (ACT == MI_OOV_ACT_GELU) v = l3_gelu2(v);
+    if (ACT == MI_OOV_ACT_SIGMOID) v = l3_f2{l3_act<ACT>(v.x), l3_act<ACT>(v.y)};
+    Y[i] = v.x;
+    if (two) Y[i + 1] = v.y;
+  }
 }
 
 template <int WM, int WN, int NB>
@@ -585,4 +614,33 @@ extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void
     case 3: return launch_x3_act<2, 2, 1>(X, B, K, wsplit, bias, N_out, act, Y, st);
     default: return launch_x3_act<2, 2, 4>(X, B, K, wsplit, bias, N_out, act, Y, st);
   }
+}
+
+extern "C" int64_t mi_oov_linear_x3_splitk_workspace(int64_t B, int64_t N_out, int64_t ksplit) {
+  if (B < 0 || N_out <= 0 || ksplit < 1 || ksplit > 65535) return MI_OOV_ERR_SHAPE;
+  return ksplit * B * N_out * static_cast<int64_t>(sizeof(float));
+}
+
+extern "C" int mi_oov_linear_x3_splitk(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N_out,
+                                       int act, float* Y, int64_t ksplit, void* workspace, void* stream) {
+  if (B < 0 || K <= 0 || N_out <= 0 || ksplit < 1 || ksplit > 65535) return MI_OOV_ERR_SHAPE;
+  if (act < 0 || act > 2) return MI_OOV_ERR_KIND;
+  if (B == 0) return MI_OOV_OK;
+  if (!X || !wsplit || !bias || !Y || !workspace) return MI_OOV_ERR_NULL;
+  if (!aligned16(wsplit) || !aligned16(workspace)) return MI_OOV_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* part = static_cast<float*>(workspace);
+  const bool vec = (K % 4 == 0) && aligned16(X);
+  const int rc = vec ? launch_x3<2, 2, 2, MI_OOV_ACT_NONE, true>(X, B, K, wsplit, bias, N_out, part, st, static_cast<int>(ksplit))
+                     : launch_x3<2, 2, 2, MI_OOV_ACT_NONE, false>(X, B, K, wsplit, bias, N_out, part, st, static_cast<int>(ksplit));
+  if (rc) return rc;
+  const int64_t total = B * N_out, units = (total + 2 * kBlock - 1) / (2 * kBlock);
+  const dim3 grid(static_cast<unsigned>(units < kMaxGrid ? units : kMaxGrid));
+  const int ks = static_cast<int>(ksplit);
+  switch (act) {
+    case MI_OOV_ACT_NONE: hipLaunchKernelGGL(linear_x3_reduce_kernel<MI_OOV_ACT_NONE>, grid, dim3(kBlock), 0, st, part, ks, total, N_out, bias, Y); break;
+    case MI_OOV_ACT_GELU: hipLaunchKernelGGL(linear_x3_reduce_kernel<MI_OOV_ACT_GELU>, grid, dim3(kBlock), 0, st, part, ks, total, N_out, bias, Y); break;
+    default: hipLaunchKernelGGL(linear_x3_reduce_kernel<MI_OOV_ACT_SIGMOID>, grid, dim3(kBlock), 0, st, part, ks, total, N_out, bias, Y); break;
+  }
+  return check_launch();
 }

@@ -993,7 +993,14 @@ class LinearX3Weights:
         return self.split
 
 
-def linear_act_x3(X, W, bias, act=None, weights=None):
+def _x3_ksplit(rows, n_out, k):
+    """Shares of K for a training product: enough 128 x 128 tiles x shares to give every CU two workgroups, no share
+    below 8 stages of 16 k."""
+    tiles = -(-rows // 128) * -(-n_out // 128)
+    return max(1, min(512 // tiles, -(-k // 16) // 8, 64))
+
+
+def linear_act_x3(X, W, bias, act=None, weights=None, ksplit=1):
     """act(X @ W.T + bias) on the bf16 matrix cores at f32 accuracy (mi_oov_linear_x3: every operand as three bf16
     planes, six products accumulated in f32; csrc/linear3.hip).  The inference form of the hash nets' layers
     (dh_embedder.py:70-89): within an f32 accumulation's error of `linear_act`, not bit-identical to it.  `weights`: a
@@ -1006,6 +1013,13 @@ def linear_act_x3(X, W, bias, act=None, weights=None):
         raise ValueError(f"shape mismatch: X {tuple(X.shape)}, W {tuple(W.shape)}, bias {tuple(bias.shape)}")
     split = (weights if weights is not None else LinearX3Weights(W)).get()
     Y = torch.empty((X.shape[0], W.shape[0]), dtype=torch.float32, device=X.device)
+    if ksplit > 1:  # (training shapes: `_gemm_nt`; the rounding depends on ksplit, so inference never takes this)
+        ws = torch.empty((int(C.lib().mi_oov_linear_x3_splitk_workspace(X.shape[0], W.shape[0], ksplit)),), dtype=torch.uint8, device=X.device)
+        with C.on_device(X):
+            rc = C.lib().mi_oov_linear_x3_splitk(C.ptr(X), X.shape[0], X.shape[1], C.ptr(split), C.ptr(bias), W.shape[0], ACTS[act],
+                                                 C.ptr(Y), ksplit, C.ptr(ws), C.stream_of(X))
+        C.check(rc, "mi_oov_linear_x3_splitk")
+        return Y
     with C.on_device(X):
         rc = C.lib().mi_oov_linear_x3(C.ptr(X), X.shape[0], X.shape[1], C.ptr(split), C.ptr(bias), W.shape[0], ACTS[act],
                                       C.ptr(Y), C.stream_of(X))
@@ -1098,19 +1112,38 @@ def transpose(A):
     return At
 
 
+_X3_TRAIN_MAX_SPLIT_BYTES = 256 << 20  # an operand whose three-plane split would be larger goes through the f32 kernel
+
+
+def _gemm_nt(A, Bm, weights=None):
+    """A [M,K] x Bm [N,K]^T -> [M,N], the product every step of the hash nets' training is made of.  On the split-bf16
+    kernel (`linear_act_x3` with a zero bias; Bm is the operand that is split ahead of the launch) unless
+    MI_OOV_LINEAR_X3=0 or Bm's split would not fit `_X3_TRAIN_MAX_SPLIT_BYTES`: then the f32 kernel."""
+    if _x3_wanted() and Bm.numel() * 6 <= _X3_TRAIN_MAX_SPLIT_BYTES:
+        zero = torch.zeros((Bm.shape[0],), dtype=torch.float32, device=A.device)
+        return linear_act_x3(A, Bm, zero, None, weights, _x3_ksplit(A.shape[0], Bm.shape[0], A.shape[1]))
+    return _full_sort_forward(A, Bm)
+
+
 class _HashNet(torch.autograd.Function):
     """The reference's *_hash_net under autograd (dh_embedder.py:70-89,191-217; dnn_embedder.py:65-109) on this
     library's kernels only.  forward keeps every layer's input and pre-activation; backward per layer:
         dZ = dY * act'(Z)     dW = dZ^T X     db = 1^T dZ     dX = dZ W
-    -- three products on the f32-MFMA GEMM (`_full_sort_forward`: one fmaf chain per element over increasing k) after
-    `transpose` has put the contracted dimension last."""
+    -- three products after `transpose` has put the contracted dimension last, each on the split-bf16 GEMM
+    (`_gemm_nt`: f32 accuracy on the bf16 matrix cores, 1.6 x the f32 matrix instruction at a 2048-row step; round 3)
+    or, under MI_OOV_LINEAR_X3=0, on the f32-MFMA GEMM (one fmaf chain per element over increasing k)."""
 
     @staticmethod
     def forward(ctx, x, acts, *params):
         h, saved = _f32(x, "x"), []
+        x3 = _x3_wanted()
         for li, act in enumerate(acts):
             W, b = params[2 * li], params[2 * li + 1]
-            z = linear_act(h, W, b, None)
+            if x3:
+                hp = torch.nn.functional.pad(h, (0, -h.shape[1] % 16)) if h.shape[1] % 16 else h
+                z = linear_act_x3(hp, W, b, None, _x3_weights_of(W))
+            else:
+                z = linear_act(h, W, b, None)
             saved += [h, z]
             h = act_forward(z, act) if act else z
         ctx.save_for_backward(*saved, *[p for i, p in enumerate(params) if i % 2 == 0])
@@ -1129,12 +1162,12 @@ class _HashNet(torch.autograd.Function):
             h, z = saved[2 * li], saved[2 * li + 1]
             dz = act_backward(g, z, ctx.acts[li]) if ctx.acts[li] else g
             dzt = transpose(dz)  # [out, B]
-            grads[2 * li] = _full_sort_forward(dzt, transpose(h))  # [out, in]
+            grads[2 * li] = _gemm_nt(dzt, transpose(h))  # [out, in]
             if ones is None:
                 ones = torch.ones((1, dz.shape[0]), dtype=torch.float32, device=dz.device)
-            grads[2 * li + 1] = _full_sort_forward(ones, dzt).view(-1)  # [out]
+            grads[2 * li + 1] = _gemm_nt(ones, dzt).view(-1)  # [out]
             if li > 0 or ctx.x_needs:
-                g = _full_sort_forward(dz, transpose(Ws[li]))  # [B, in]
+                g = _gemm_nt(dz, transpose(Ws[li]))  # [B, in]
         return (g if ctx.x_needs else None, None, *grads)
 
 

@@ -361,6 +361,14 @@ int64_t mi_oov_linear_x3_weights_bytes(int64_t N_out, int64_t K);
 int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream);
 int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias,
                      int64_t N_out, int act, float* Y, void* stream);
+/* The same product with K cut into ksplit shares (1 .. 65535) that run side by side -- for the shapes of the hash nets'
+ * TRAINING (dh_embedder.py:191-217 under autograd): dW = dZ^T X has a few output tiles and K = the batch, one workgroup
+ * per tile would walk it alone.  Each share leaves its sums in a slab of workspace
+ * (mi_oov_linear_x3_splitk_workspace(B, N_out, ksplit) bytes, 16-byte aligned), a second kernel adds the slabs in
+ * order, then bias and activation: deterministic, but NOT the un-split entry's rounding (a result depends on ksplit). */
+int64_t mi_oov_linear_x3_splitk_workspace(int64_t B, int64_t N_out, int64_t ksplit);
+int mi_oov_linear_x3_splitk(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias,
+                            int64_t N_out, int act, float* Y, int64_t ksplit, void* workspace, void* stream);
 
 /* Training of the hash nets on this library's GEMM (csrc/mlp.hip): what torch autograd does for the reference's
  * nn.Sequential(Linear, GELU, ..., Linear, Sigmoid) (dh_embedder.py:70-89,191-217, dnn_embedder.py:65-109).

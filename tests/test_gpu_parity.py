@@ -345,6 +345,28 @@ def test_linear_x3_padded_rows_and_full_size(oracle, ops, dev, monkeypatch):
     assert torch.equal(part, y[32768:])
 
 
+@pytest.mark.parametrize("M,K,N_out,ksplit", [(512, 2048, 1024, 8), (70, 999, 33, 5), (130, 64, 200, 7), (3, 16, 5, 4)])
+def test_linear_x3_splitk_vs_oracle(M, K, N_out, ksplit, oracle, ops, dev):
+    """mi_oov_linear_x3_splitk (training's dW = dZ^T X shape: few output tiles, long K): K in ksplit shares, slabs added in
+    order -- the bound of test_linear_x3_vs_oracle against the oracle, the same bits on a second run, ksplit = 1 equal
+    to the un-split entry; shares that get no stage (ksplit = 7 over 4 stages) contribute zeros."""
+    rng = np.random.default_rng(M + K)
+    X = (rng.random((M, K)) * 2 - 1).astype(np.float32)
+    W = (rng.standard_normal((N_out, K)) / np.sqrt(K)).astype(np.float32)
+    b = rng.standard_normal(N_out).astype(np.float32)
+    Xt, Wt, bt = T(X, dev), T(W, dev), T(b, dev)
+    den = np.abs(X).astype(np.float64) @ np.abs(W).astype(np.float64).T + np.abs(b)
+    for act, code in ((None, 0), ("gelu", 1), ("sigmoid", 2)):
+        got = ops.linear_act_x3(Xt, Wt, bt, act, ksplit=ksplit)
+        want = oracle.linear_act(X, W, b, code)
+        assert np.all(np.abs(got.cpu().numpy().astype(np.float64) - want) <= 10 * 2.0 ** -24 * den + 2e-6 * np.abs(want) + 1e-7), act
+        assert torch.equal(got, ops.linear_act_x3(Xt, Wt, bt, act, ksplit=ksplit))
+    lib = ops.C.lib()
+    assert lib.mi_oov_linear_x3_splitk_workspace(M, N_out, ksplit) == ksplit * M * N_out * 4
+    assert lib.mi_oov_linear_x3_splitk(None, 4, 16, None, None, 8, 1, None, 0, None, None) == -2
+    assert lib.mi_oov_linear_x3_splitk(None, 4, 16, None, None, 8, 1, None, 4, None, None) == -1
+
+
 def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
     """Non-finite operands give non-finite results exactly where the f32 product does (NaN where that holds +-inf: the lower
     planes of an infinite value are inf - inf); the split weights follow the weight tensor's version counter."""
