@@ -243,3 +243,22 @@ def test_torch_library_registration():
         many = torch.ops.mi_oov.lsh_embed_score_multi([fids, fids], feat, planes, torch.zeros(8, 64, device="cuda"),
                                                       [torch.zeros(7, 64, device="cuda")] * 2)
         assert len(many) == 2 and many[0].shape == (7,)
+
+
+def test_split_layer_host_rules(monkeypatch):
+    """Host-side rules of the split-bf16 layers (no GPU): inference takes them unless MI_OOV_LINEAR_X3=0; the share count of
+    a training product gives every CU about two workgroups, never a share below 8 stages of 16 k, and leaves products
+    with enough tiles alone."""
+    import mi_oov
+    ops = mi_oov.ops
+    monkeypatch.delenv("MI_OOV_LINEAR_X3", raising=False)
+    assert ops._x3_wanted()
+    monkeypatch.setenv("MI_OOV_LINEAR_X3", "0")
+    assert not ops._x3_wanted()
+    monkeypatch.setenv("MI_OOV_LINEAR_X3", "1")
+    assert ops._x3_wanted()
+    assert ops._x3_ksplit(512, 1024, 2048) == 16      # dW of the first dhe layer at a 2048-row step: 32 tiles, 128 stages
+    assert ops._x3_ksplit(512, 1024, 65536) == 16     # ... the batch 32 x larger: still 16 shares (two workgroups per CU)
+    assert ops._x3_ksplit(1, 512, 2048) == 16         # db: 4 tiles
+    assert ops._x3_ksplit(2048, 1024, 512) == 4       # dX: 128 tiles, 32 stages
+    assert ops._x3_ksplit(65536, 512, 512) == 1 and ops._x3_ksplit(4, 4, 16) == 1
