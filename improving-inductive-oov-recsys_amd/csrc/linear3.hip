@@ -5,21 +5,25 @@
 // The f32 matrix instruction (v_mfma_f32_32x32x2_f32, mi_oov_linear_act) runs at 1/16 of the bf16 one's rate, and the
 // 1024-512-512-512-64 net of dhe is 142 GFLOP per 65536 lookups: 1.28 ms at 70 % of the f32 matrix peak.  Here every
 // f32 operand is held as THREE bf16 values h + m + l (round-to-nearest pieces of the running remainder: 3 x 8 = 24
-// significand bits, so h + m + l is the f32 value exactly) and six of the nine cross products are accumulated in f32 on
-// v_mfma_f32_32x32x16_bf16 -- l*h, h*l, m*m, m*h, h*m, h*h; the three left out (m*l, l*m, l*l) are below 2^-24 of
-// |x||w| each.  Every bf16 x bf16 product is exact in f32, so the result differs from the exact dot product by the
-// accumulator's roundings only, like the f32 chain's (measured against f64: the same error as the f32 kernel's or
-// smaller, tests/test_gpu_parity.py::test_linear_x3_*).  It is NOT the oracle's summation order: parity is within a
-// tolerance written in the test, not bit for bit -- mi_oov_linear_act stays the bit-exact form (training uses it).
+// significand bits, so h + m + l is the f32 value exactly) and six of the nine cross products are accumulated in f32 --
+// l*h, h*l, m*m, m*h, h*m, h*h; the three left out (m*l, l*m, l*l) are below 2^-24 of |x||w| each.  Every bf16 x bf16
+// product is exact in f32, so the result differs from the exact dot product by the accumulator's roundings only, like
+// the f32 chain's (measured against f64: the same error as the f32 kernel's or smaller,
+// tests/test_gpu_parity.py::test_linear_x3_*).  It is NOT the oracle's summation order: parity is within a tolerance
+// written in the test, not bit for bit -- mi_oov_linear_act stays the bit-exact form (MI_OOV_LINEAR_X3=0 on the host).
 //
-// Kernel: a workgroup of WM x WN waves computes a (64 WM) x (32 NB WN) tile, each wave 64 x (32 NB) of it (2 x NB
-// accumulators of 32 x 32).  K is walked 16 at a time through a double-buffered LDS stage (one barrier per stage):
-//   X  : f32 rows straight from the producer -- split into the three planes while staging (6 VALU operations per
+// The arithmetic, shared by both kernels of this file (they agree bit for bit): v_mfma_f32_16x16x32_bf16 with TWO planes
+// side by side in its 32 k, so that 16 k of the operands take three instructions per 16 x 16 output block,
+//   [x_h | x_l] . [w_l | w_h],   [x_h | x_m] . [w_m | w_h],   [x_h | x_m] . [w_h | w_m]      (in this order),
+// the product taken transposed (W rows as the A operand: a lane ends with four consecutive output columns of one row).
+//   X  : f32 rows straight from the producer -- split into the three planes while staging (5.5 vector operations per
 //        element, v_cvt_pk_bf16_f32), so no layer has to write anything but plain f32;
-//   W  : split ONCE per call by linear_x3_split_kernel into [K/16][N padded][3 planes][16] bf16 -- a stage of a
-//        workgroup is one contiguous piece of it.
-// LDS row = the three planes of 16 k side by side + 16 B of padding (112 B): the 16 lanes of a ds_read_b128 phase hit
-// 16 different 16-byte bank groups.  Per 16 k a wave reads (2 + NB) x 3 fragments for 2 NB x 6 matrix instructions.
+//   W  : split ONCE per weight update by linear_x3_split_kernel into [K/16][N padded][3 planes][16] bf16 -- a stage of a
+//        workgroup is one contiguous piece of it, and the pipelined kernel's LDS image as it stands.
+// LDS row = the three planes of 16 k side by side (96 B, no padding): conflict-free for the lane groups of the
+// ds_read_b128 that fetches a fragment (lane l: row l & 15, k half (l >> 4) & 1, plane-of-the-pair l >> 5).
+// Kernels: linear_x3_kernel (any shape; register-staged, double-buffered LDS; also the split-K form of training's
+// weight gradients) and linear_x3_fast_kernel (K % 16 == 0, wide outputs, enough tiles: persistent, W by LDS-DMA).
 #include "common.hpp"
 
 namespace mi_oov {
@@ -27,7 +31,6 @@ namespace mi_oov {
 typedef __bf16 l3_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 l3_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float l3_f32x2 __attribute__((ext_vector_type(2)));
-typedef float l3_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned int l3_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kL3NPad = 256;  // rows of the split weights are padded to a multiple of this (any tile shape fits)

@@ -341,10 +341,10 @@ enum { MI_OOV_ACT_NONE = 0, MI_OOV_ACT_GELU = 1, MI_OOV_ACT_SIGMOID = 2 };
 int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, const float* bias,
                       int64_t N_out, int act, float* Y, void* stream);
 
-/* The same layer on the bf16 matrix cores at f32 accuracy (csrc/linear3.hip; the inference form of the hash nets,
+/* The same layer on the bf16 matrix cores at f32 accuracy (csrc/linear3.hip; what the hash nets run on,
  * dh_embedder.py:140-170 -> 70-89).  Every f32 operand is held as three bf16 values h + m + l (= the f32 value exactly)
- * and six of the nine cross products are accumulated in f32 on v_mfma_f32_32x32x16_bf16; the three left out are below
- * 2^-24 |x||w| each.  Error against the exact dot product: that of an f32 accumulation (not larger than the f32 chain's
+ * and six of the nine cross products are accumulated in f32 on v_mfma_f32_16x16x32_bf16 (two planes side by side in
+ * the instruction's 32 k); the three left out are below 2^-24 |x||w| each.  Error against the exact dot product: that of an f32 accumulation (not larger than the f32 chain's
  * of mi_oov_linear_act, measured), but NOT the oracle's summation order -- parity is within the tolerance written in
  * tests/test_gpu_parity.py::test_linear_x3_vs_oracle, not bit for bit.  Finite operands only: where an
  * operand is infinite, NaN or above the largest bf16 (3.39e38) the result is NaN (the f32 product: +-inf or NaN).
@@ -355,8 +355,9 @@ int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, cons
  *                                                             inside the kernel while it is staged.
  * K here is the row length of X: the K the weights were prepared with, or that rounded up to a multiple of 16 -- the
  * columns beyond the weights' K meet the zeros the split is padded with (they must hold finite values).  Rows of a
- * multiple of 16 floats, 16-byte aligned, K >= 32 and N_out > 128 take the pipelined 256 x 256 kernel (one persistent
- * workgroup per CU, weights by LDS-DMA); everything else a generic tile kernel of the same arithmetic.                 */
+ * multiple of 16 floats, 16-byte aligned, K >= 32, N_out > 128 and enough rows to fill half of the CUs with 256 x 256
+ * tiles take the pipelined kernel (one persistent workgroup per CU, weights by LDS-DMA); everything else a generic tile
+ * kernel of the same arithmetic in the same order: a row's result does not depend on the batch it is computed in.   */
 int64_t mi_oov_linear_x3_weights_bytes(int64_t N_out, int64_t K);
 int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream);
 int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias,
