@@ -72,6 +72,7 @@ _SIGNATURES = {
     "mi_oov_linear_act": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
     "mi_oov_linear_x3_weights_bytes": (_i64, [_i64, _i64]),
     "mi_oov_linear_x3_prepare": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_linear_x3_prepare_t": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "mi_oov_linear_x3": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
     "mi_oov_linear_x3_splitk_workspace": (_i64, [_i64, _i64, _i64]),
     "mi_oov_linear_x3_splitk": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, ctypes.c_int, _vp, _i64, _vp, _vp]),

@@ -78,14 +78,23 @@ __device__ __forceinline__ void load8(const float* __restrict__ A, int64_t row, 
 // W f32[N,K] -> split [K/16][Np][3][16] bf16: a row of a chunk is the pipelined kernel's LDS row as it stands (6 units of
 // 16 bytes: unit (chunk * Np + n) * 6 + plane * 2 + half), so a stage of a workgroup is one contiguous piece that an
 // LDS-DMA copies without a register in between.
+template <bool TRANSPOSED>  // TRANSPOSED: W is given as its transpose, f32[K,N] row-major (training: dW's and dX's operands as they lie)
 __global__ __launch_bounds__(kBlock) void linear_x3_split_kernel(const float* __restrict__ W, int64_t N, int64_t K,
                                                                  l3_u32x4* __restrict__ out) {
   const int64_t Np = l3_np(N), units = l3_chunks(K) * Np * 2;
   for (int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; u < units; u += static_cast<int64_t>(gridDim.x) * kBlock) {
-    const int half = static_cast<int>(u & 1);
-    const int64_t n = (u >> 1) % Np, chunk = (u >> 1) / Np;
+    // plain: (half, n, chunk) with the half fastest -- a pair of threads reads 64 contiguous bytes of a row;
+    // transposed: (n, half, chunk) with n fastest -- a wave reads 64 consecutive floats of one k row at a time
+    const int half = TRANSPOSED ? static_cast<int>((u / Np) & 1) : static_cast<int>(u & 1);
+    const int64_t n = TRANSPOSED ? u % Np : (u >> 1) % Np, chunk = (u >> 1) / Np;
     float x[8];
-    load8<false>(W, n, N, K, chunk * 16 + half * 8, x);
+    if (TRANSPOSED) {
+      const int64_t k0 = chunk * 16 + half * 8;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) x[i] = (n < N && k0 + i < K) ? W[(k0 + i) * N + n] : 0.f;
+    } else {
+      load8<false>(W, n, N, K, chunk * 16 + half * 8, x);
+    }
     l3_u32x4 h, m, l;
     split3_x8(x, h, m, l);
     l3_u32x4* dst = out + (chunk * Np + n) * 6 + half;
@@ -573,15 +582,26 @@ extern "C" int64_t mi_oov_linear_x3_weights_bytes(int64_t N_out, int64_t K) {
   return l3_chunks(K) * l3_np(N_out) * 96;
 }
 
-extern "C" int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream) {
+static int x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream, bool transposed) {
   if (N_out <= 0 || K <= 0) return MI_OOV_ERR_SHAPE;
   if (!W || !wsplit) return MI_OOV_ERR_NULL;
   if (!aligned16(wsplit)) return MI_OOV_ERR_ALIGN;
   const int64_t units = l3_chunks(K) * l3_np(N_out) * 2;
   const int64_t grid = (units + kBlock - 1) / kBlock;
-  hipLaunchKernelGGL(linear_x3_split_kernel, dim3(static_cast<unsigned>(grid < kMaxGrid ? grid : kMaxGrid)), dim3(kBlock), 0,
-                     static_cast<hipStream_t>(stream), W, N_out, K, static_cast<l3_u32x4*>(wsplit));
+  const dim3 g(static_cast<unsigned>(grid < kMaxGrid ? grid : kMaxGrid));
+  if (transposed)
+    hipLaunchKernelGGL(linear_x3_split_kernel<true>, g, dim3(kBlock), 0, static_cast<hipStream_t>(stream), W, N_out, K, static_cast<l3_u32x4*>(wsplit));
+  else
+    hipLaunchKernelGGL(linear_x3_split_kernel<false>, g, dim3(kBlock), 0, static_cast<hipStream_t>(stream), W, N_out, K, static_cast<l3_u32x4*>(wsplit));
   return check_launch();
+}
+
+extern "C" int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream) {
+  return x3_prepare(W, N_out, K, wsplit, stream, false);
+}
+
+extern "C" int mi_oov_linear_x3_prepare_t(const float* Wt, int64_t N_out, int64_t K, void* wsplit, void* stream) {
+  return x3_prepare(Wt, N_out, K, wsplit, stream, true);
 }
 
 extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias, int64_t N_out,

@@ -965,11 +965,13 @@ class LinearX3Weights:
     once and re-made when the weight tensor was written to since (torch's version counter, as `LshTable`; after a write
     through `.data` call `invalidate()`)."""
 
-    __slots__ = ("_weight", "split", "version")
+    __slots__ = ("_weight", "split", "version", "transposed")
 
-    def __init__(self, weight):
+    def __init__(self, weight, transposed=False):
+        """transposed: `weight` is the TRANSPOSE of the layer's weight, [K, N_out] (mi_oov_linear_x3_prepare_t: training's
+        backward products take their operands as they lie)."""
         self._weight = weakref.ref(weight)  # (weak: hash_net_forward keys its cache of these by the weight tensor)
-        self.split, self.version = None, None
+        self.split, self.version, self.transposed = None, None, bool(transposed)
 
     def invalidate(self):
         self.version = None
@@ -980,14 +982,15 @@ class LinearX3Weights:
             raise RuntimeError("the weight tensor of this LinearX3Weights is gone")
         if self.split is None or self.version != w._version or self.split.device != w.device:
             src = _f32(w, "W")
-            n, k = src.shape
+            n, k = (src.shape[1], src.shape[0]) if self.transposed else src.shape
             nbytes = int(C.lib().mi_oov_linear_x3_weights_bytes(n, k))
             if nbytes <= 0:
                 raise ValueError(f"unsupported weight shape {tuple(src.shape)}")
             if self.split is None or self.split.numel() != nbytes or self.split.device != w.device:
                 self.split = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+            prepare = C.lib().mi_oov_linear_x3_prepare_t if self.transposed else C.lib().mi_oov_linear_x3_prepare
             with C.on_device(src):
-                rc = C.lib().mi_oov_linear_x3_prepare(C.ptr(src), n, k, C.ptr(self.split), C.stream_of(src))
+                rc = prepare(C.ptr(src), n, k, C.ptr(self.split), C.stream_of(src))
             C.check(rc, "mi_oov_linear_x3_prepare")
             self.version = w._version
         return self.split
@@ -1006,6 +1009,8 @@ def linear_act_x3(X, W, bias, act=None, weights=None, ksplit=1):
     (dh_embedder.py:70-89): within an f32 accumulation's error of `linear_act`, not bit-identical to it.  `weights`: a
     `LinearX3Weights` of W to reuse its split."""
     X, W, bias = _f32(X, "X"), _f32(W, "W"), _f32(bias, "bias")
+    if weights is not None and weights.transposed:  # W is the transposed weight [K, N_out]; only its split is used
+        W = W.t()
     K = W.shape[1]
     # X may carry the columns up to the next multiple of 16 (finite values: they meet the zero weights the split pads
     # with) -- rows of a multiple of 16 floats take the pipelined kernel, see `hash_net_forward`
@@ -1115,14 +1120,15 @@ def transpose(A):
 _X3_TRAIN_MAX_SPLIT_BYTES = 256 << 20  # an operand whose three-plane split would be larger goes through the f32 kernel
 
 
-def _gemm_nt(A, Bm, weights=None):
-    """A [M,K] x Bm [N,K]^T -> [M,N], the product every step of the hash nets' training is made of.  On the split-bf16
-    kernel (`linear_act_x3` with a zero bias; Bm is the operand that is split ahead of the launch) unless
-    MI_OOV_LINEAR_X3=0 or Bm's split would not fit `_X3_TRAIN_MAX_SPLIT_BYTES`: then the f32 kernel."""
-    if _x3_wanted() and Bm.numel() * 6 <= _X3_TRAIN_MAX_SPLIT_BYTES:
-        zero = torch.zeros((Bm.shape[0],), dtype=torch.float32, device=A.device)
-        return linear_act_x3(A, Bm, zero, None, weights, _x3_ksplit(A.shape[0], Bm.shape[0], A.shape[1]))
-    return _full_sort_forward(A, Bm)
+def _gemm_nt(A, Bt):
+    """A [M,K] x Bt [K,N] -> [M,N], the product every step of the hash nets' training is made of.  On the split-bf16
+    kernel (`linear_act_x3` with a zero bias; Bt is split as it lies, `mi_oov_linear_x3_prepare_t`, K cut into shares for
+    the shapes with few output tiles) unless MI_OOV_LINEAR_X3=0 or Bt's split would not fit
+    `_X3_TRAIN_MAX_SPLIT_BYTES`: then the f32 kernel on a transposed copy."""
+    if _x3_wanted() and Bt.numel() * 6 <= _X3_TRAIN_MAX_SPLIT_BYTES:
+        zero = torch.zeros((Bt.shape[1],), dtype=torch.float32, device=A.device)
+        return linear_act_x3(A, Bt, zero, None, LinearX3Weights(Bt, transposed=True), _x3_ksplit(A.shape[0], Bt.shape[1], A.shape[1]))
+    return _full_sort_forward(A, transpose(Bt))
 
 
 class _HashNet(torch.autograd.Function):
@@ -1161,13 +1167,12 @@ class _HashNet(torch.autograd.Function):
         for li in range(n - 1, -1, -1):
             h, z = saved[2 * li], saved[2 * li + 1]
             dz = act_backward(g, z, ctx.acts[li]) if ctx.acts[li] else g
-            dzt = transpose(dz)  # [out, B]
-            grads[2 * li] = _gemm_nt(dzt, transpose(h))  # [out, in]
+            grads[2 * li] = _gemm_nt(transpose(dz), h)  # dZ^T [out, B] x X [B, in] -> [out, in]
             if ones is None:
                 ones = torch.ones((1, dz.shape[0]), dtype=torch.float32, device=dz.device)
-            grads[2 * li + 1] = _gemm_nt(ones, dzt).view(-1)  # [out]
+            grads[2 * li + 1] = _gemm_nt(ones, dz).view(-1)  # 1^T [1, B] x dZ [B, out] -> [out]
             if li > 0 or ctx.x_needs:
-                g = _gemm_nt(dz, transpose(Ws[li]))  # [B, in]
+                g = _gemm_nt(dz, Ws[li])  # dZ [B, out] x W [out, in] -> [B, in]
         return (g if ctx.x_needs else None, None, *grads)
 
 

@@ -360,6 +360,9 @@ int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, cons
  * kernel of the same arithmetic in the same order: a row's result does not depend on the batch it is computed in.   */
 int64_t mi_oov_linear_x3_weights_bytes(int64_t N_out, int64_t K);
 int mi_oov_linear_x3_prepare(const float* W, int64_t N_out, int64_t K, void* wsplit, void* stream);
+/* the same split from the TRANSPOSE of the weights, Wt f32[K,N_out] row-major (training: the operands of dW = dZ^T X,
+ * db = 1^T dZ and dX = dZ W lie that way; no transposed copy is made first) */
+int mi_oov_linear_x3_prepare_t(const float* Wt, int64_t N_out, int64_t K, void* wsplit, void* stream);
 int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void* wsplit, const float* bias,
                      int64_t N_out, int act, float* Y, void* stream);
 /* The same product with K cut into ksplit shares (1 .. 65535) that run side by side -- for the shapes of the hash nets'

@@ -361,7 +361,11 @@ def test_linear_x3_splitk_vs_oracle(M, K, N_out, ksplit, oracle, ops, dev):
         want = oracle.linear_act(X, W, b, code)
         assert np.all(np.abs(got.cpu().numpy().astype(np.float64) - want) <= 10 * 2.0 ** -24 * den + 2e-6 * np.abs(want) + 1e-7), act
         assert torch.equal(got, ops.linear_act_x3(Xt, Wt, bt, act, ksplit=ksplit))
+    # the weights given as their transpose (mi_oov_linear_x3_prepare_t: how training's backward products find their operands)
+    Wtt = Wt.t().contiguous()
+    assert torch.equal(ops.linear_act_x3(Xt, Wtt, bt, None, ops.LinearX3Weights(Wtt, transposed=True), ksplit), ops.linear_act_x3(Xt, Wt, bt, None, ksplit=ksplit))
     lib = ops.C.lib()
+    assert lib.mi_oov_linear_x3_prepare_t(None, 8, 16, None, None) == -1 and lib.mi_oov_linear_x3_prepare_t(None, 0, 16, None, None) == -2
     assert lib.mi_oov_linear_x3_splitk_workspace(M, N_out, ksplit) == ksplit * M * N_out * 4
     assert lib.mi_oov_linear_x3_splitk(None, 4, 16, None, None, 8, 1, None, 0, None, None) == -2
     assert lib.mi_oov_linear_x3_splitk(None, 4, 16, None, None, 8, 1, None, 4, None, None) == -1
