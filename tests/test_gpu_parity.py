@@ -371,6 +371,25 @@ def test_linear_x3_splitk_vs_oracle(M, K, N_out, ksplit, oracle, ops, dev):
     assert lib.mi_oov_linear_x3_splitk(None, 4, 16, None, None, 8, 1, None, 4, None, None) == -1
 
 
+@pytest.mark.parametrize("B,K,N_out", [(33300, 32, 512), (66000, 48, 300), (35000, 160, 257)])
+def test_linear_x3_persistent_stream_of_short_tiles(B, K, N_out, ops, dev, monkeypatch):
+    """More 256 x 256 tiles than CUs, two to ten stages each: the persistent workgroups of the pipelined kernel cross
+    tile boundaries every few stages (the next tile's loads issued in this tile's last two stages, K = 32: in every
+    stage).  Bit-identical to the generic kernel's 128 x 128 tiles."""
+    g = torch.Generator(device=dev).manual_seed(B + K)
+    X = torch.rand((B, K), generator=g, device=dev) * 2 - 1
+    W = torch.randn((N_out, K), generator=g, device=dev) / K ** 0.5
+    b = torch.randn((N_out,), generator=g, device=dev)
+    monkeypatch.setenv("MI_OOV_X3_SHAPE", "1")
+    want = ops.linear_act_x3(X, W, b, "gelu")
+    monkeypatch.setenv("MI_OOV_X3_SHAPE", "4")
+    got = ops.linear_act_x3(X, W, b, "gelu")
+    monkeypatch.delenv("MI_OOV_X3_SHAPE")
+    assert torch.equal(got, want) and torch.equal(ops.linear_act_x3(X, W, b, "gelu"), want)
+    ref = torch.nn.functional.gelu(X @ W.T + b)
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5)
+
+
 def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
     """Non-finite operands give non-finite results exactly where the f32 product does (NaN where that holds +-inf: the lower
     planes of an infinite value are inf - inf); the split weights follow the weight tensor's version counter."""
