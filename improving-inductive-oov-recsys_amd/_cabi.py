@@ -57,6 +57,7 @@ _SIGNATURES = {
                                                _vp, _vp]),
     "mi_oov_slsh_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_siphash24_mod": (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_uint32, _vp, _vp]),
+    "mi_oov_siphash24_mod_ld": (ctypes.c_int, [_vp, _i64, _vp, _i64, ctypes.c_uint32, _vp, _i64, _vp]),
     "mi_oov_mapper_hash": (ctypes.c_int, [_vp, _i64, ctypes.c_int, _vp, _vp]),
     "mi_oov_mapper_map": (ctypes.c_int, [_vp, _i64, ctypes.c_int, _i64, _i64, _vp, _vp]),
     "mi_oov_gather_mean": (ctypes.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _vp]),

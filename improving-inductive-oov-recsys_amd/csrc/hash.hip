@@ -102,7 +102,7 @@ __device__ __forceinline__ uint32_t siphash24_lo(const SipKey& ks, u64p m) {
 template <bool KEYS_IN_LDS>
 __global__ __launch_bounds__(kBlock) void siphash_kernel(const int64_t* __restrict__ ids, int64_t B,
                                                          const uint8_t* __restrict__ keys, int K, int log2kp,
-                                                         uint32_t mask, float* __restrict__ out) {
+                                                         uint32_t mask, float* __restrict__ out, int64_t ld) {
   extern __shared__ __attribute__((aligned(16))) uint32_t skeys[];  // [K][8]: the key states (sip_key_state)
   const uint32_t* kp = reinterpret_cast<const uint32_t*>(keys);    // little-endian host & device
   if (KEYS_IN_LDS) {
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void siphash_kernel(const int64_t* __restri
         ks = sip_key_state({kp[4 * j], kp[4 * j + 1]}, {kp[4 * j + 2], kp[4 * j + 3]});
       }
       const uint32_t h = siphash24_lo(ks, m);
-      out[b * K + j] = static_cast<float>(h & mask);  // < 2^24: exact in f32
+      out[b * ld + j] = static_cast<float>(h & mask);  // < 2^24: exact in f32
     }
   }
 }
@@ -208,10 +208,10 @@ __global__ __launch_bounds__(kBlock) void mapper_kernel(const int64_t* __restric
 
 }  // namespace mi_oov
 
-extern "C" int mi_oov_siphash24_mod(const int64_t* ids, int64_t B, const uint8_t* keys, int64_t K, uint32_t mod,
-                                    float* out, void* stream) {
+extern "C" int mi_oov_siphash24_mod_ld(const int64_t* ids, int64_t B, const uint8_t* keys, int64_t K, uint32_t mod,
+                                       float* out, int64_t ld, void* stream) {
   using namespace mi_oov;
-  if (B < 0 || K <= 0) return MI_OOV_ERR_SHAPE;
+  if (B < 0 || K <= 0 || ld < K) return MI_OOV_ERR_SHAPE;
   if (mod == 0 || (mod & (mod - 1)) != 0 || mod > (1u << 24)) return MI_OOV_ERR_SHAPE;
   if (B == 0) return MI_OOV_OK;
   if (!ids || !keys || !out) return MI_OOV_ERR_NULL;
@@ -226,12 +226,17 @@ extern "C" int mi_oov_siphash24_mod(const int64_t* ids, int64_t B, const uint8_t
   const size_t lds = static_cast<size_t>(K) * 32;
   if (lds <= 64 * 1024) {
     hipLaunchKernelGGL(siphash_kernel<true>, dim3(grid), dim3(kBlock), lds, st, ids, B, keys, static_cast<int>(K),
-                       log2kp, mod - 1, out);
+                       log2kp, mod - 1, out, ld);
   } else {
     hipLaunchKernelGGL(siphash_kernel<false>, dim3(grid), dim3(kBlock), 0, st, ids, B, keys, static_cast<int>(K),
-                       log2kp, mod - 1, out);
+                       log2kp, mod - 1, out, ld);
   }
   return check_launch();
+}
+
+extern "C" int mi_oov_siphash24_mod(const int64_t* ids, int64_t B, const uint8_t* keys, int64_t K, uint32_t mod,
+                                    float* out, void* stream) {
+  return mi_oov_siphash24_mod_ld(ids, B, keys, K, mod, out, K, stream);
 }
 
 static int run_mapper(const int64_t* ids, int64_t B, int kind, int64_t n_orig, int64_t n_buckets, bool map,

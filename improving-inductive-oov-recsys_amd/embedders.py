@@ -342,12 +342,16 @@ def _hash_mlp(in_features, hidden, out_features, device):
                          nn.Sigmoid()).to(device)
 
 
+def _needs_grad(net, x):
+    return torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in net.parameters()))
+
+
 def _run_hash_net(net, x):
     """The reference's `*_hash_net(x)`.  Without autograd the Linear+GELU / Linear+Sigmoid pairs run on
-    mi_oov_linear_act (f32 MFMA, activation fused in the epilogue); when a gradient is required the same GEMM kernel
-    runs the forward unfused (pre-activations kept) and the backward (`ops.hash_net_train`): torch autograd only links
-    the pieces, it computes nothing."""
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in net.parameters())):
+    mi_oov_linear_x3 (bf16 matrix cores at f32 accuracy, activation fused in the epilogue); when a gradient is required
+    the same GEMM runs the forward unfused (pre-activations kept) and the backward (`ops.hash_net_train`): torch
+    autograd only links the pieces, it computes nothing."""
+    if _needs_grad(net, x):
         return ops.hash_net_train(net, x)
     return ops.hash_net_forward(net, x)
 
@@ -389,6 +393,16 @@ class _HashKeyMixin:
         the layers of chunk c was built and measured in round 3: 1.71 ms serial against 1.94 / 2.07 / 2.16 / 3.04 ms with
         2 / 3 / 4 / 8 chunks at K = 1024, 65536 lookups -- the f32 matrix instruction issues at the vector rate, so the
         integer hash and the GEMM compete for the same issue slots, and the smaller GEMMs fill the chip worse.)"""
+        if extra is not None and not _needs_grad(net, extra) and ops._x3_wanted():
+            # fdhe, inference: the hashes go straight into the net's input (rows of a multiple of 16 floats: what the
+            # pipelined layer kernel takes), the feature columns beside them, zeros behind -- no concatenation and no
+            # padding copy of the [B, K + F] matrix afterwards (two 268 MB copies at K = 1024, 65536 lookups)
+            K, F = self._key_tensor(ids.device).shape[0], extra.shape[1]
+            x = torch.empty((ids.numel(), -(-(K + F) // 16) * 16), dtype=torch.float32, device=ids.device)
+            ops.siphash24_mod(ids, self._key_tensor(ids.device), self.MAX_HASH, out=x)
+            x[:, K:K + F] = extra
+            x[:, K + F:] = 0.0
+            return ops.hash_net_forward(net, x)
         h = self._hash_ids(ids)
         return _run_hash_net(net, h if extra is None else torch.hstack((h, extra)))
 

@@ -717,16 +717,22 @@ def slsh_embed(ids, feat, planes, buckets):
     return _slsh_forward(ids, feat, planes, buckets, buckets.shape[0])[0]
 
 
-def siphash24_mod(ids, keys, mod=16777216):
-    """f32[B,K] of SipHash-2-4(key_j, LE64(id)) % mod (R/inductive/dh_embedder.py:140-170)."""
+def siphash24_mod(ids, keys, mod=16777216, out=None):
+    """f32[B,K] of SipHash-2-4(key_j, LE64(id)) % mod (R/inductive/dh_embedder.py:140-170).  out: a contiguous f32[B, ld]
+    buffer with ld >= K whose first K columns receive the hashes (the others are left alone); returned as is."""
     ids = _ids(ids)
     keys = C.dev_tensor(keys, torch.uint8, "keys")
     if keys.dim() != 2 or keys.shape[1] != 16:
         raise ValueError("keys must be u8[K,16]")
     B, K = ids.numel(), keys.shape[0]
-    out = torch.empty((B, K), dtype=torch.float32, device=ids.device)
+    if out is None:
+        out = torch.empty((B, K), dtype=torch.float32, device=ids.device)
+    else:
+        out = _f32(out, "out")
+        if out.dim() != 2 or out.shape[0] != B or out.shape[1] < K:
+            raise ValueError(f"out must be f32[{B}, >= {K}], got {tuple(out.shape)}")
     with C.on_device(ids):
-        rc = C.lib().mi_oov_siphash24_mod(C.ptr(ids), B, C.ptr(keys), K, mod, C.ptr(out), C.stream_of(ids))
+        rc = C.lib().mi_oov_siphash24_mod_ld(C.ptr(ids), B, C.ptr(keys), K, mod, C.ptr(out), out.shape[1], C.stream_of(ids))
     C.check(rc, "mi_oov_siphash24_mod")
     return out
 

@@ -238,6 +238,10 @@ int mi_oov_slsh_embed_multi(const int64_t* const* ids_tab, float* const* out_tab
 int mi_oov_siphash24_mod(const int64_t* ids, int64_t B,
                          const uint8_t* keys, int64_t K, uint32_t mod,
                          float* out, void* stream);
+/* the same into rows of ld >= K floats (out f32[B,ld], columns K .. ld untouched): fdhe writes its hashes straight into
+ * the [B, K + F (+ padding)] input of its net (feat_dh_embedder.py:164-172) instead of concatenating afterwards */
+int mi_oov_siphash24_mod_ld(const int64_t* ids, int64_t B, const uint8_t* keys, int64_t K, uint32_t mod,
+                            float* out, int64_t ld, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * random mapper: RandomOOVInductiveMapper (R/inductive/random_mapper.py:70-130).

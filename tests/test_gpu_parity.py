@@ -390,6 +390,22 @@ def test_linear_x3_persistent_stream_of_short_tiles(B, K, N_out, ops, dev, monke
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-5)
 
 
+def test_siphash_into_wider_rows(oracle, ops, dev):
+    """mi_oov_siphash24_mod_ld: the hashes written into the first K columns of wider rows (fdhe's net input), the other
+    columns untouched; the integers are those of the plain entry (pinned on the oracle and the reference's fixture)."""
+    rng = np.random.default_rng(4)
+    ids = T(rng.integers(0, 1 << 40, 777), dev)
+    keys = T(rng.integers(0, 256, (70, 16), dtype=np.uint8), dev)
+    plain = ops.siphash24_mod(ids, keys)
+    buf = torch.full((777, 96), -3.0, device=dev)
+    out = ops.siphash24_mod(ids, keys, out=buf)
+    assert out.data_ptr() == buf.data_ptr() and torch.equal(buf[:, :70], plain) and bool((buf[:, 70:] == -3.0).all())
+    assert np.array_equal(plain.cpu().numpy(), oracle.siphash24_mod(ids.cpu().numpy(), keys.cpu().numpy(), 16777216))
+    with pytest.raises(ValueError):
+        ops.siphash24_mod(ids, keys, out=torch.empty((777, 69), device=dev))
+    assert ops.C.lib().mi_oov_siphash24_mod_ld(None, 4, None, 8, 16777216, None, 7, None) == -2
+
+
 def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
     """Non-finite operands give non-finite results exactly where the f32 product does (NaN where that holds +-inf: the lower
     planes of an infinite value are inf - inf); the split weights follow the weight tensor's version counter."""
