@@ -392,7 +392,9 @@ class _HashKeyMixin:
         One SipHash launch, then the layers.  (Cutting the batch in chunks and hashing chunk c + 1 on a side stream under
         the layers of chunk c was built and measured in round 3: 1.71 ms serial against 1.94 / 2.07 / 2.16 / 3.04 ms with
         2 / 3 / 4 / 8 chunks at K = 1024, 65536 lookups -- the f32 matrix instruction issues at the vector rate, so the
-        integer hash and the GEMM compete for the same issue slots, and the smaller GEMMs fill the chip worse.)"""
+        integer hash and the GEMM compete for the same issue slots, and the smaller GEMMs fill the chip worse.  Again with
+        the split-bf16 layers: 1.18 ms serial, 1.26 / 1.42 with 2 / 4 chunks -- the pipelined layer kernel's two waves per
+        SIMD hold 496 of its 512 registers, so a hash wave only runs where a layer workgroup has left.)"""
         if extra is not None and not _needs_grad(net, extra) and ops._x3_wanted():
             # fdhe, inference: the hashes go straight into the net's input (rows of a multiple of 16 floats: what the
             # pipelined layer kernel takes), the feature columns beside them, zeros behind -- no concatenation and no
