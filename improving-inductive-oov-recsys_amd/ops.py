@@ -1023,6 +1023,8 @@ def linear_act_x3(X, W, bias, act=None, weights=None, ksplit=1):
     if (X.shape[1] != K and X.shape[1] != -(-K // 16) * 16) or bias.numel() != W.shape[0]:
         raise ValueError(f"shape mismatch: X {tuple(X.shape)}, W {tuple(W.shape)}, bias {tuple(bias.shape)}")
     split = (weights if weights is not None else LinearX3Weights(W)).get()
+    if split.numel() != int(C.lib().mi_oov_linear_x3_weights_bytes(W.shape[0], K)) or split.device != X.device:
+        raise ValueError("`weights` is not the split of a weight of this shape on this device")
     Y = torch.empty((X.shape[0], W.shape[0]), dtype=torch.float32, device=X.device)
     if ksplit > 1:  # (training shapes: `_gemm_nt`; the rounding depends on ksplit, so inference never takes this)
         ws = torch.empty((int(C.lib().mi_oov_linear_x3_splitk_workspace(X.shape[0], W.shape[0], ksplit)),), dtype=torch.uint8, device=X.device)
