@@ -406,6 +406,33 @@ def test_siphash_into_wider_rows(oracle, ops, dev):
     assert ops.C.lib().mi_oov_siphash24_mod_ld(None, 4, None, 8, 16777216, None, 7, None) == -2
 
 
+def test_linear_x3_random_shapes(ops, dev, monkeypatch):
+    """Thirty random (rows, K, N_out, activation) through every tile form the shape admits, against the bit-exact f32 kernel
+    (itself pinned on the oracle): the bound of test_linear_x3_vs_oracle, and all forms bit-identical to one another."""
+    rng = np.random.default_rng(2024)
+    g = torch.Generator(device=dev).manual_seed(7)
+    for _ in range(30):
+        B = int(rng.choice([1, 3, 64, 129, 700, 2049, 9000]))
+        K = int(rng.choice([1, 7, 16, 22, 32, 48, 100, 256, 1000, 1024]))
+        N_out = int(rng.choice([1, 5, 64, 65, 129, 300, 512, 777]))
+        act = [None, "gelu", "sigmoid"][int(rng.integers(0, 3))]
+        X = torch.rand((B, K), generator=g, device=dev) * 2 - 1
+        W = torch.randn((N_out, K), generator=g, device=dev) / K ** 0.5
+        b = torch.randn((N_out,), generator=g, device=dev)
+        den = X.abs() @ W.abs().T + b.abs()
+        pre = ops.linear_act(X, W, b, None)
+        outs = []
+        for form in ("0", "1", "2", "3", "4"):
+            monkeypatch.setenv("MI_OOV_X3_SHAPE", form)
+            outs.append(ops.linear_act_x3(X, W, b, None))
+            assert torch.equal(outs[-1], outs[0]), (B, K, N_out, form)
+            got = ops.linear_act_x3(X, W, b, act)
+            want = ops.linear_act(X, W, b, act)
+            assert bool(((got - want).abs() <= 10 * 2.0 ** -24 * den + 2e-6 * want.abs() + 1e-7).all()), (B, K, N_out, act, form)
+        assert bool(((outs[0] - pre).abs() <= 8 * 2.0 ** -24 * den).all()), (B, K, N_out)
+    monkeypatch.delenv("MI_OOV_X3_SHAPE")
+
+
 def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
     """Non-finite operands give non-finite results exactly where the f32 product does (NaN where that holds +-inf: the lower
     planes of an infinite value are inf - inf); the split weights follow the weight tensor's version counter."""
