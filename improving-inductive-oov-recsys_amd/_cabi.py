@@ -81,6 +81,8 @@ _SIGNATURES = {
     "mi_oov_act_backward": (ctypes.c_int, [_vp, _vp, _i64, ctypes.c_int, _vp, _vp]),
     "mi_oov_transpose": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp]),
     "mi_oov_score_topk_workspace": (_i64, [_i64, _i64, _i64]),
+    "mi_oov_score_topk_workspace_d": (_i64, [_i64, _i64, _i64, _i64]),
+    "mi_oov_score_topk_prepared_workspace": (_i64, [_i64, _i64, _i64, _i64, ctypes.c_int]),
     "mi_oov_score_topk": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
 }
 

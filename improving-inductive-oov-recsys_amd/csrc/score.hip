@@ -1909,7 +1909,7 @@ struct FusedLayout {
   int64_t NT, cap, stride, seg_width, off_tilemax, off_tau, off_tauf, off_u2, off_thr, off_eps, off_e2max, off_ub, off_eb, off_cnt, off_cand, bytes;
 };
 static int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
-static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16, int kh = 1) {
+static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16, int kh = 1, bool with_eb = true) {
   FusedLayout L;
   // Pass 1 only needs a LOWER bound of the k-th best score, and the k-th best of any subset of the columns is
   // one: it visits every `stride`-th 128-column block (1/stride of the GEMM work).  The filter pass then lets
@@ -1947,13 +1947,25 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16, int 
   L.off_e2max = align256(L.off_eps + B * 4);
   L.off_ub = align256(L.off_e2max + kNormGrid * 4);        // bf16 copies of U and E (64-column inputs only)
   L.off_eb = align256(L.off_ub + B * 128 * kh);  // kh = 64-k halves per row: 1 (D <= 64) or 2 (D <= 128)
-  L.off_cnt = align256(L.off_eb + eb_rows(N) * 128 * kh);
+  L.off_cnt = align256(L.off_eb + (with_eb ? eb_rows(N) * 128 * kh : 0));  // (a prepared catalogue brings its own bf16 copy of E)
   L.off_cand = align256(L.off_cnt + B * (128 + 1) * 4);  // f32 path: kSeg + 1 counters per row; bf16 path: <= 128 strips + 1
   L.bytes = align256(L.off_cand + B * (L.cap + kOvfCap) * 8);
   return L;
 }
 // The fused two-pass path needs at least 2k column tiles per row (tau is the k-th tile maximum).
 static bool use_fused_topk(int64_t N, int64_t k) { return k <= 256 && (N + 63) / 64 >= 2 * k; }
+
+// the same for a known row width: one k-half of bf16 copies for D <= 64 (the query below keeps room for two)
+extern "C" int64_t mi_oov_score_topk_workspace_d(int64_t B, int64_t N, int64_t D, int64_t k) {
+  if (B <= 0 || N <= 0 || D <= 0 || k <= 0) return 0;
+  if (use_fused_topk(N, k)) {
+    const int64_t b = fused_layout(B, N, k, false).bytes;
+    if (D > 128) return b;
+    const int64_t a = fused_layout(B, N, k, true, D > 64 ? 2 : 1).bytes;
+    return a > b ? a : b;
+  }
+  return topk_chunk_rows(B, N) * N * static_cast<int64_t>(sizeof(float));
+}
 
 extern "C" int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k) {
   if (B <= 0 || N <= 0 || k <= 0) return 0;
@@ -1993,7 +2005,7 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
     const bool use_bf16 = (bf16_path || mask || catalogue) && D <= 128 && ((D != 64 && D != 128) || vec);
     if ((mask || catalogue) && !use_bf16) return MI_OOV_ERR_ALIGN;  // (the entry points checked the shape; only alignment is left)
     const int kh = (use_bf16 && D > 64) ? 2 : 1;
-    const FusedLayout L = fused_layout(B, N, k, use_bf16, kh);
+    const FusedLayout L = fused_layout(B, N, k, use_bf16, kh, catalogue == nullptr);
     char* ws = static_cast<char*>(workspace);
     TopkArgs ta{};
     ta.tilemax = reinterpret_cast<uint32_t*>(ws + L.off_tilemax);
@@ -2214,8 +2226,16 @@ extern "C" int mi_oov_topk_catalogue_prepare(const float* E, int64_t N, int64_t 
   return check_launch();
 }
 
+// Workspace of a call against a prepared catalogue: the lists and the user rows' copies for THIS row width, no room for a
+// bf16 copy of E (the catalogue holds it) -- the general query keeps room for either path and two k-halves, which at
+// 10 M rows is 2.56 GB of copy and made the host cut a 4096-user batch into 32 chunks (round 3's D <= 128 change:
+// 16.4 ms instead of 6.4 for the knn search of BASELINE's table).  The mask, when there is one, sits behind it.
+static int64_t prepared_lists_bytes(int64_t B, int64_t N, int64_t D, int64_t k) {
+  return align256(fused_layout(B, N, k, true, D > 64 ? 2 : 1, false).bytes);
+}
+
 // mi_oov_score_topk (excl_ptr == NULL) or mi_oov_score_topk_masked (excl_ptr != NULL) against a prepared catalogue of
-// the same E; workspace as for the respective call.  Shapes the bf16 path does not take are an error here (a caller
+// the same E; workspace: mi_oov_score_topk_prepared_workspace (the respective call's, larger, is fine too).  Shapes the bf16 path does not take are an error here (a caller
 // that prepared a catalogue has a 64-column, aligned E).
 extern "C" int mi_oov_score_topk_prepared(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
                                           int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols,
@@ -2226,8 +2246,13 @@ extern "C" int mi_oov_score_topk_prepared(const float* U, int64_t B, const float
   if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0 || (reinterpret_cast<uintptr_t>(catalogue) & 15u) != 0 || !aligned16(U) || !aligned16(E))
     return MI_OOV_ERR_ALIGN;
   unsigned long long* mask = nullptr;
-  if (excl_ptr) mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + align256(mi_oov_score_topk_workspace(B, N, k)));
+  if (excl_ptr) mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + prepared_lists_bytes(B, N, D, k));
   return score_topk_impl(U, B, E, N, D, k, n_skip_low, excl_ptr, excl_cols, mask, catalogue, vals, idx, workspace, stream);
+}
+
+extern "C" int64_t mi_oov_score_topk_prepared_workspace(int64_t B, int64_t N, int64_t D, int64_t k, int masked) {
+  if (!masked_topk_supported(B, N, D, k)) return 0;
+  return prepared_lists_bytes(B, N, D, k) + (masked ? align256(B * ((N + 63) / 64) * 8) : 0);
 }
 
 // ---- full-sort evaluation with per-user exclusions (history masks) ---------------------------------------------

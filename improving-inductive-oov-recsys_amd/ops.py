@@ -1230,8 +1230,7 @@ def _prepared_call(U, cat, k, n_skip_low, excl_ptr, excl_cols, vals, idx):
     """One mi_oov_score_topk_prepared launch; returns False when the shape is not one the fused bf16 path takes."""
     lib = C.lib()
     B, N, D = U.shape[0], cat.E.shape[0], U.shape[1]
-    need = int(lib.mi_oov_score_topk_masked_workspace(B, N, D, k)) if excl_ptr is not None else \
-        (int(lib.mi_oov_score_topk_workspace(B, N, k)) if int(lib.mi_oov_score_topk_masked_workspace(B, N, D, k)) > 0 else 0)
+    need = int(lib.mi_oov_score_topk_prepared_workspace(B, N, D, k, 1 if excl_ptr is not None else 0))
     if need <= 0 or (D in (64, 128) and U.data_ptr() % 16):
         return False
     ws = torch.empty((need,), dtype=torch.uint8, device=U.device)
@@ -1255,15 +1254,19 @@ def score_topk(U, E, k, n_skip_low=0):
     vals = torch.empty((B, k), dtype=torch.float32, device=U.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=U.device)
     lib = C.lib()
-    if cat is not None and B > 0 and lib.mi_oov_score_topk_workspace(B, N, k) <= _TOPK_WORKSPACE_MAX_BYTES \
+    def ws_bytes(rows):  # a prepared catalogue holds the bf16 copy of E: its calls need the lists only
+        need = int(lib.mi_oov_score_topk_prepared_workspace(rows, N, D, k, 0)) if cat is not None else 0
+        return need if need > 0 else int(lib.mi_oov_score_topk_workspace_d(rows, N, D, k))
+
+    if cat is not None and B > 0 and ws_bytes(B) <= _TOPK_WORKSPACE_MAX_BYTES \
             and _prepared_call(U, cat, k, n_skip_low, None, None, vals, idx):
         return vals, idx
     # the fused path's workspace grows with B x N (tile maxima, candidate lists): a 10 M-row catalogue is ~165 KB per
     # user, so big batches go through in chunks of users (multiples of the 128-row tile)
     rows = B
-    while rows > 128 and lib.mi_oov_score_topk_workspace(rows, N, k) > _TOPK_WORKSPACE_MAX_BYTES:
+    while rows > 128 and ws_bytes(rows) > _TOPK_WORKSPACE_MAX_BYTES:
         rows = max(128, (rows // 2 + 127) // 128 * 128)
-    ws = torch.empty((max(16, int(lib.mi_oov_score_topk_workspace(min(rows, B), N, k))),), dtype=torch.uint8, device=U.device)
+    ws = torch.empty((max(16, int(lib.mi_oov_score_topk_workspace_d(min(rows, B), N, D, k))),), dtype=torch.uint8, device=U.device)
     with C.on_device(U):
         for b0 in range(0, max(B, 1), max(rows, 1)):
             nb = min(rows, B - b0)
@@ -1337,7 +1340,8 @@ def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
         excl_cols = torch.zeros((1,), dtype=torch.int64, device=U.device)
     lib = C.lib()
     # histories of any length, one call, no host sync: exclusion bitmap applied inside the fused kernel (D = 64)
-    need = int(lib.mi_oov_score_topk_masked_workspace(B, N, U.shape[1], k))
+    need = int(lib.mi_oov_score_topk_prepared_workspace(B, N, U.shape[1], k, 1)) if cat is not None else \
+        int(lib.mi_oov_score_topk_masked_workspace(B, N, U.shape[1], k))
     if _USE_MASKED_TOPK and 0 < need <= _MASKED_TOPK_MAX_BYTES and U.data_ptr() % 16 == 0 and E.data_ptr() % 16 == 0:
         if cat is not None and _prepared_call(U, cat, k, n_skip_low, excl_ptr, excl_cols, vals, idx):
             return vals, idx

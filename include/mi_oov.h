@@ -398,6 +398,9 @@ int mi_oov_transpose(const float* A, int64_t R, int64_t C, float* At, void* stre
  *   n_skip_low: columns [0, n_skip_low) are excluded (the evaluator masks padding item 0).
  *   workspace: mi_oov_score_topk_workspace(B,N,k) bytes.                               */
 int64_t mi_oov_score_topk_workspace(int64_t B, int64_t N, int64_t k);
+/* the same for a known row width D (<= 64: one k-half of bf16 copies instead of the two the query above keeps room for;
+ * at 10 M rows the difference is 1.28 GB) -- sufficient for mi_oov_score_topk with that D */
+int64_t mi_oov_score_topk_workspace_d(int64_t B, int64_t N, int64_t D, int64_t k);
 int mi_oov_score_topk(const float* U, int64_t B, const float* E, int64_t N, int64_t D,
                       int64_t k, int64_t n_skip_low,
                       float* vals, int64_t* idx, void* workspace, void* stream);
@@ -453,6 +456,10 @@ int mi_oov_topk_catalogue_prepare(const float* E, int64_t N, int64_t D, void* ca
 int mi_oov_score_topk_prepared(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
                                int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols,
                                const void* catalogue, float* vals, int64_t* idx, void* workspace, void* stream);
+/* bytes of workspace for mi_oov_score_topk_prepared (masked: with an exclusion list): the lists for this row width only
+ * -- the catalogue holds the bf16 copy of E, so a 10 M-row search of 4096 users fits one call (0 where the shape is not
+ * taken, as mi_oov_score_topk_masked_workspace) */
+int64_t mi_oov_score_topk_prepared_workspace(int64_t B, int64_t N, int64_t D, int64_t k, int masked);
 
 #ifdef __cplusplus
 }

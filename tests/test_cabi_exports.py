@@ -76,6 +76,10 @@ def test_argument_validation_of_the_widened_entry_points(lib):
     assert lib.mi_oov_topk_catalogue_prepare(None, 50_000, 129, None, None) == -2
     assert lib.mi_oov_topk_catalogue_prepare(None, 50_000, 64, None, None) == -1
     assert lib.mi_oov_score_topk_prepared(None, 4, None, 50_000, 64, 20, 0, None, None, None, None, None, None, None) == -1
+    pw = lib.mi_oov_score_topk_prepared_workspace(4096, 10_000_000, 64, 2, 0)                 # lists only: the catalogue holds the bf16 copy of E
+    assert 0 < pw < (2 << 30) < lib.mi_oov_score_topk_workspace(4096, 10_000_000, 2) and pw < lib.mi_oov_score_topk_prepared_workspace(4096, 10_000_000, 64, 2, 1)
+    assert lib.mi_oov_score_topk_workspace_d(4096, 10_000_000, 64, 2) < (2 << 30) < lib.mi_oov_score_topk_workspace_d(4096, 10_000_000, 128, 2) == lib.mi_oov_score_topk_workspace(4096, 10_000_000, 2)  # one / two k-halves of E's copy: the host's 2 GiB chunking threshold lies between
+    assert lib.mi_oov_score_topk_prepared_workspace(4096, 1000, 64, 20, 0) == 0 and lib.mi_oov_score_topk_prepared_workspace(4096, 50_000, 129, 20, 0) == 0
     assert lib.mi_oov_score_topk_prepared(None, 4, None, 1000, 64, 20, 0, None, None, None, None, None, None, None) == -2
     assert lib.mi_oov_linear_act(None, 4, 16, None, None, 8, 7, None, None) in (-2, -3)       # unknown activation
     assert lib.mi_oov_linear_x3_weights_bytes(512, 1024) == 64 * 512 * 96                     # [K/16][N -> 256s][3 planes x 32 B]

@@ -194,7 +194,7 @@ def main():
         Ebig = torch.randn(10_000_000, D, device=dev)
         catB = ops.TopkCatalogue(Ebig)
         cases["score_topk prepared k=2 B=4096 N=10000000"] = (lambda i: ops.score_topk(U, catB, 2, 1), Bs * 10_000_000, 0, 2 * D)
-        cases["score_topk unprepared k=2 B=4096 N=10000000"] = (lambda i: ops.score_topk(U, Ebig, 2, 1), Bs * 10_000_000, 0, 2 * D)
+        cases["score_topk prepared: the same without preparing, k=2 B=4096 N=10000000"] = (lambda i: ops.score_topk(U, Ebig, 2, 1), Bs * 10_000_000, 0, 2 * D)
     if args.only.startswith("score_topk degenerate"):  # every row ties everywhere: all rows take the exact fallback
         Uz = torch.zeros(512, D, device=dev)
         cases["score_topk degenerate (512 zero user rows, N=50000, k=20: exact fallback for every row)"] = (lambda i: ops.score_topk(Uz, E, 20, 1), 512 * Ns, 0, 2 * D)
