@@ -76,16 +76,19 @@ __global__ __launch_bounds__(kBlock) void row_copy_kernel(const void* __restrict
 }
 
 // out[o,:] = mean_{t in [o*g, min(M,(o+1)*g))} W[idx[t],:], summed in increasing t.
-// G2: the reference's g = 2 (knn_embedder.py:126,147) with both rows of an output, and the pairs of FOUR outputs per
-// 16-lane group, requested together (8 gathers in flight per lane instead of one at a time) -- same sums, same order.
+// G2: the reference's g = 2 (knn_embedder.py:126,147) with both rows of an output, and the pairs of R outputs per
+// 16-lane group, requested together (2 R gathers in flight per lane instead of one at a time) -- same sums, same order.
 // TAB: idx_src / out_src are DEVICE arrays of K pointers, one per queued batch of M indices (mi_oov_gather_mean_multi).
+#ifndef MI_GM_R
+#define MI_GM_R 2  // outputs per 16-lane group of a SINGLE launch: 65536 outputs in 11.8 us with 2 (and with 1), 12.8 with 4 -- a lone launch wants its 2048 workgroups more than deeper gathers per lane; the queued form keeps 4
+#endif
 template <bool VEC, bool G2, bool TAB = false>
 __global__ __launch_bounds__(kBlock) void gather_mean_kernel(const void* __restrict__ idx_src, int64_t M, int64_t g,
                                                              const float* __restrict__ W, int64_t N, int64_t D,
                                                              void* __restrict__ out_src, int64_t K) {
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
   const int64_t nout = (M + g - 1) / g;
-  constexpr int R = G2 ? 4 : 1;  // outputs per 16-lane group and tile
+  constexpr int R = G2 ? (TAB ? 4 : MI_GM_R) : 1;  // outputs per 16-lane group and tile
   const int64_t tpb = (nout + 4 * R - 1) / (4 * R);
   const int64_t ntiles = tpb * (TAB ? K : 1);
   const int dchunks = static_cast<int>((D + 63) / 64);
@@ -687,7 +690,7 @@ extern "C" int mi_oov_gather_mean(const int64_t* idx, int64_t M, int64_t g, cons
   const bool vec = (D % 4 == 0) && aligned16(W) && aligned16(out);
   const int64_t nout = (M + g - 1) / g;
   if (g == 2) {  // the reference's group size: four outputs per 16-lane group, their 8 gathers in flight together
-    const int grid = grid_for(nout, 64);
+    const int grid = grid_for(nout, 16 * MI_GM_R);
     if (vec)
       hipLaunchKernelGGL((gather_mean_kernel<true, true>), dim3(grid), dim3(kBlock), 0, st, idx, M, g, W, N, D, out, 1);
     else
