@@ -629,7 +629,10 @@ extern "C" int mi_oov_linear_x3(const float* X, int64_t B, int64_t K, const void
     }
   }
   // narrow outputs (the last layer of the nets, 64 wide): a 128 x 64 tile; otherwise 128 x 256
-  if (N_out <= 64 && shape == 0) return launch_x3_act<2, 2, 1>(X, B, K, wsplit, bias, N_out, act, Y, st);
+  // ... and 128 x 64 ones when even the 128 x 128 tiles would leave three CUs in four idle (1024 rows x 1024 -> 512: 51 us
+  // against 58; a small batch is bound by the serial walk of a tile over K, not by its matrix instructions)
+  const int64_t tiles128 = ((B + 127) / 128) * ((N_out + 127) / 128);
+  if ((N_out <= 64 || tiles128 <= l3_cus() / 4) && shape == 0) return launch_x3_act<2, 2, 1>(X, B, K, wsplit, bias, N_out, act, Y, st);
   if ((N_out <= 128 || tiles256 <= l3_cus() / 2) && shape == 0) return launch_x3_act<2, 2, 2>(X, B, K, wsplit, bias, N_out, act, Y, st);
   switch (shape) {
     case 1: return launch_x3_act<2, 2, 2>(X, B, K, wsplit, bias, N_out, act, Y, st);
