@@ -433,6 +433,28 @@ def test_linear_x3_random_shapes(ops, dev, monkeypatch):
     monkeypatch.delenv("MI_OOV_X3_SHAPE")
 
 
+def test_linear_x3_split_is_exact(ops, dev):
+    """The three bf16 planes mi_oov_linear_x3_prepare makes add up to the f32 weight EXACTLY (each the round-to-nearest bf16
+    of what the ones before it left: 3 x 8 significand bits), from the plain and from the transposed source; rows beyond
+    N_out and columns beyond K are zero.  Decoded on the CPU from the split's documented layout [K/16][N -> 256s][3][16]."""
+    rng = np.random.default_rng(11)
+    N_out, K = 70, 50
+    W = (rng.standard_normal((N_out, K)) * 10.0 ** rng.integers(-20, 20, (N_out, K))).astype(np.float32)
+    W[0, :4] = [0.0, -0.0, 1.0, -3.0e38]
+    Wt = T(W, dev)
+    for transposed in (False, True):
+        src = Wt.t().contiguous() if transposed else Wt
+        raw = ops.LinearX3Weights(src, transposed=transposed).get().cpu().numpy()
+        chunks, Np = -(-K // 16), 256
+        planes = raw.view(np.uint16).reshape(chunks, Np, 3, 16).astype(np.uint32) << 16
+        planes = planes.view(np.float32)                                   # bf16 -> f32: exact
+        total = (planes[:, :, 0] + planes[:, :, 1]) + planes[:, :, 2]        # h + m exact in f32, + l exact
+        full = total.transpose(1, 0, 2).reshape(Np, chunks * 16)            # [n, k]
+        assert np.array_equal(full[:N_out, :K], W), transposed  # (value equality: the planes of -0 are -0, +0, +0)
+        assert not full[N_out:].any() and not full[:, K:].any()
+        assert np.all(np.abs(planes[:, :N_out, 1]) <= np.abs(planes[:, :N_out, 0]) * 2.0 ** -8 + 1e-45)  # m below half an ulp of h
+
+
 def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
     """Non-finite operands give non-finite results exactly where the f32 product does (NaN where that holds +-inf: the lower
     planes of an infinite value are inf - inf); the split weights follow the weight tensor's version counter."""
