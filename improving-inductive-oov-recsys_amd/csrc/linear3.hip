@@ -7,9 +7,9 @@
 // f32 operand is held as THREE bf16 values h + m + l (round-to-nearest pieces of the running remainder: 3 x 8 = 24
 // significand bits, so h + m + l is the f32 value exactly) and six of the nine cross products are accumulated in f32 --
 // l*h, h*l, m*m, m*h, h*m, h*h; the three left out (m*l, l*m, l*l) are below 2^-24 of |x||w| each.  Every bf16 x bf16
-// product is exact in f32, so the result differs from the exact dot product by the accumulator's roundings only, like
-// the f32 chain's (measured against f64: the same error as the f32 kernel's or smaller,
-// tests/test_gpu_parity.py::test_linear_x3_*).  It is NOT the oracle's summation order: parity is within a tolerance
+// product is exact in f32, so what is lost is lost in the matrix instruction's own accumulation (not a single rounding
+// of the exact 32-term sum: a CPU model of that does not reproduce its bits) -- measured against f64 the same error
+// as the f32 kernel's or smaller (tests/test_gpu_parity.py::test_linear_x3_*).  It is NOT the oracle's summation order: parity is within a tolerance
 // written in the test, not bit for bit -- mi_oov_linear_act stays the bit-exact form (MI_OOV_LINEAR_X3=0 on the host).
 //
 // The arithmetic, shared by both kernels of this file (they agree bit for bit): v_mfma_f32_16x16x32_bf16 with TWO planes
