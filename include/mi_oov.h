@@ -348,9 +348,10 @@ int mi_oov_linear_act(const float* X, int64_t B, int64_t K, const float* W, cons
 /* The same layer on the bf16 matrix cores at f32 accuracy (csrc/linear3.hip; what the hash nets run on,
  * dh_embedder.py:140-170 -> 70-89).  Every f32 operand is held as three bf16 values h + m + l (= the f32 value exactly)
  * and six of the nine cross products are accumulated in f32 on v_mfma_f32_16x16x32_bf16 (two planes side by side in
- * the instruction's 32 k); the three left out are below 2^-24 |x||w| each.  Error against the exact dot product: that of an f32 accumulation (not larger than the f32 chain's
- * of mi_oov_linear_act, measured), but NOT the oracle's summation order -- parity is within the tolerance written in
- * tests/test_gpu_parity.py::test_linear_x3_vs_oracle, not bit for bit.  Finite operands only: where an
+ * the instruction's 32 k); the three left out are below 2^-24 |x||w| each.  Error against the exact dot product: that of an f32 accumulation -- measured not larger than the
+ * f32 chain's of mi_oov_linear_act on zero-mean, same-sign and wide-range operands -- but NOT the
+ * oracle's summation order: parity is within the tolerances written in tests/test_gpu_parity.py::test_linear_x3_*
+ * (8 * 2^-24 * (sum|x||w| + |b|) against the oracle on zero-mean operands), not bit for bit.  Finite operands only: where an
  * operand is infinite, NaN or above the largest bf16 (3.39e38) the result is NaN (the f32 product: +-inf or NaN).
  *   mi_oov_linear_x3_weights_bytes(N_out, K)   bytes of the split weights (three planes, rows padded to 256, K to 16)
  *   mi_oov_linear_x3_prepare(W, N_out, K, wsplit, stream)     W f32[N_out,K] -> wsplit (16-byte aligned); once per
