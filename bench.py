@@ -67,6 +67,9 @@ def parse():
                     help="developer: run the sharded path at N = 1 too (one-rank RCCL group, self-exchange) to time its kernels")
     ap.add_argument("--local-fast", action="store_true",
                     help="--table sharded: lookups a rank owns itself skip the exchange (fused kernel on the local block)")
+    ap.add_argument("--sustained-steps", type=int, default=640,
+                    help="--table sharded: also time this many steps in one go (exchanges overlapping) and report them under "
+                         "sharded.sustained; 0 = skip")
     ap.add_argument("--cap-factor", type=float, default=1.0,
                     help="--table sharded: segment capacity = this multiple of the expected share of an exchange + 8 "
                          "standard deviations (ids are uniform; the run fails loudly if a segment ever overflows)")
@@ -310,11 +313,17 @@ def main():
                 # has settled earlier would otherwise go on to the warm-up exchange while another repeats the ramp's
                 if reduce_max(0.0 if done else 1.0) == 0.0:
                     break
-            region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             if W:
                 run_steps(n_ramp, W)
+            return timed_steps(run_steps, n_ramp + W, K)
+
+    def timed_steps(run_steps, i0, n):
+        """fence -> n steps between two HIP events on the launch stream -> fence; (host seconds, event ms, launches), each
+        the max over the ranks."""
+        with torch.no_grad():
+            region = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             # first use of an event creates it (~40 us) and the first query / synchronize after one is slower too
-            # (tools/region_cost.py): done here, untimed, so that the K steps are what the region holds
+            # (tools/region_cost.py): done here, untimed, so that the n steps are what the region holds
             region[0].record()
             region[1].record()
             while not region[1].query():
@@ -322,7 +331,7 @@ def main():
             fence()
             t0 = time.perf_counter()
             region[0].record()
-            launches = run_steps(n_ramp + W, K)
+            launches = run_steps(i0, n)
             region[1].record()
             if not args.no_spin:
                 # poll the end event instead of sleeping in hipDeviceSynchronize: a blocking wait wakes up tens of us
@@ -430,11 +439,37 @@ def main():
 
         elapsed_s, region_ms, n_blocks = time_region(run_steps)
         torch.cuda.synchronize()
+        last = n_ramp + W + K - 1
+        kept = scores[(last - n_ramp) % ring].clone()  # the last timed batch's scores: compared with the unsharded kernel below
+        # A 20-step run is ONE exchange (a serial chain, nothing overlaps); the sustained figure is what the pipeline
+        # delivers when exchanges overlap: `--sustained-steps` (>= 640) steps on id batches of their own, same user-row ring.
+        sustained = None
+        n_sus = int(args.sustained_steps)
+        if n_sus > 0 and n_sus != K:
+            g2 = torch.Generator(device=dev)
+            g2.manual_seed(5 + 1000 * rank)
+            sus_ids = torch.randint(0, N, (n_sus * B,), generator=g2, device=dev)
+
+            def run_sus(i0, n):
+                bl, done = [], 0
+                while done < n:
+                    sc0 = done % ring
+                    take = min(n - done, S, ring - sc0)
+                    bl.append((sus_ids[done * B:(done + take) * B], ring_rows[sc0 * B:(sc0 + take) * B], ring_scores[sc0 * B:(sc0 + take) * B]))
+                    done += take
+                pipe.run([b[0] for b in bl], [b[1] for b in bl], [b[2] for b in bl])
+                return len(bl)
+            run_sus(0, min(n_sus, 2 * S))  # untimed: first use of these buffers
+            s_el, s_ms, s_blocks = timed_steps(run_sus, 0, n_sus)
+            sustained = {"steps": n_sus, "value": world * B * n_sus / s_el, "ms_per_step": 1e3 * s_el / n_sus,
+                         "us_per_step_hip_events": s_ms * 1e3 / n_sus, "exchanges": s_blocks}
+            del sus_ids
+        torch.cuda.synchronize()
         dropped = reduce_max(float(table.overflow.item()))  # every rank learns of an overflow on any rank
         if dropped:
             raise RuntimeError(f"--cap-factor {args.cap_factor} too tight: a segment overflowed by {int(dropped)} lookups")
         if rank != 0:
-            return {}
+            return {"kept_scores": kept}
         # The three kernels of an exchange (bucketing of step t+2, owner of step t, requester of step t-1) run on three
         # streams at once and share HBM, so no kernel has a duration of its own: the roofline object is the whole step --
         # algorithmic bytes of all three per lookup over the HIP-event time of the region.
@@ -454,20 +489,38 @@ def main():
                 "detail": {"steps_per_exchange": S, "exchanges": n_blocks, "segment_capacity": table.capacity(min(S, K) * B),
                            "cap_factor": args.cap_factor, "bytes_on_wire_per_lookup": 8 + H, "local_fast": bool(args.local_fast),
                            "region_ms_hip_events": region_ms, "us_per_step_hip_events": region_ms * 1e3 / K,
-                           "overflowed_lookups": 0}}
+                           "overflowed_lookups": 0, "sustained": sustained},
+                "kept_scores": kept}
 
     sharded_line = None
     if (world > 1 or args.force_sharded) and args.table == "sharded":
-        try:
-            sharded_line = sharded_runner()
-        except Exception as e:  # noqa: BLE001 -- the replicated line is still worth printing
-            import traceback
-            sharded_line = {"error": f"{type(e).__name__}: {e}", "where": traceback.format_exc().splitlines()[-3:]}
+        # A failure of the sharded runner is FATAL (non-zero exit on this rank; the launcher ends the others): the line's
+        # `value` at N > 1 is the sharded figure, and printing the replicated one in its place would report the wrong mode.
+        sharded_line = sharded_runner()
         torch.cuda.empty_cache()
 
     feat, planes, buckets = make_inputs(args, dev, N)
     run_steps, kernel, entry = replicated_runner(feat, planes, buckets)
     elapsed_s, region_ms, launches = time_region(run_steps)
+
+    # ---- after the timed region: the LAST timed batch's scores against ONE single-batch launch of mi_oov_lsh_embed_score
+    # (csrc/lsh64.hip: another kernel, the same arithmetic) on the same ids and user rows -- bit for bit (NaN = NaN).  A run
+    # whose timed output is wrong exits non-zero instead of printing a line.
+    torch.cuda.synchronize()
+    last = n_ramp + W + K - 1
+    got = scores[(last - n_ramp) % ring]
+    want = ops.lsh_embed_score(all_ids[last], feat, planes, buckets, user_of(last))
+    torch.cuda.synchronize()
+
+    def same_bits(a, b):
+        return bool((((a == b) | (torch.isnan(a) & torch.isnan(b))).all()).item())
+    checked = {"batch": last - n_ramp - W, "lookups": B, "against": "mi_oov_lsh_embed_score (single-batch kernel), bit for bit",
+               "ok": same_bits(got, want), "nan_scores": int(torch.isnan(want).sum().item())}
+    if sharded_line is not None:
+        checked["sharded_ok"] = same_bits(sharded_line.pop("kept_scores"), want)
+    bad = 0.0 if (checked["ok"] and checked.get("sharded_ok", True)) else 1.0
+    if reduce_max(bad) != 0.0:
+        raise SystemExit(f"bench.py rank {rank}: the timed region's scores differ from the single-batch kernel's: {checked}")
 
     if rank == 0:
         launch_us = region_ms * 1e3 / max(1, launches)
@@ -505,8 +558,10 @@ def main():
                        "user_row_ring_bytes": ring * B * D * 4, "ranks": world,
                        "backend": None if world == 1 else ("rccl" if args.dist_backend == "nccl" else args.dist_backend)},
             "roofline": roofline,
+            "checked": True,
+            "check": checked,
         }
-        if sharded_line is not None and "error" not in sharded_line:
+        if sharded_line is not None:
             # N > 1 headline = the row-sharded table north_star specifies; the replicated figure stays beside it
             out["replicated"] = {"value": rep_value, "ms_per_step": out["ms_per_step"], "roofline": roofline,
                                  "table": "replicated per GPU, no data-path collective"}
@@ -517,8 +572,6 @@ def main():
             out["config"]["launch_mode"] = sharded_line["launch_mode"]
             out["roofline"] = sharded_line["roofline"]
             out["sharded"] = sharded_line.get("detail")
-        elif sharded_line is not None:
-            out["sharded"] = sharded_line
         if world == 1 and mode == "multi" and F == 64 and D == 64 and H <= 8 and not args.no_also:
             out["also"] = also_rows_stored(args, ops, feat, planes, buckets, all_ids, n_ramp, dev)
         if world == 1 and not args.no_cpu_baseline:
