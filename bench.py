@@ -514,6 +514,8 @@ def main():
 
     def same_bits(a, b):
         return bool((((a == b) | (torch.isnan(a) & torch.isnan(b))).all()).item())
+    if mode == "unfused":  # the two-launch mode keeps no scores (a developer comparison, never the headline): re-run its last step
+        got = ops.rowdot(user_of(last), ops.lsh_embed(all_ids[last], feat, planes, buckets))
     checked = {"batch": last - n_ramp - W, "lookups": B, "against": "mi_oov_lsh_embed_score (single-batch kernel), bit for bit",
                "ok": same_bits(got, want), "nan_scores": int(torch.isnan(want).sum().item())}
     if sharded_line is not None:

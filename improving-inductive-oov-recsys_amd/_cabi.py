@@ -39,6 +39,11 @@ _SIGNATURES = {
     "mi_oov_score_topk_prepared": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_segment_topk": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_topk_hits": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mi_oov_topk_hits_range": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "mi_oov_eval_rows_build": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mi_oov_segment_dedup": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "mi_oov_score_topk_excl_dense_workspace": (_i64, [_i64, _i64]),
+    "mi_oov_score_topk_excl_dense": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_slsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_scatter_add_rows": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp]),
     "mi_oov_lsh_embed_score": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),

@@ -18,6 +18,7 @@ extern "C" const char* mi_oov_strerror(int code) {
     case MI_OOV_ERR_LAUNCH: return "HIP launch failed (see mi_oov_last_hip_error)";
     case MI_OOV_ERR_ALIGN: return "pointer is not aligned as documented";
     case MI_OOV_ERR_WORKSPACE: return "workspace too small";
+    case MI_OOV_ERR_ALIAS: return "an output buffer is also an input";
     default: return "unknown error code";
   }
 }

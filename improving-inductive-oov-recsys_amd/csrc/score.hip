@@ -342,18 +342,22 @@ __device__ __forceinline__ uint64_t u64_max(uint64_t a, uint64_t b) { return a >
 
 // One workgroup per row; k selection passes, each a max-reduction of (key<<32 | ~col) over the
 // candidates strictly below the previous winner.
+// `mask` (optional): row r's exclusion bits at mask + r * mask_words; an excluded column is never a candidate.
 __global__ __launch_bounds__(kBlock) void topk_rows_kernel(const float* __restrict__ S, int64_t rows, int64_t N,
                                                            int64_t ldS, int64_t k, int64_t n_skip_low,
-                                                           float* __restrict__ vals, int64_t* __restrict__ idx) {
+                                                           float* __restrict__ vals, int64_t* __restrict__ idx,
+                                                           const uint64_t* __restrict__ mask = nullptr, int64_t mask_words = 0) {
   __shared__ uint64_t red[kBlock / 64];
   __shared__ uint64_t winner;
   const int64_t row = blockIdx.x;
   if (row >= rows) return;
   const float* srow = S + row * ldS;
+  const uint64_t* mrow = mask ? mask + row * mask_words : nullptr;
   uint64_t prev = ~0ULL;
   for (int64_t t = 0; t < k; ++t) {
     uint64_t best = 0;
     for (int64_t c = n_skip_low + threadIdx.x; c < N; c += kBlock) {
+      if (mrow && ((mrow[c >> 6] >> (c & 63)) & 1ull)) continue;
       const uint64_t cand = (static_cast<uint64_t>(order_key(srow[c])) << 32) |
                             (0xFFFFFFFFu - static_cast<uint32_t>(c));
       if (t == 0 || cand < prev) best = u64_max(best, cand);
@@ -572,6 +576,26 @@ __global__ __launch_bounds__(kBlock) void topk_select_kernel(const float* __rest
   const int64_t row = blockIdx.x;
   if (row >= rows) return;
   select_topk_row(MatKeys{S + row * ldS}, N, k, n_skip_low, vals + row * k, idx + row * k);
+}
+
+// ... with a row of exclusion bits (the route of last resort of mi_oov_score_topk_excl_dense): excluded columns rank below
+// every real key and are blanked afterwards, as in the fused path's exact fallback
+__global__ __launch_bounds__(kBlock) void topk_select_masked_kernel(const float* __restrict__ S, int64_t rows, int64_t N,
+                                                                    int64_t ldS, int k, int64_t n_skip_low,
+                                                                    const uint64_t* __restrict__ mask, int64_t mask_words,
+                                                                    float* __restrict__ vals, int64_t* __restrict__ idx) {
+  const int64_t row = blockIdx.x;
+  if (row >= rows) return;
+  const uint64_t* mrow = mask + row * mask_words;
+  select_topk_row(MaskedKeys<MatKeys>{MatKeys{S + row * ldS}, mrow}, N, k, n_skip_low, vals + row * k, idx + row * k);
+  __syncthreads();
+  for (int t = threadIdx.x; t < k; t += kBlock) {
+    const int64_t c = idx[row * k + t];
+    if (c >= 0 && ((mrow[c >> 6] >> (c & 63)) & 1ull)) {
+      idx[row * k + t] = -1;
+      vals[row * k + t] = -__builtin_inff();
+    }
+  }
 }
 
 // fused path, between the two GEMM passes: tau[row] = k-th best of the row's tile maxima
@@ -914,9 +938,12 @@ __global__ __launch_bounds__(kBlock) void segment_topk_wave_kernel(const float* 
 
 // rec.topk of the reference collector: out[s, j] = 1 when the j-th recommended column of segment s is one of its
 // positives, out[s, k] = number of positives (collector.py:161-166); positives are CSR (pos_ptr, pos_cols).
+// RANGE: only positives with col_lo <= column < col_hi count (the old-item / new-item slices of the filtered collectors).
+template <bool RANGE>
 __global__ __launch_bounds__(kBlock) void topk_hits_kernel(const int64_t* __restrict__ idx, int64_t S, int k,
                                                            const int64_t* __restrict__ pos_ptr,
-                                                           const int64_t* __restrict__ pos_cols, int* __restrict__ out) {
+                                                           const int64_t* __restrict__ pos_cols, int64_t col_lo, int64_t col_hi,
+                                                           int* __restrict__ out) {
   const int64_t total = S * (k + 1);
   for (int64_t i = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; i < total;
        i += static_cast<int64_t>(gridDim.x) * kBlock) {
@@ -924,12 +951,18 @@ __global__ __launch_bounds__(kBlock) void topk_hits_kernel(const int64_t* __rest
     const int j = static_cast<int>(i % (k + 1));
     const int64_t p0 = pos_ptr[s], p1 = pos_ptr[s + 1];
     if (j == k) {
-      out[i] = static_cast<int>(p1 - p0);
+      if (RANGE) {
+        int n = 0;
+        for (int64_t q = p0; q < p1; ++q) n += (pos_cols[q] >= col_lo && pos_cols[q] < col_hi) ? 1 : 0;
+        out[i] = n;
+      } else {
+        out[i] = static_cast<int>(p1 - p0);
+      }
     } else {
       const int64_t c = idx[s * k + j];
       int hit = 0;
       for (int64_t q = p0; q < p1; ++q) hit |= (pos_cols[q] == c) ? 1 : 0;
-      out[i] = (c >= 0) ? hit : 0;
+      out[i] = (c >= 0 && (!RANGE || (c >= col_lo && c < col_hi))) ? hit : 0;
     }
   }
 }
@@ -952,14 +985,23 @@ extern "C" int mi_oov_segment_topk(const float* scores, const int64_t* cols, con
   return check_launch();
 }
 
-extern "C" int mi_oov_topk_hits(const int64_t* idx, int64_t S, int64_t k, const int64_t* pos_ptr, const int64_t* pos_cols,
-                                int32_t* out, void* stream) {
+extern "C" int mi_oov_topk_hits_range(const int64_t* idx, int64_t S, int64_t k, const int64_t* pos_ptr, const int64_t* pos_cols,
+                                      int64_t col_lo, int64_t col_hi, int32_t* out, void* stream) {
   if (S < 0 || k <= 0) return MI_OOV_ERR_SHAPE;
   if (S == 0) return MI_OOV_OK;
   if (!idx || !pos_ptr || !pos_cols || !out) return MI_OOV_ERR_NULL;
-  hipLaunchKernelGGL(topk_hits_kernel, dim3(grid_for(S * (k + 1), kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), idx,
-                     S, static_cast<int>(k), pos_ptr, pos_cols, out);
+  if (col_lo <= 0 && col_hi >= (1LL << 62))
+    hipLaunchKernelGGL(topk_hits_kernel<false>, dim3(grid_for(S * (k + 1), kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), idx,
+                       S, static_cast<int>(k), pos_ptr, pos_cols, col_lo, col_hi, out);
+  else
+    hipLaunchKernelGGL(topk_hits_kernel<true>, dim3(grid_for(S * (k + 1), kBlock)), dim3(kBlock), 0, static_cast<hipStream_t>(stream), idx,
+                       S, static_cast<int>(k), pos_ptr, pos_cols, col_lo, col_hi, out);
   return check_launch();
+}
+
+extern "C" int mi_oov_topk_hits(const int64_t* idx, int64_t S, int64_t k, const int64_t* pos_ptr, const int64_t* pos_cols,
+                                int32_t* out, void* stream) {
+  return mi_oov_topk_hits_range(idx, S, k, pos_ptr, pos_cols, 0, 1LL << 62, out, stream);
 }
 
 // ---- bf16 prefilter: both GEMM passes of the fused top-k (D = 64) ---------------------------------------------------------
@@ -2320,3 +2362,41 @@ extern "C" int mi_oov_score_topk_excl(const float* U, int64_t B, const float* E,
   return check_launch();
 }
 
+// ---- the route of last resort: any D, any k, any history length, any catalogue size -----------------------------------------
+// Scores of a chunk of users materialised (<= 1 GiB), the chunk's exclusion bitmap beside them, exact selection that skips
+// excluded columns.  What ops.score_topk_excl used to do with torch (materialise, a Python loop over rows, torch.topk).
+extern "C" int64_t mi_oov_score_topk_excl_dense_workspace(int64_t B, int64_t N) {
+  if (B <= 0 || N <= 0) return 0;
+  const int64_t rows = topk_chunk_rows(B, N);
+  return align256(rows * N * static_cast<int64_t>(sizeof(float))) + align256(rows * ((N + 63) / 64) * 8);
+}
+
+extern "C" int mi_oov_score_topk_excl_dense(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                                            int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols,
+                                            float* vals, int64_t* idx, void* workspace, void* stream) {
+  if (B < 0 || N <= 0 || D <= 0 || k <= 0 || n_skip_low < 0 || N >= (1LL << 32)) return MI_OOV_ERR_SHAPE;
+  if (B == 0) return MI_OOV_OK;
+  if (!U || !E || !excl_ptr || !excl_cols || !vals || !idx || !workspace) return MI_OOV_ERR_NULL;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15u) != 0) return MI_OOV_ERR_ALIGN;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t chunk = topk_chunk_rows(B, N), words = (N + 63) / 64;
+  float* S = static_cast<float*>(workspace);
+  unsigned long long* mask = reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + align256(chunk * N * static_cast<int64_t>(sizeof(float))));
+  for (int64_t b0 = 0; b0 < B; b0 += chunk) {
+    const int64_t rows = (b0 + chunk <= B) ? chunk : (B - b0);
+    if (int rc = launch_full_sort(U + b0 * D, rows, E, N, D, S, N, st)) return rc;
+    if (hipMemsetAsync(mask, 0, static_cast<size_t>(rows) * words * 8, st) != hipSuccess) {
+      check_launch();
+      return MI_OOV_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(mask_build_kernel, dim3(static_cast<unsigned>(rows)), dim3(kBlock), 0, st, excl_ptr + b0, excl_cols, rows, N, mask, words);
+    if (k <= 256)
+      hipLaunchKernelGGL(topk_select_masked_kernel, dim3(static_cast<unsigned>(rows)), dim3(kBlock), 0, st, S, rows, N, N, static_cast<int>(k),
+                         n_skip_low, reinterpret_cast<const uint64_t*>(mask), words, vals + b0 * k, idx + b0 * k);
+    else
+      hipLaunchKernelGGL(topk_rows_kernel, dim3(static_cast<unsigned>(rows)), dim3(kBlock), 0, st, S, rows, N, N, k, n_skip_low, vals + b0 * k,
+                         idx + b0 * k, reinterpret_cast<const uint64_t*>(mask), words);
+    if (int rc = check_launch()) return rc;
+  }
+  return MI_OOV_OK;
+}

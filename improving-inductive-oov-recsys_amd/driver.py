@@ -290,11 +290,15 @@ def evaluate(model, users, items, tot_items, cfg, n_users, n_items, device, gen)
     The reference scores one such batch per model.predict call.  Scores and rankings of a user do not depend on what
     else is in its batch, so here the batches are QUEUED: the plan (which users form which batch) is made on the host
     from ONE device -> host copy of the per-user counts -- the reference's dataloader plans on the host as well --,
-    every batch is then assembled with device operations only (negatives drawn batch by batch, in the reference's
-    order, so the sampled items do not depend on the queueing), and up to `eval_rows_per_launch` rows of consecutive
-    batches go through model.predict and the evaluator as ONE call: with BPR + lsh that is one user-row launch and one
-    fused lookup + score launch (the persistent kernel of csrc/lsh64p.hip from 524288 rows on) instead of two launches
-    and half a dozen host synchronisations per 1e5-row batch."""
+    the negatives are drawn batch by batch, in the reference's order (so the sampled items do not depend on the
+    queueing), and up to `eval_rows_per_launch` rows of consecutive batches are built, scored and ranked as ONE group:
+    `mi_oov_eval_rows_build` writes the group's (user, item) rows in one pass from the per-user counts (rows are
+    user-contiguous by construction: nothing is sorted), model.predict scores them -- with BPR + lsh one user-row launch
+    and one fused lookup + score launch (the persistent kernel of csrc/lsh64p.hip from 524288 rows on) --, and
+    `SampledRankingEvaluator.eval_group` ranks them (`mi_oov_segment_dedup`, three `mi_oov_segment_topk` +
+    `mi_oov_topk_hits_range` for the nine collectors).  The count vector is the run's only device -> host copy before the
+    rec.topk blocks come back in `ev.evaluate()`."""
+    from . import ops
     from .evaluator import SampledRankingEvaluator
     ukey, ikey, nneg = cfg["USER_ID_FIELD"], cfg["ITEM_ID_FIELD"], int(cfg["eval_negatives"])
     ev = SampledRankingEvaluator(cfg["topk"], cfg["metrics"] or ("recall", "mrr", "ndcg", "hit", "precision"),
@@ -325,30 +329,28 @@ def evaluate(model, users, items, tot_items, cfg, n_users, n_items, device, gen)
         cur_rows += rows
     if cur:
         groups.append(cur)
+    # positives CSR over the sorted users (device); a group's slice of it, rebased, is the group's CSR
+    pos_ptr_all = torch.cat((torch.zeros(1, dtype=torch.int64, device=device), torch.cumsum(counts, 0)))
     with torch.no_grad():
         for grp in groups:
-            g_lo = grp[0][0]
-            row_parts, col_parts, pos_u_parts, pos_i_parts = [], [], [], []
-            for lo_u, hi_u, pos_lo, npos in grp:
-                cnt = counts[lo_u:hi_u]
-                local = torch.arange(lo_u - g_lo, hi_u - g_lo, device=device)  # index of the user inside the group
-                pos_u = torch.repeat_interleave(local, cnt, output_size=npos)
-                pos_i = si[pos_lo:pos_lo + npos]
-                neg_u = torch.repeat_interleave(local, cnt * nneg, output_size=npos * nneg)
-                neg_i = torch.randint(1, tot_items, (npos * nneg,), generator=gen, device=device)
-                # rows of one user are contiguous: its positives, then its negatives (stable sort by user)
-                row_idx = torch.cat((pos_u, neg_u))
-                col_idx = torch.cat((pos_i, neg_i))
-                perm = torch.sort(row_idx, stable=True).indices
-                row_parts.append(row_idx[perm])
-                col_parts.append(col_idx[perm])
-                pos_u_parts.append(pos_u)
-                pos_i_parts.append(pos_i)
-            row_idx, col_idx = torch.cat(row_parts), torch.cat(col_parts)
-            pos_u, pos_i = torch.cat(pos_u_parts), torch.cat(pos_i_parts)
-            g_users = uniq[g_lo:grp[-1][1]]
-            scores = model.predict({ukey: g_users[row_idx], ikey: col_idx.clone()})
-            ev.eval_batch(scores, g_users, row_idx, col_idx, pos_u, pos_i)
+            g_lo, g_hi, p_lo = grp[0][0], grp[-1][1], grp[0][2]
+            n_pos = sum(bt[3] for bt in grp)
+            # negatives: ONE draw per reference batch, in the reference's order (so the sampled items do not depend on the
+            # queueing), each straight into its place of the group's array -- a batch's negatives lie in user order
+            # (general_dataloader.py:157-190), so consecutive batches concatenate to the layout mi_oov_eval_rows_build reads
+            neg = torch.empty((n_pos * nneg,), dtype=torch.int64, device=device)
+            off = 0
+            for _, _, _, npos in grp:
+                torch.randint(1, tot_items, (npos * nneg,), generator=gen, device=device, out=neg[off:off + npos * nneg])
+                off += npos * nneg
+            g_users = uniq[g_lo:g_hi]
+            pos_i = si[p_lo:p_lo + n_pos]
+            pos_ptr = pos_ptr_all[g_lo:g_hi + 1] - p_lo
+            # the group's rows in one pass: per user its positives, then its negatives; rows are user-contiguous by
+            # construction, so nothing is sorted and the evaluator is told so (eval_group)
+            row_user, row_item, seg_ptr = ops.eval_rows_build(pos_ptr, g_users, pos_i, neg, nneg)
+            scores = model.predict({ukey: row_user, ikey: row_item.clone()})
+            ev.eval_group(scores, g_users, row_item, seg_ptr, pos_ptr, pos_i)
     return ev.evaluate()
 
 

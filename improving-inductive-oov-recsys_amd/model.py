@@ -21,12 +21,15 @@ def xavier_normal_initialization(module):
     """R/model/init.py: Embedding and Linear weights xavier-normal, Linear bias 0.  Applied with
     self.apply(), it re-initialises bucket tables and embedder MLPs but never the LSH planes
     (a ParameterList), exactly as in the reference (bpr.py:46)."""
+    # (the reference writes through `.data`; here on the Parameter itself -- nn.init runs under no_grad -- so that torch's
+    # version counter moves and what is derived from a weight, ops.LshTable / ops.LinearX3Weights, sees a re-initialisation
+    # after the first forward call.  Same generator draws, same values.)
     if isinstance(module, nn.Embedding):
-        nn.init.xavier_normal_(module.weight.data)
+        nn.init.xavier_normal_(module.weight)
     elif isinstance(module, nn.Linear):
-        nn.init.xavier_normal_(module.weight.data)
+        nn.init.xavier_normal_(module.weight)
         if module.bias is not None:
-            nn.init.constant_(module.bias.data, 0)
+            nn.init.constant_(module.bias, 0)
 
 
 _SYNC_FREE_TRAIN = os.environ.get("MI_OOV_TRAIN_LOOKUP", "1") != "0"  # developer A/B knob (tools/train_step_time.py)

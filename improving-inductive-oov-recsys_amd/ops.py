@@ -189,15 +189,17 @@ class LshTable:
     """The 2^H-row table of aggregates `(bits @ buckets) / popcount` for ONE bucket tensor, prepared once
     (`mi_oov_lsh_table_prepare`) and handed to the persistent launches, which then load it instead of rebuilding it at
     their head.  `get()` returns the device table, re-prepared whenever the bucket tensor was written to since (torch's
-    version counter: an optimizer step, `load_state_dict` and every other in-place operation on the tensor bump it;
-    a write through `.data` does NOT -- call `invalidate()` after one), or None for shapes the persistent kernel does
-    not take (D != 64 or more than 8 buckets): callers pass that on and the launch builds the table itself."""
+    version counter: an optimizer step, `load_state_dict` and every other in-place operation on the tensor bump it) or
+    points at other memory (`p.data = new`); an in-place write THROUGH `.data` (`w.data.normal_()`) moves neither --
+    call `invalidate()` after one (this package's own initialiser writes under `torch.no_grad()`, which does bump the
+    counter).  None for shapes the persistent kernel does not take (D != 64 or more than 8 buckets): callers pass that on
+    and the launch builds the table itself."""
 
-    __slots__ = ("buckets", "table", "version")
+    __slots__ = ("buckets", "table", "version", "addr")
 
     def __init__(self, buckets):
         self.buckets = buckets  # the caller's tensor (a Parameter keeps its identity across optimizer steps)
-        self.table, self.version = None, None
+        self.table, self.version, self.addr = None, None, None
 
     def invalidate(self):
         self.version = None
@@ -208,14 +210,16 @@ class LshTable:
         nbytes = int(C.lib().mi_oov_lsh_table_bytes(H, D))
         if nbytes <= 0 or not b.is_cuda or b.data_ptr() % 16 or not b.is_contiguous():
             return None
-        if self.table is None or self.version != b._version or self.table.device != b.device:
+        # stale when the tensor was written in place (version counter), re-pointed (`p.data = other`: same Parameter, same
+        # version, another address) or moved to another device
+        if self.table is None or self.version != b._version or self.addr != b.data_ptr() or self.table.device != b.device:
             if self.table is None or self.table.device != b.device:
                 self.table = torch.empty((1 << H, D), dtype=torch.float32, device=b.device)
             src = _f32(b, "buckets")
             with C.on_device(src):
                 rc = C.lib().mi_oov_lsh_table_prepare(C.ptr(src), H, D, C.ptr(self.table), C.stream_of(src))
             C.check(rc, "mi_oov_lsh_table_prepare")
-            self.version = b._version
+            self.version, self.addr = b._version, b.data_ptr()
         return self.table
 
 
@@ -728,6 +732,8 @@ def siphash24_mod(ids, keys, mod=16777216, out=None):
     if out is None:
         out = torch.empty((B, K), dtype=torch.float32, device=ids.device)
     else:
+        if not out.is_contiguous():  # (the validator below would hand the kernel a contiguous COPY and leave `out` unwritten)
+            raise ValueError("out must be contiguous")
         out = _f32(out, "out")
         if out.dim() != 2 or out.shape[0] != B or out.shape[1] < K:
             raise ValueError(f"out must be f32[{B}, >= {K}], got {tuple(out.shape)}")
@@ -954,7 +960,7 @@ ACTS = {None: 0, "none": 0, "gelu": 1, "sigmoid": 2}
 
 def linear_act(X, W, bias, act=None):
     """act(X @ W.T + bias) on the f32 matrix cores (nn.Linear + nn.GELU()/nn.Sigmoid() of the hash nets,
-    dh_embedder.py:70-89).  Forward only: training goes through torch autograd."""
+    dh_embedder.py:70-89): the oracle's fmaf chain, bit for bit.  Forward only (`hash_net_train` supplies a backward)."""
     X, W, bias = _f32(X, "X"), _f32(W, "W"), _f32(bias, "bias")
     if X.shape[1] != W.shape[1] or bias.numel() != W.shape[0]:
         raise ValueError(f"shape mismatch: X {tuple(X.shape)}, W {tuple(W.shape)}, bias {tuple(bias.shape)}")
@@ -968,16 +974,16 @@ def linear_act(X, W, bias, act=None):
 
 class LinearX3Weights:
     """A Linear layer's weight split into its three bf16 planes for `linear_act_x3` (mi_oov_linear_x3_prepare): made
-    once and re-made when the weight tensor was written to since (torch's version counter, as `LshTable`; after a write
-    through `.data` call `invalidate()`)."""
+    once and re-made when the weight tensor was written to since or points at other memory (torch's version counter and
+    the data pointer, as `LshTable`; after an in-place write through `.data` call `invalidate()`)."""
 
-    __slots__ = ("_weight", "split", "version", "transposed")
+    __slots__ = ("_weight", "split", "version", "addr", "transposed")
 
     def __init__(self, weight, transposed=False):
         """transposed: `weight` is the TRANSPOSE of the layer's weight, [K, N_out] (mi_oov_linear_x3_prepare_t: training's
         backward products take their operands as they lie)."""
         self._weight = weakref.ref(weight)  # (weak: hash_net_forward keys its cache of these by the weight tensor)
-        self.split, self.version, self.transposed = None, None, bool(transposed)
+        self.split, self.version, self.addr, self.transposed = None, None, None, bool(transposed)
 
     def invalidate(self):
         self.version = None
@@ -986,7 +992,7 @@ class LinearX3Weights:
         w = self._weight()
         if w is None:
             raise RuntimeError("the weight tensor of this LinearX3Weights is gone")
-        if self.split is None or self.version != w._version or self.split.device != w.device:
+        if self.split is None or self.version != w._version or self.addr != w.data_ptr() or self.split.device != w.device:
             src = _f32(w, "W")
             n, k = (src.shape[1], src.shape[0]) if self.transposed else src.shape
             nbytes = int(C.lib().mi_oov_linear_x3_weights_bytes(n, k))
@@ -998,7 +1004,7 @@ class LinearX3Weights:
             with C.on_device(src):
                 rc = prepare(C.ptr(src), n, k, C.ptr(self.split), C.stream_of(src))
             C.check(rc, "mi_oov_linear_x3_prepare")
-            self.version = w._version
+            self.version, self.addr = w._version, w.data_ptr()
         return self.split
 
 
@@ -1059,8 +1065,10 @@ def _hash_net_layers(net):
 
 # `hash_net_forward` runs every batch on the split-bf16 layers: they are quicker than the f32 matrix instruction at every
 # size (65536 x 1024 -> 512: 324 vs 587 us, 1024 rows: 56 vs 91, 64 rows: 65 vs 86) and every tile form does the same
-# arithmetic in the same order, so a row's result does not depend on the batch it sits in.  MI_OOV_LINEAR_X3=0 puts
-# inference on the f32 kernel (`linear_act`, bit-identical to the oracle's chain; what training uses).
+# arithmetic in the same order, so a row's result does not depend on the batch it sits in.  Training (`hash_net_train`)
+# runs on the split layers too -- forward on `mi_oov_linear_x3`, the three backward products on `mi_oov_linear_x3_splitk`,
+# whose rounding depends on the number of K shares and so on the batch shape (`_x3_ksplit`).  MI_OOV_LINEAR_X3=0 puts both
+# on the f32 kernel (`linear_act`, bit-identical to the oracle's chain).
 _x3_weights = {}  # id(Linear.weight) -> LinearX3Weights (which holds the tensor weakly; dropped when the tensor dies)
 
 
@@ -1082,8 +1090,9 @@ def hash_net_forward(net, x):
     f32 accuracy (`linear_act_x3`; the weights' three-plane split is kept per weight tensor and re-made when the tensor's
     version counter moves; an input whose width is not a multiple of 16 is padded with zero columns once).  Within an
     f32 accumulation's error of the f32 product, not the oracle's summation order; MI_OOV_LINEAR_X3=0 selects the
-    bit-exact f32 kernel instead.  Under autograd `hash_net_train` keeps the pre-activations and supplies the backward
-    on the f32 GEMM kernel."""
+    bit-exact f32 kernel instead.  Under autograd `hash_net_train` keeps the pre-activations and supplies the backward,
+    on the same split-bf16 GEMM (`_gemm_nt`: mi_oov_linear_x3_splitk; gradients then depend on the batch shape through the
+    K shares) unless MI_OOV_LINEAR_X3=0."""
     x3 = _x3_wanted()
     for lin, act in _hash_net_layers(net):
         if x3:
@@ -1266,12 +1275,15 @@ def score_topk(U, E, k, n_skip_low=0):
     rows = B
     while rows > 128 and ws_bytes(rows) > _TOPK_WORKSPACE_MAX_BYTES:
         rows = max(128, (rows // 2 + 127) // 128 * 128)
-    ws = torch.empty((max(16, int(lib.mi_oov_score_topk_workspace_d(min(rows, B), N, D, k))),), dtype=torch.uint8, device=U.device)
+    ws = None  # (a prepared catalogue's chunks bring their own, smaller workspace: the general one -- with room for a bf16
+    # copy of E, gigabytes at 10 M rows -- is allocated only if a chunk falls through to mi_oov_score_topk)
     with C.on_device(U):
         for b0 in range(0, max(B, 1), max(rows, 1)):
             nb = min(rows, B - b0)
             if cat is not None and nb > 0 and _prepared_call(U[b0:b0 + nb], cat, k, n_skip_low, None, None, vals[b0:b0 + nb], idx[b0:b0 + nb]):
                 continue
+            if ws is None:
+                ws = torch.empty((max(16, int(lib.mi_oov_score_topk_workspace_d(min(rows, B), N, D, k))),), dtype=torch.uint8, device=U.device)
             rc = lib.mi_oov_score_topk(C.ptr(U[b0:b0 + nb]), nb, C.ptr(E), N, D, k, n_skip_low, C.ptr(vals[b0:b0 + nb]),
                                        C.ptr(idx[b0:b0 + nb]), C.ptr(ws), C.stream_of(U))
             C.check(rc, "mi_oov_score_topk")
@@ -1299,17 +1311,55 @@ def segment_topk(scores, cols, seg_ptr, k, col_lo=0, col_hi=None):
     return vals, idx
 
 
-def topk_hits(idx, pos_ptr, pos_cols):
+def topk_hits(idx, pos_ptr, pos_cols, col_lo=0, col_hi=None):
     """The collector's rec.topk block (collector.py:161-166): int32[S, k+1] = hit flags of idx[s,:] against the
-    positives of segment s (CSR) followed by the positive count."""
+    positives of segment s (CSR) followed by the positive count.  col_lo / col_hi: only positives with a column in
+    [col_lo, col_hi) count (mi_oov_topk_hits_range: the old-item / new-item slices, no compaction of the lists)."""
     idx, pos_ptr, pos_cols = _ids(idx, "idx"), _ids(pos_ptr, "pos_ptr"), _ids(pos_cols, "pos_cols")
     S, k = idx.shape
     out = torch.empty((S, k + 1), dtype=torch.int32, device=idx.device)
     if pos_cols.numel() == 0:
         pos_cols = torch.zeros((1,), dtype=torch.int64, device=idx.device)
     with C.on_device(idx):
-        rc = C.lib().mi_oov_topk_hits(C.ptr(idx), S, k, C.ptr(pos_ptr), C.ptr(pos_cols), C.ptr(out), C.stream_of(idx))
-    C.check(rc, "mi_oov_topk_hits")
+        rc = C.lib().mi_oov_topk_hits_range(C.ptr(idx), S, k, C.ptr(pos_ptr), C.ptr(pos_cols), int(col_lo),
+                                            int(col_hi) if col_hi is not None else (1 << 62), C.ptr(out), C.stream_of(idx))
+    C.check(rc, "mi_oov_topk_hits_range")
+    return out
+
+
+def eval_rows_build(pos_ptr, user_ids, pos_items, neg_items, n_neg, want_pos_user=False):
+    """The rows of a group of NegSampleEvalDataLoader batches in one pass (mi_oov_eval_rows_build; general_dataloader.py:
+    157-190): per user its positives, then n_neg sampled items per positive.  pos_ptr i64[U+1] (CSR of the positives per
+    user, pos_ptr[0] = 0), user_ids i64[U], pos_items i64[P], neg_items i64[P * n_neg] in user order.
+    -> (row_user i64[M], row_item i64[M], seg_ptr i64[U+1][, pos_user i64[P]]), M = P (1 + n_neg).  No host sync: P is
+    taken from the shape of pos_items."""
+    pos_ptr, user_ids, pos_items = _ids(pos_ptr, "pos_ptr"), _ids(user_ids, "user_ids"), _ids(pos_items, "pos_items")
+    neg_items = _ids(neg_items, "neg_items")
+    U, P, n_neg = user_ids.numel(), pos_items.numel(), int(n_neg)
+    if pos_ptr.numel() != U + 1 or neg_items.numel() != P * n_neg:
+        raise ValueError(f"need pos_ptr i64[{U + 1}] and neg_items i64[{P * n_neg}], got {pos_ptr.numel()} and {neg_items.numel()}")
+    dev = pos_items.device
+    M = P * (1 + n_neg)
+    row_user = torch.empty((M,), dtype=torch.int64, device=dev)
+    row_item = torch.empty((M,), dtype=torch.int64, device=dev)
+    seg_ptr = torch.empty((U + 1,), dtype=torch.int64, device=dev)
+    pos_user = torch.empty((P,), dtype=torch.int64, device=dev) if want_pos_user else None
+    with C.on_device(pos_items):
+        rc = C.lib().mi_oov_eval_rows_build(C.ptr(pos_ptr), U, C.ptr(user_ids), C.ptr(pos_items), C.ptr(neg_items), n_neg,
+                                            C.ptr(row_user), C.ptr(row_item), C.ptr(seg_ptr), C.ptr(pos_user), C.stream_of(pos_items))
+    C.check(rc, "mi_oov_eval_rows_build")
+    return (row_user, row_item, seg_ptr, pos_user) if want_pos_user else (row_user, row_item, seg_ptr)
+
+
+def segment_dedup(cols, seg_ptr):
+    """cols with every repeated column of a segment (after its first occurrence) replaced by -1 (mi_oov_segment_dedup):
+    what the reference's dense scatter `scores[row_idx, col_idx] = origin_scores` does to a duplicated candidate
+    (R/inductive/evaluator.py:118-134).  `segment_topk` skips the -1 entries when it is given a column range."""
+    cols, seg_ptr = _ids(cols, "cols"), _ids(seg_ptr, "seg_ptr")
+    out = torch.empty_like(cols)
+    with C.on_device(cols):
+        rc = C.lib().mi_oov_segment_dedup(C.ptr(cols), C.ptr(seg_ptr), seg_ptr.numel() - 1, C.ptr(out), C.stream_of(cols))
+    C.check(rc, "mi_oov_segment_dedup")
     return out
 
 
@@ -1319,11 +1369,15 @@ _USE_MASKED_TOPK = True           # tests flip this to cover the k + h_max path 
 
 def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
     """top-k of U @ E.T per user with scores[:, :n_skip_low] and the user's excluded columns (history) treated as
-    -inf (InductiveEvaluator.eval_batch, R/inductive/evaluator.py:92-95), without materialising the scores.
-    excl_ptr i64[B+1], excl_cols i64[nnz] ascending within a row.  64-column tables take the masked fused kernel
-    (`mi_oov_score_topk_masked`: any history length, no host synchronisation).  Other shapes: users are processed
-    in groups such that k + (longest history of the group) <= 256 (`mi_oov_score_topk_excl`); users with longer
-    histories go through the materialising path."""
+    -inf (InductiveEvaluator.eval_batch, R/inductive/evaluator.py:92-95), without returning the scores.
+    excl_ptr i64[B+1], excl_cols i64[nnz].  Routes, all inside the library and none with a host synchronisation:
+      * rows of up to 128 floats over a catalogue the fused path takes: `mi_oov_score_topk_masked` (exclusion bitmap inside
+        the fused bf16 kernel; any history length); a user batch whose workspace would pass `_MASKED_TOPK_MAX_BYTES` goes
+        through in chunks of users (the exclusion CSR is addressed through a shifted excl_ptr: nothing is copied);
+      * everything else (D > 128, k > 256, a catalogue of fewer than 128 k rows): `mi_oov_score_topk_excl_dense` -- scores of
+        <= 1 GiB of users materialised, bitmap, exact select.
+    `h_max` (longest history, known to the caller) with `_USE_MASKED_TOPK = False` selects the older top-(k + h_max) route
+    (`mi_oov_score_topk_excl`, k + h_max <= 256; tests and tools/tune.py compare it with the masked kernel)."""
     cat = E if isinstance(E, TopkCatalogue) else None
     if cat is not None:
         if not cat.fresh():
@@ -1331,7 +1385,9 @@ def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
         E = cat.E
     U, E = _f32(U, "U"), _f32(E, "E")
     excl_ptr, excl_cols = _ids(excl_ptr, "excl_ptr"), _ids(excl_cols, "excl_cols")
-    B, N = U.shape[0], E.shape[0]
+    B, N, D = U.shape[0], E.shape[0], U.shape[1]
+    if excl_ptr.numel() != B + 1:
+        raise ValueError(f"excl_ptr must have {B + 1} entries, got {excl_ptr.numel()}")
     vals = torch.empty((B, k), dtype=torch.float32, device=U.device)
     idx = torch.empty((B, k), dtype=torch.int64, device=U.device)
     if B == 0:
@@ -1339,45 +1395,39 @@ def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0, h_max=None):
     if excl_cols.numel() == 0:
         excl_cols = torch.zeros((1,), dtype=torch.int64, device=U.device)
     lib = C.lib()
-    # histories of any length, one call, no host sync: exclusion bitmap applied inside the fused kernel (D = 64)
-    need = int(lib.mi_oov_score_topk_prepared_workspace(B, N, U.shape[1], k, 1)) if cat is not None else \
-        int(lib.mi_oov_score_topk_masked_workspace(B, N, U.shape[1], k))
-    if _USE_MASKED_TOPK and 0 < need <= _MASKED_TOPK_MAX_BYTES and U.data_ptr() % 16 == 0 and E.data_ptr() % 16 == 0:
-        if cat is not None and _prepared_call(U, cat, k, n_skip_low, excl_ptr, excl_cols, vals, idx):
-            return vals, idx
-        ws = torch.empty((need,), dtype=torch.uint8, device=U.device)
+
+    def masked_bytes(rows):
+        return int(lib.mi_oov_score_topk_prepared_workspace(rows, N, D, k, 1)) if cat is not None else \
+            int(lib.mi_oov_score_topk_masked_workspace(rows, N, D, k))
+
+    if _USE_MASKED_TOPK and masked_bytes(B) > 0 and U.data_ptr() % 16 == 0 and E.data_ptr() % 16 == 0:
+        rows = B  # users per call: a multiple of the 128-row tile once the batch is cut (row stride D * 4: chunks stay aligned)
+        while rows > 128 and masked_bytes(rows) > _MASKED_TOPK_MAX_BYTES:
+            rows = max(128, (rows // 2 + 127) // 128 * 128)
+        ws = None
         with C.on_device(U):
-            rc = lib.mi_oov_score_topk_masked(C.ptr(U), B, C.ptr(E), N, U.shape[1], k, int(n_skip_low), C.ptr(excl_ptr),
-                                              C.ptr(excl_cols), C.ptr(vals), C.ptr(idx), C.ptr(ws), C.stream_of(U))
-        C.check(rc, "mi_oov_score_topk_masked")
+            for b0 in range(0, B, rows):
+                nb = min(rows, B - b0)
+                ptr_b = excl_ptr[b0:b0 + nb + 1]  # absolute offsets into excl_cols: a view is the chunk's CSR
+                if cat is not None and _prepared_call(U[b0:b0 + nb], cat, k, n_skip_low, ptr_b, excl_cols, vals[b0:b0 + nb], idx[b0:b0 + nb]):
+                    continue
+                if ws is None:
+                    ws = torch.empty((int(lib.mi_oov_score_topk_masked_workspace(min(rows, B), N, D, k)),), dtype=torch.uint8, device=U.device)
+                rc = lib.mi_oov_score_topk_masked(C.ptr(U[b0:b0 + nb]), nb, C.ptr(E), N, D, k, int(n_skip_low), C.ptr(ptr_b),
+                                                  C.ptr(excl_cols), C.ptr(vals[b0:b0 + nb]), C.ptr(idx[b0:b0 + nb]), C.ptr(ws), C.stream_of(U))
+                C.check(rc, "mi_oov_score_topk_masked")
         return vals, idx
-    lens = excl_ptr[1:] - excl_ptr[:-1]
-    longest = int(lens.max()) if h_max is None else int(h_max)
-    if k + longest <= 256:
+    if not _USE_MASKED_TOPK and h_max is not None and k + int(h_max) <= 256:
+        longest = int(h_max)
         ws = torch.empty((max(int(lib.mi_oov_score_topk_excl_workspace(B, N, k, longest)), 16),), dtype=torch.uint8, device=U.device)
         with C.on_device(U):
-            rc = lib.mi_oov_score_topk_excl(C.ptr(U), B, C.ptr(E), N, U.shape[1], k, int(n_skip_low), C.ptr(excl_ptr),
+            rc = lib.mi_oov_score_topk_excl(C.ptr(U), B, C.ptr(E), N, D, k, int(n_skip_low), C.ptr(excl_ptr),
                                             C.ptr(excl_cols), longest, C.ptr(vals), C.ptr(idx), C.ptr(ws), C.stream_of(U))
         C.check(rc, "mi_oov_score_topk_excl")
         return vals, idx
-    # long histories: fused path for the users that fit, materialised scores + mask for the rest
-    short = lens <= 256 - k
-    for sel, fused in ((short, True), (~short, False)):
-        rows = torch.nonzero(sel).view(-1)
-        if rows.numel() == 0:
-            continue
-        sub_ptr = torch.cat((torch.zeros(1, dtype=torch.int64, device=U.device), torch.cumsum(lens[rows], 0)))
-        take = torch.cat([torch.arange(int(excl_ptr[r]), int(excl_ptr[r + 1]), device=U.device) for r in rows.tolist()]) \
-            if int(sub_ptr[-1]) else torch.zeros((0,), dtype=torch.int64, device=U.device)
-        sub_cols = excl_cols[take] if take.numel() else torch.zeros((1,), dtype=torch.int64, device=U.device)
-        if fused:
-            v, i = score_topk_excl(U[rows], E, k, sub_ptr, sub_cols, n_skip_low, int(lens[rows].max()))
-        else:
-            S = full_sort_scores(U[rows], E).view(rows.numel(), N)
-            S[:, :n_skip_low] = -float("inf")
-            if take.numel():
-                S[torch.repeat_interleave(torch.arange(rows.numel(), device=U.device), lens[rows]), sub_cols] = -float("inf")
-            v, i = torch.topk(S, k, dim=1)
-        vals[rows], idx[rows] = v, i
+    ws = torch.empty((max(int(lib.mi_oov_score_topk_excl_dense_workspace(B, N)), 16),), dtype=torch.uint8, device=U.device)
+    with C.on_device(U):
+        rc = lib.mi_oov_score_topk_excl_dense(C.ptr(U), B, C.ptr(E), N, D, k, int(n_skip_low), C.ptr(excl_ptr), C.ptr(excl_cols),
+                                              C.ptr(vals), C.ptr(idx), C.ptr(ws), C.stream_of(U))
+    C.check(rc, "mi_oov_score_topk_excl_dense")
     return vals, idx
-

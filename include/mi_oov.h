@@ -46,7 +46,8 @@ enum {
   MI_OOV_ERR_KIND = -3,      /* unknown enum value (hash function ...)          */
   MI_OOV_ERR_LAUNCH = -4,    /* hipLaunchKernel / hipMemsetAsync reported error */
   MI_OOV_ERR_ALIGN = -5,     /* pointer not aligned as documented               */
-  MI_OOV_ERR_WORKSPACE = -6  /* workspace too small                             */
+  MI_OOV_ERR_WORKSPACE = -6, /* workspace too small                             */
+  MI_OOV_ERR_ALIAS = -7      /* an output buffer is also an input               */
 };
 
 int mi_oov_version(void);
@@ -422,6 +423,32 @@ int mi_oov_segment_topk(const float* scores, const int64_t* cols, const int64_t*
 int mi_oov_topk_hits(const int64_t* idx, int64_t S, int64_t k, const int64_t* pos_ptr, const int64_t* pos_cols,
                      int32_t* out, void* stream);
 
+/* ... with a column range on the POSITIVES: positives outside [col_lo, col_hi) neither count in out[s,k] nor match -- the
+ * old-item / new-item slices of the filtered collectors (R/inductive/collector_filter.py:128-256) without compacting the
+ * positive lists.  mi_oov_topk_hits = the whole range.                                                             */
+int mi_oov_topk_hits_range(const int64_t* idx, int64_t S, int64_t k, const int64_t* pos_ptr, const int64_t* pos_cols,
+                           int64_t col_lo, int64_t col_hi, int32_t* out, void* stream);
+
+/* The rows of NegSampleEvalDataLoader's batches (R/data/dataloader/general_dataloader.py:157-190,
+ * abstract_dataloader.py:227-235: per user its positives first, then n_neg sampled items per positive) for a GROUP of
+ * consecutive batches, in one pass: user u of the group (u < n_users) has positives pos_items[pos_ptr[u] .. pos_ptr[u+1])
+ * and negatives neg_items[pos_ptr[u] * n_neg .. pos_ptr[u+1] * n_neg) (the negatives of a batch are drawn as one array in
+ * user order, so consecutive batches concatenate to exactly this layout); its rows are
+ * [seg_ptr[u], seg_ptr[u+1]), seg_ptr[u] = pos_ptr[u] * (1 + n_neg).
+ *   pos_ptr i64[n_users+1] (pos_ptr[0] = 0), user_ids i64[n_users], pos_items i64[P], neg_items i64[P * n_neg]
+ *   -> row_user i64[M], row_item i64[M] (M = P (1 + n_neg): what model.predict is handed), seg_ptr i64[n_users+1],
+ *      pos_user i64[P] or NULL (index of the user of every positive).                                               */
+int mi_oov_eval_rows_build(const int64_t* pos_ptr, int64_t n_users, const int64_t* user_ids, const int64_t* pos_items,
+                           const int64_t* neg_items, int64_t n_neg, int64_t* row_user, int64_t* row_item,
+                           int64_t* seg_ptr, int64_t* pos_user, void* stream);
+
+/* The reference scatters a batch's scores into a dense matrix, `scores[row_idx, col_idx] = origin_scores`
+ * (R/inductive/evaluator.py:118-134): a (user, item) pair that occurs twice keeps ONE entry.  out[i] = cols[i] where
+ * candidate i is the first of its segment with that column, -1 where an earlier one has it (mi_oov_segment_topk skips
+ * negative columns whenever it is given a column range, e.g. [0, 2^62 - 1)).  cols i64[M], seg_ptr i64[S+1] -> out i64[M];
+ * out must not be cols (MI_OOV_ERR_ALIAS).  Any segment length, no workspace.                                      */
+int mi_oov_segment_dedup(const int64_t* cols, const int64_t* seg_ptr, int64_t S, int64_t* out, void* stream);
+
 /* mi_oov_score_topk with per-user exclusions: what the collector's topk sees after InductiveEvaluator.eval_batch has
  * set scores[:,0] and scores[history_index] to -inf (R/inductive/evaluator.py:92-95).  excl_ptr i64[B+1] / excl_cols
  * i64[nnz] is the CSR of excluded columns, ASCENDING within a row; h_max >= the longest row; k + h_max <= 256
@@ -432,6 +459,16 @@ int64_t mi_oov_score_topk_excl_workspace(int64_t B, int64_t N, int64_t k, int64_
 int mi_oov_score_topk_excl(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
                            int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols, int64_t h_max,
                            float* vals, int64_t* idx, void* workspace, void* stream);
+
+/* The same result for EVERY shape (any D, any k, any history length, catalogues too small for the fused path): scores of
+ * a chunk of users materialised in the workspace (mi_oov_full_sort_scores' kernel), the exclusion bitmap built beside
+ * them, an exact radix select that skips excluded columns -- the route of last resort, all inside the library and without
+ * a host synchronisation.  excl_cols need not be sorted; entries outside [0, N) are ignored; missing entries (-inf, -1).
+ *   workspace: mi_oov_score_topk_excl_dense_workspace(B, N) bytes, 16-byte aligned.                                 */
+int64_t mi_oov_score_topk_excl_dense_workspace(int64_t B, int64_t N);
+int mi_oov_score_topk_excl_dense(const float* U, int64_t B, const float* E, int64_t N, int64_t D, int64_t k,
+                                 int64_t n_skip_low, const int64_t* excl_ptr, const int64_t* excl_cols,
+                                 float* vals, int64_t* idx, void* workspace, void* stream);
 
 /* The same result with exclusion lists of ANY length, still without a [B,N] matrix: the CSR becomes a bitmap of
  * B x ceil(N/64) words inside the workspace; the first pass of the fused kernel leaves excluded columns out of its tile

@@ -281,6 +281,39 @@ def topk_hits(idx, pos_ptr, pos_cols):
     return out
 
 
+def topk_hits_range(idx, pos_ptr, pos_cols, col_lo, col_hi):
+    idx = np.ascontiguousarray(idx, dtype=np.int64)
+    pos_ptr = np.ascontiguousarray(pos_ptr, dtype=np.int64)
+    pos_cols = np.ascontiguousarray(pos_cols, dtype=np.int64)
+    S, k = idx.shape
+    out = np.empty((S, k + 1), np.int32)
+    lib().oov_topk_hits_range(_p(idx), _c(S), _c(k), _p(pos_ptr), _p(pos_cols), _c(col_lo), _c(col_hi), _p(out))
+    return out
+
+
+def eval_rows_build(pos_ptr, user_ids, pos_items, neg_items, n_neg):
+    """-> (row_user, row_item, seg_ptr, pos_user)"""
+    pos_ptr = np.ascontiguousarray(pos_ptr, dtype=np.int64)
+    user_ids = np.ascontiguousarray(user_ids, dtype=np.int64)
+    pos_items = np.ascontiguousarray(pos_items, dtype=np.int64)
+    neg_items = np.ascontiguousarray(neg_items, dtype=np.int64)
+    U, P = len(user_ids), len(pos_items)
+    M = P * (1 + n_neg)
+    row_user, row_item = np.empty(M, np.int64), np.empty(M, np.int64)
+    seg_ptr, pos_user = np.empty(U + 1, np.int64), np.empty(P, np.int64)
+    lib().oov_eval_rows_build(_p(pos_ptr), _c(U), _p(user_ids), _p(pos_items), _p(neg_items), _c(n_neg), _p(row_user),
+                              _p(row_item), _p(seg_ptr), _p(pos_user))
+    return row_user, row_item, seg_ptr, pos_user
+
+
+def segment_dedup(cols, seg_ptr):
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    seg_ptr = np.ascontiguousarray(seg_ptr, dtype=np.int64)
+    out = np.empty_like(cols)
+    lib().oov_segment_dedup(_p(cols), _p(seg_ptr), _c(len(seg_ptr) - 1), _p(out))
+    return out
+
+
 def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0):
     U, E = _f32(U), _f32(E)
     excl_ptr = np.ascontiguousarray(excl_ptr, dtype=np.int64)

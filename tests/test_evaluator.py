@@ -112,14 +112,19 @@ def test_gpu_collector_dedups_and_slices(dev):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("masked", [True, False])
-@pytest.mark.parametrize("B,N,k,hmax", [(70, 3000, 10, 40), (9, 1300, 5, 0), (130, 4159, 20, 200), (40, 2500, 10, 600)])
-def test_gpu_full_sort_topk_with_history_vs_oracle(B, N, k, hmax, masked, oracle, dev, monkeypatch):
-    """Full-sort evaluation: column 0 and every user's history masked (evaluator.py:92-95) inside the fused top-k.
-    masked: the exclusion bitmap inside the kernel (any history length); otherwise top-(k + longest history), where
-    histories longer than 256 - k fall back to materialised scores for those users."""
+@pytest.mark.parametrize("route", ["masked", "masked_chunked", "k_plus_hmax", "dense"])
+@pytest.mark.parametrize("B,N,k,hmax", [(70, 3000, 10, 40), (9, 1300, 5, 0), (130, 4159, 20, 200), (40, 2500, 10, 600), (300, 2700, 10, 90)])
+def test_gpu_full_sort_topk_with_history_vs_oracle(B, N, k, hmax, route, oracle, dev, monkeypatch):
+    """Full-sort evaluation: column 0 and every user's history masked (evaluator.py:92-95) inside the top-k, on every route of
+    ops.score_topk_excl -- masked: the exclusion bitmap inside the fused kernel (any history length); masked_chunked: the
+    same with a workspace bound so small that the user batch is cut into 128-row chunks (the CSR addressed through a
+    shifted excl_ptr); k_plus_hmax: top-(k + longest history) then a filter pass (the caller states h_max; longer
+    histories than 256 - k go on to the dense route); dense: materialised chunk + bitmap + exact select, all inside the
+    library (round 4: this replaced a torch.topk fallback with a Python loop over rows)."""
     from mi_oov import ops
-    monkeypatch.setattr(ops, "_USE_MASKED_TOPK", masked)
+    monkeypatch.setattr(ops, "_USE_MASKED_TOPK", route.startswith("masked"))
+    if route == "masked_chunked":
+        monkeypatch.setattr(ops, "_MASKED_TOPK_MAX_BYTES", 1 << 16)
     rng = np.random.default_rng(B + N)
     U = rng.standard_normal((B, 64), dtype=np.float32)
     E = rng.standard_normal((N, 64), dtype=np.float32)
@@ -135,7 +140,8 @@ def test_gpu_full_sort_topk_with_history_vs_oracle(B, N, k, hmax, masked, oracle
             seg[:3] = best[b]
             cols[ptr[b]:ptr[b + 1]] = np.sort(np.unique(np.concatenate((seg, best[b])))[:lens[b]]) if len(np.unique(seg)) == lens[b] else np.sort(seg)
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
-    v, i = ops.score_topk_excl(T(U), T(E), k, T(ptr), T(cols.astype(np.int64)), n_skip_low=1)
+    v, i = ops.score_topk_excl(T(U), T(E), k, T(ptr), T(cols.astype(np.int64)), n_skip_low=1,
+                               h_max=hmax if route == "k_plus_hmax" else None)
     ov, oi = oracle.score_topk_excl(U, E, k, ptr, cols, 1)
     i = i.cpu().numpy()
     assert np.array_equal(i, oi)
@@ -177,6 +183,43 @@ def test_gpu_masked_topk_edge_cases(case, oracle, dev):
     from mi_oov import _cabi
     assert _cabi.lib().mi_oov_score_topk_masked_workspace(B, N, 64, k) > 0   # the shape is one the masked kernel takes
     v, i = ops.score_topk_excl(T(U), T(E), k, T(ptr), T(cols), n_skip_low=1)
+    ov, oi = oracle.score_topk_excl(U, E, k, ptr, cols, 1)
+    assert np.array_equal(i.cpu().numpy(), oi)
+    assert np.array_equal(v.cpu().numpy(), ov)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,N,D,k", [(33, 900, 200, 10),      # rows wider than the fused path's 128 floats
+                                     (20, 5000, 64, 300),     # k beyond the fused path's 256 (the k-pass kernel)
+                                     (50, 700, 64, 20),       # a catalogue of fewer than 128 k rows
+                                     (7, 257, 19, 257)])      # k = N: every allowed column, then (-inf, -1)
+def test_gpu_score_topk_excl_dense_route_vs_oracle(B, N, D, k, oracle, dev):
+    """Shapes the fused masked kernel refuses (its workspace query returns 0) go through mi_oov_score_topk_excl_dense --
+    no torch.topk, no Python loop over rows, no host synchronisation -- and equal the oracle: unsorted lists with
+    duplicates and out-of-range columns, histories that hold the best columns, users left with fewer than k columns."""
+    from mi_oov import ops, _cabi
+    rng = np.random.default_rng(B + N + D)
+    U = rng.standard_normal((B, D), dtype=np.float32)
+    E = rng.standard_normal((N, D), dtype=np.float32)
+    _, best = oracle.score_topk(U, E, min(N - 1, 40), 1)
+    lists = []
+    for b in range(B):
+        c = np.concatenate((best[b][: int(rng.integers(0, best.shape[1] + 1))], rng.integers(1, N, int(rng.integers(0, 300))), [-3, N, N + 5]))
+        if b % 9 == 0:  # nearly everything excluded
+            c = np.setdiff1d(np.arange(N), rng.choice(np.arange(1, N), size=3 + b % 5, replace=False))
+        rng.shuffle(c)
+        lists.append(np.asarray(c, np.int64))
+    ptr = np.concatenate(([0], np.cumsum([len(c) for c in lists]))).astype(np.int64)
+    cols = np.concatenate(lists)
+    assert _cabi.lib().mi_oov_score_topk_masked_workspace(B, N, D, k) == 0
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    args = (T(U), T(E), k, T(ptr), T(cols))
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        v, i = ops.score_topk_excl(*args, n_skip_low=1)
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
     ov, oi = oracle.score_topk_excl(U, E, k, ptr, cols, 1)
     assert np.array_equal(i.cpu().numpy(), oi)
     assert np.array_equal(v.cpu().numpy(), ov)

@@ -494,6 +494,19 @@ def test_linear_x3_special_values_and_weights_cache(oracle, ops, dev):
     Wt.data.mul_(0.5)  # a write through .data moves no counter: invalidate() by hand
     cache.invalidate()
     assert torch.equal(ops.linear_act_x3(Xt, Wt, bt, None, cache), y0)
+    # a Parameter re-pointed at other memory (`p.data = new`: same object, same version counter) is seen through its address
+    P = torch.nn.Parameter(Wt.clone())
+    pc = ops.LinearX3Weights(P)
+    assert torch.equal(ops.linear_act_x3(Xt, P, bt, None, pc), y0)
+    v0 = P._version
+    P.data = (2.0 * Wt).contiguous()
+    assert P._version == v0
+    assert torch.equal(ops.linear_act_x3(Xt, P, bt, None, pc), 2 * y0)
+    # contiguous outputs only: a non-contiguous `out` would be written into a temporary copy
+    ids = torch.arange(4, device=dev)
+    keys = torch.zeros((3, 16), dtype=torch.uint8, device=dev)
+    with pytest.raises(ValueError):
+        ops.siphash24_mod(ids, keys, out=torch.empty((8, 4), device=dev)[:, :4].t())
 
 
 def test_hash_net_forward_runs_the_split_layers_whatever_the_batch(ops, dev, monkeypatch):
@@ -1122,6 +1135,36 @@ def test_lsh_table_prepared_equals_per_lookup_arithmetic_and_tracks_updates(orac
         assert bits_equal(got2, want2), f"H = {H} after an in-place update"
     assert ops.LshTable(torch.zeros((9, 64), device=dev)).get() is None
     assert ops.LshTable(torch.zeros((8, 32), device=dev)).get() is None
+    # a Parameter re-pointed at other memory keeps its version counter: the table follows the address
+    P = torch.nn.Parameter(T(buckets, dev))
+    tab = ops.LshTable(P)
+    t0 = tab.get().clone()
+    P.data = (P.data * 2.0).contiguous()
+    assert not torch.equal(torch.nan_to_num(tab.get()), torch.nan_to_num(t0))
+
+
+def test_reinitialising_a_model_after_a_forward_call_is_seen(dev):
+    """the package's initialiser used to write through `.data`, which moves no version counter -- a sweep that
+    re-initialises a model after its first inference call kept scoring with the old split weights / the old table of
+    aggregates.  It now writes on the Parameter (under no_grad): the counter moves and both caches re-make themselves."""
+    import mi_oov
+    from mi_oov import ops
+    from mi_oov.model import xavier_normal_initialization
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(32, 48), torch.nn.GELU(), torch.nn.Linear(48, 16), torch.nn.Sigmoid()).to(dev)
+    x = torch.randn((70, 32), device=dev)
+    with torch.no_grad():
+        y0 = ops.hash_net_forward(net, x)
+        net.apply(xavier_normal_initialization)
+        y1 = ops.hash_net_forward(net, x)
+        ref = torch.sigmoid(torch.nn.functional.linear(torch.nn.functional.gelu(torch.nn.functional.linear(x, net[0].weight, net[0].bias)),
+                                                       net[2].weight, net[2].bias))
+    assert not torch.equal(y0, y1) and float((y1 - ref).abs().max()) < 1e-5
+    emb = torch.nn.Embedding(8, 64).to(dev)
+    tab = ops.LshTable(emb.weight)
+    t0 = tab.get().clone()
+    emb.apply(xavier_normal_initialization)
+    assert not torch.equal(torch.nan_to_num(tab.get()), torch.nan_to_num(t0))
 
 
 @pytest.mark.parametrize("B", [524288 + 37, 600000])

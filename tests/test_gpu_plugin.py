@@ -747,6 +747,23 @@ def test_full_size_queued_batches_equal_single_launches(mi, dev):
                 assert same(lrows[k], ops.lsh_lookup(ids[k], vt, feat, planes, buckets)), ("lookup rows", k)
                 assert same(lsc[k], ops.lsh_lookup_score(ids[k], vt, feat, planes, buckets, users[k])), ("lookup score", k)
         assert int(torch.isnan(rows[0]).all(1).sum()) > 100  # the all-zero codes' NaN rows are there (about 1 in 256)
+        # the headline entry itself (VERDICT r03 #4a): the fused score of K queued batches, lsh64_persistent_kernel<8, 0, true,
+        # false> -- what bench.py times -- without the prepared table (mi_oov_lsh_embed_score_multi), with it
+        # (mi_oov_lsh_multi through LshMultiScorer.run) and as the prevalidated call bench.py issues (LshMultiScorer.bind)
+        want = [ops.lsh_embed_score(ids[k], feat, planes, buckets, users[k]) for k in range(K)]
+        plain = ops.lsh_embed_score_multi(ids, feat, planes, buckets, users)
+        scorer = ops.LshMultiScorer(feat, planes, buckets)
+        assert scorer.persistent and scorer._table is not None
+        q = ops.LshBatchQueue(ids, users)
+        prepared = [t.clone() for t in scorer.run(q)]
+        for t in q.scores:
+            t.fill_(-1.0)
+        scorer.bind(q, 1, K - 1)()  # batches 1 .. K-1 of the queue
+        for k in range(K):
+            assert same(plain[k], want[k]), ("score, table built by the launch", k)
+            assert same(prepared[k], want[k]), ("score, prepared table", k)
+            assert same(q.scores[k], want[k]) if k else bool((q.scores[0] == -1.0).all()), ("score, bound call", k)
+        assert int(torch.isnan(want[0]).sum()) > 100
         gr = ops.gather_rows_multi(ids, feat)
         idx2 = [torch.randint(0, N, (B, 2), generator=g, device=dev) for _ in range(K)]
         gm = ops.gather_mean_multi(idx2, feat, 2)

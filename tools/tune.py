@@ -184,9 +184,9 @@ def main():
             ptr = torch.cat((torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(lens, 0)))
             colsx = torch.randint(1, Ns, (int(ptr[-1]),), generator=gh, device=dev)
             for masked in (True, False):
-                def run(i, ptr=ptr, colsx=colsx, masked=masked):
+                def run(i, ptr=ptr, colsx=colsx, masked=masked, hmax=hmax):
                     ops._USE_MASKED_TOPK = masked
-                    return ops.score_topk_excl(U, E, 20, ptr, colsx, 1)
+                    return ops.score_topk_excl(U, E, 20, ptr, colsx, 1, h_max=hmax)
                 cases[f"score_topk_excl k=20 B=4096 N=50000 hist~{hmean} max {hmax} {'masked' if masked else 'k+h_max'}"] = (run, Bs * Ns, 0, 2 * D)
     if args.only.startswith("score_topk prepared"):  # catalogue converted once (knn search table, evaluation item table)
         catE = ops.TopkCatalogue(E)
@@ -205,14 +205,37 @@ def main():
             U_ = torch.randn(b_, D, device=dev)
             E_ = torch.randn(n_, D, device=dev)
             cases[f"score_topk sweep k={k_} B={b_} N={n_}"] = (lambda i, U_=U_, E_=E_, k_=k_: ops.score_topk(U_, E_, k_, 1), b_ * n_, 0, 2 * D)
+    # Bytes a case really MOVES where that differs from SURVEY 8(d)'s algorithmic count: the slsh kernels
+    # serve the bucket row from LDS (the reference's arithmetic reaches H + 1 rows only), so 8 + 4F + 4D cross HBM, not
+    # 8 + 4F + 8D; the fused score entries are handed user ROWS, not user ids (524 of the 532 bytes).  A roofline fraction
+    # is printed on the moved bytes, and never above 1: a figure beyond the peak is an accounting error, not evidence.
+    moved = {}
+    for name in cases:
+        if name.startswith("slsh_embed"):
+            d = 128 if "D=128" in name else D
+            moved[name] = 8 + 4 * F + 4 * d
+        elif "score" in name and name.startswith(("lsh_embed_score", "lsh_lookup_multi score")):
+            moved[name] = 8 + 4 * F + 4 * D + 4
+    HBM_PEAK = 8000.0
     with torch.no_grad():
         for name, (fn, units, bpu, fpu) in cases.items():
             if args.only and not any(o in name for o in args.only.split(",")):
                 continue
             us = timeit(fn, args.iters if units < 10 ** 8 else 5)
-            print(json.dumps({"case": name, "us_per_launch": round(us, 2), "units_per_launch": units,
-                              "GB_per_s": round(units * bpu / us / 1e3, 1), "TFLOP_per_s": round(units * fpu / us / 1e6, 2),
-                              "M_units_per_s": round(units / us, 1)}), flush=True)
+            bmoved = moved.get(name, bpu)
+            gbs_moved = units * bmoved / us / 1e3
+            line = {"case": name, "us_per_launch": round(us, 2), "units_per_launch": units,
+                    "GB_per_s_survey": round(units * bpu / us / 1e3, 1), "GB_per_s_moved": round(gbs_moved, 1),
+                    "bytes_per_unit_survey": bpu, "bytes_per_unit_moved": bmoved,
+                    "TFLOP_per_s": round(units * fpu / us / 1e6, 2), "M_units_per_s": round(units / us, 1)}
+            if bpu:
+                if gbs_moved > HBM_PEAK:  # refused: no fraction is printed for it
+                    line["frac_of_hbm_peak_moved"] = None
+                    line["accounting_error"] = (f"{gbs_moved:.0f} GB/s on MOVED bytes exceeds the {HBM_PEAK:.0f} GB/s peak: the byte "
+                                                "count of this case is wrong, or its inputs were served by the Infinity Cache")
+                else:
+                    line["frac_of_hbm_peak_moved"] = round(gbs_moved / HBM_PEAK, 3)
+            print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":
