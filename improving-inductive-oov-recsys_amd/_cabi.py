@@ -30,6 +30,9 @@ _SIGNATURES = {
     "mi_oov_lsh_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp]),
     "mi_oov_lsh_backward_workspace": (_i64, [_i64, _i64, _i64]),
     "mi_oov_lsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "mi_oov_lsh_backward_fused_workspace": (_i64, [_i64, _i64, _i64]),
+    "mi_oov_lsh_embed_backward_fused": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "mi_oov_slsh_embed_backward_fused": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_score_topk_excl_workspace": (_i64, [_i64, _i64, _i64, _i64]),
     "mi_oov_score_topk_excl": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_score_topk_masked_workspace": (_i64, [_i64, _i64, _i64, _i64]),
@@ -42,6 +45,8 @@ _SIGNATURES = {
     "mi_oov_topk_hits_range": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i64, _vp, _vp]),
     "mi_oov_eval_rows_build": (ctypes.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_segment_dedup": (ctypes.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "mi_oov_topk_metric_sums_workspace": (_i64, [_i64, _i64]),
+    "mi_oov_topk_metric_sums": (ctypes.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, ctypes.c_int, _vp, _vp, _vp, _vp]),
     "mi_oov_score_topk_excl_dense_workspace": (_i64, [_i64, _i64]),
     "mi_oov_score_topk_excl_dense": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_slsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),

@@ -145,9 +145,123 @@ __global__ __launch_bounds__(kBlock) void segment_dedup_kernel(const int64_t* __
   }
 }
 
+// ---- the TopkMetric family on the device (R/evaluator/metrics.py:36-235, base_metric.py:60-84) -----------------------------
+// The reference turns the collected rec.topk block int[U, K+1] into per-user curves for k = 1..K in float64 NumPy and averages
+// them over the users whose curve holds no NaN.  On the host that arithmetic was what an evaluation run waited for once the
+// kernels around it were quick (36 000 users x 9 collectors x 5 metrics: 0.1 s of NumPy).  Here:
+//   phase 1, one THREAD per user: the six curves exactly as NumPy computes a row -- sequential cumsums over k, int -> double
+//            true divisions, the discount table 1 / log2(rank + 1) and its cumsum handed over FROM the host's NumPy (so
+//            not an ulp of libm differs), -ffp-contract=off;
+//   phase 2, one WAVE per (user side, metric), lane = rank k: the column sums over the selected users added ONE USER AFTER
+//            THE OTHER in user order -- the order of NumPy's reduction over the leading axis -- so the sums, and with them
+//            the means, are the float64 values NumPy returns, bit for bit (tests/test_eval_rows.py checks exactly that).
+// Metric ids: 0 recall, 1 hit, 2 precision, 3 ndcg, 4 mrr, 5 map.  Only recall has NaN rows (no positive: 0 / 0).
+constexpr int kNumMetrics = 6;
+
+__global__ __launch_bounds__(kBlock) void topk_metric_curves_kernel(const int32_t* __restrict__ rec, int64_t U, int K,
+                                                                    const double* __restrict__ disc, const double* __restrict__ idcg_base,
+                                                                    double* __restrict__ val, uint8_t* __restrict__ nanrow) {
+  for (int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; u < U; u += static_cast<int64_t>(gridDim.x) * kBlock) {
+    const int32_t* r = rec + u * (K + 1);
+    const int64_t pos_len = r[K];
+    const int64_t n = pos_len < K ? pos_len : K;  // np.minimum(pos_len, K)
+    nanrow[u] = pos_len == 0 ? 1 : 0;
+    int64_t cum = 0;
+    int first = -1;
+    double dcg = 0.0, sum_pre = 0.0;
+    for (int k = 0; k < K; ++k) {
+      const bool h = r[k] != 0;  // rec[:, :-1].astype(bool)
+      cum += h ? 1 : 0;
+      if (h && first < 0) first = k;
+      const double prec = static_cast<double>(cum) / static_cast<double>(k + 1);
+      dcg = dcg + (h ? disc[k] : 0.0);
+      sum_pre = sum_pre + prec * (h ? 1.0 : 0.0);
+      const int cap = static_cast<int>(n <= 0 ? K - 1 : (k < n - 1 ? k : n - 1));  // NumPy's index -1 wraps to the last entry
+      double* v = val + u * K + k;
+      const int64_t plane = U * K;
+      v[0 * plane] = static_cast<double>(cum) / static_cast<double>(pos_len);  // 0 / 0 -> NaN: the row is dropped (nanrow)
+      v[1 * plane] = cum > 0 ? 1.0 : 0.0;
+      v[2 * plane] = prec;
+      v[3 * plane] = dcg / idcg_base[cap];
+      v[4 * plane] = first >= 0 ? 1.0 / static_cast<double>(first + 1) : 0.0;
+      v[5 * plane] = sum_pre / static_cast<double>(cap + 1);
+    }
+  }
+}
+
+// side 0: every user; 1: users with id < n_old_users; 2: the others
+__global__ __launch_bounds__(64) void topk_metric_sums_kernel(const double* __restrict__ val, const uint8_t* __restrict__ nanrow,
+                                                              const int64_t* __restrict__ uids, int64_t n_old_users, int64_t U, int K,
+                                                              double* __restrict__ sums, int64_t* __restrict__ counts) {
+  const int side = blockIdx.x / kNumMetrics, m = blockIdx.x % kNumMetrics;
+  const int lane = threadIdx.x;
+  const double* v = val + static_cast<int64_t>(m) * U * K;
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};  // ranks lane, lane + 64, lane + 128, lane + 192 (K <= 256)
+  int64_t cnt = 0;
+  constexpr int R = 8;  // users whose loads are in flight together
+  for (int64_t u0 = 0; u0 < U; u0 += R) {
+    double x[R][4];
+    bool sel[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int64_t u = u0 + j;
+      const bool live = u < U;
+      const int64_t uc = live ? u : U - 1;
+      bool s = live;
+      if (side != 0) s = s && ((uids[uc] < n_old_users) == (side == 1));
+      if (m == 0) s = s && nanrow[uc] == 0;
+      sel[j] = s;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) x[j][q] = (lane + 64 * q < K) ? v[uc * K + lane + 64 * q] : 0.0;
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+      if (sel[j]) {  // wave-uniform
+        ++cnt;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = acc[q] + x[j][q];
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (lane + 64 * q < K) sums[(static_cast<int64_t>(side) * kNumMetrics + m) * K + lane + 64 * q] = acc[q];
+  if (lane == 0) counts[side * kNumMetrics + m] = cnt;
+}
+
 }  // namespace mi_oov
 
 using namespace mi_oov;
+
+extern "C" int64_t mi_oov_topk_metric_sums_workspace(int64_t U, int64_t K) {
+  if (U <= 0 || K <= 0) return 0;
+  return (kNumMetrics * U * K * 8 + U + 255) / 256 * 256;
+}
+
+extern "C" int mi_oov_topk_metric_sums(const int32_t* rec, int64_t U, int64_t K, const double* disc, const double* idcg_base,
+                                       const int64_t* uids, int64_t n_old_users, int n_sides, double* sums, int64_t* counts,
+                                       void* workspace, void* stream) {
+  if (U < 0 || K <= 0 || K > 256 || (n_sides != 1 && n_sides != 3)) return MI_OOV_ERR_SHAPE;
+  if (!sums || !counts) return MI_OOV_ERR_NULL;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (U == 0) {
+    if (hipMemsetAsync(sums, 0, static_cast<size_t>(n_sides) * kNumMetrics * K * 8, st) != hipSuccess ||
+        hipMemsetAsync(counts, 0, static_cast<size_t>(n_sides) * kNumMetrics * 8, st) != hipSuccess) {
+      check_launch();
+      return MI_OOV_ERR_LAUNCH;
+    }
+    return MI_OOV_OK;
+  }
+  if (!rec || !disc || !idcg_base || !workspace || (n_sides == 3 && !uids)) return MI_OOV_ERR_NULL;
+  if ((reinterpret_cast<uintptr_t>(workspace) & 7u) != 0) return MI_OOV_ERR_ALIGN;
+  double* val = static_cast<double*>(workspace);
+  uint8_t* nanrow = reinterpret_cast<uint8_t*>(val + kNumMetrics * U * K);
+  hipLaunchKernelGGL(topk_metric_curves_kernel, dim3(grid_for(U, kBlock)), dim3(kBlock), 0, st, rec, U, static_cast<int>(K), disc, idcg_base,
+                     val, nanrow);
+  if (int rc = check_launch()) return rc;
+  hipLaunchKernelGGL(topk_metric_sums_kernel, dim3(static_cast<unsigned>(n_sides * kNumMetrics)), dim3(64), 0, st, val, nanrow, uids,
+                     n_old_users, U, static_cast<int>(K), sums, counts);
+  return check_launch();
+}
 
 extern "C" int mi_oov_eval_rows_build(const int64_t* pos_ptr, int64_t n_users, const int64_t* user_ids, const int64_t* pos_items,
                                       const int64_t* neg_items, int64_t n_neg, int64_t* row_user, int64_t* row_item,

@@ -406,6 +406,143 @@ __global__ __launch_bounds__(kBlock) void lsh_bwd_final_kernel(const float* __re
   if (lane == 0) gradW[(h0 + j) * D + d] = s;
 }
 
+// ---- round 4: the same reduction in ONE launch ----------------------------------------------------------
+// The two launches above cost 9.6 + 7.2 us per 65536 lookups (slsh with 9 buckets: two passes over the batch = four
+// launches, 28.8 us) for 17 MB of gradient rows: launch latency, and a final pass whose lanes read the partials 2 KB apart.
+// Here a workgroup writes the partials of its partitions for ALL planes (a second group of eight planes re-reads the
+// partition's 16 KB from L1 / L2), publishes them (release fence + ticket), and the LAST `nfin` workgroups to arrive
+// each finish a share of the columns once every partial is there: 16 consecutive columns per chunk (64 contiguous bytes
+// of every partial row), thread (lsub, c) adding the partials p = l, l + 64, ... of sum-lanes l = lsub, lsub + 16,
+// lsub + 32, lsub + 48 in increasing p, then the oracle's stride-halving tree over the 64 lane sums in LDS.  Same values
+// added in the same order as the two-launch form (and as oracle/oov_oracle.c::oov_lsh_embed_backward): bit-identical.
+// A finisher that arrives early spins on the ticket counter; at most nfin - 1 <= 63 workgroups ever wait, each for
+// workgroups that are running or still to be dispatched, so the grid always drains.  `counters` (u32[2], caller-owned) must
+// be zero at launch and is zero again when the kernel ends: the last finisher resets it.
+constexpr int kFinCols = 16, kFinMax = 64;
+
+template <bool VEC, bool ONEHOT, bool FAST8>
+__global__ __launch_bounds__(kBlock) void lsh_bwd_fused_kernel(const uint8_t* __restrict__ bits, const int64_t* __restrict__ idx,
+                                                               const float* __restrict__ g, int64_t B, int64_t H, int64_t D,
+                                                               float* partial, unsigned* counters, int nfin,
+                                                               float* __restrict__ gradW) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [16][kBwdH][DP]; the finishers' [64][kFinCols] lane sums
+  __shared__ unsigned s_ticket;
+  const int gr = threadIdx.x >> 4, l16 = threadIdx.x & 15;
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  const int DP = dchunks * 64;
+  const int64_t RP = col_part_rows(B);
+  const int64_t P = (B + RP - 1) / RP;
+  const int64_t HP = (H + kBwdH - 1) / kBwdH * kBwdH;  // planes per partial row, padded to whole groups of eight
+  for (int64_t part = blockIdx.x; part < P; part += gridDim.x) {
+    const int64_t r0 = part * RP;
+    const int64_t r1 = (r0 + RP < B) ? r0 + RP : B;
+    for (int64_t h0 = 0; h0 < H; h0 += kBwdH) {
+      const int nh = static_cast<int>((H - h0) < kBwdH ? (H - h0) : kBwdH);
+      for (int c = 0; c < dchunks; ++c) {
+        const int e = (c * 16 + l16) * 4;
+        float4 acc[kBwdH];
+#pragma unroll
+        for (int j = 0; j < kBwdH; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int64_t rb = r0 + gr; rb < r1; rb += 64) {  // 4 rows of this thread per round, every load first
+          float4 tv[4];
+          uint64_t wv[4];   // FAST8: the row's eight bits; ONEHOT: its bucket index relative to h0
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t r = rb + 16 * q;
+            const bool live = r < r1;
+            tv[q] = live ? load4<VEC>(g + r * D, e, D) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (FAST8) wv[q] = live ? *reinterpret_cast<const uint64_t*>(bits + r * 8) : 0ull;
+            else if constexpr (ONEHOT) wv[q] = live ? static_cast<uint64_t>(idx[r] - h0) : ~0ull;
+            else wv[q] = 0ull;
+          }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int64_t r = rb + 16 * q;
+            if (r >= r1) break;
+            float4 t = tv[q];
+            if constexpr (FAST8) {
+              uint64_t sum = (wv[q] & 0x00FF00FF00FF00FFull) + ((wv[q] >> 8) & 0x00FF00FF00FF00FFull);
+              sum = (sum & 0x0000FFFF0000FFFFull) + ((sum >> 16) & 0x0000FFFF0000FFFFull);
+              const float cnt = static_cast<float>(static_cast<uint32_t>(sum) + static_cast<uint32_t>(sum >> 32));
+              t = div4_by_count(t, cnt);
+            } else if constexpr (!ONEHOT) {
+              float cnt = 0.f;
+              for (int64_t h = 0; h < H; ++h) cnt = cnt + static_cast<float>(bits[r * H + h]);
+              t.x = t.x / cnt; t.y = t.y / cnt; t.z = t.z / cnt; t.w = t.w / cnt;
+            }
+#pragma unroll
+            for (int j = 0; j < kBwdH; ++j) {
+              if (j < nh) {
+                float bit;
+                if constexpr (FAST8) bit = static_cast<float>(static_cast<uint32_t>(wv[q] >> (8 * j)) & 0xFFu);
+                else if constexpr (ONEHOT) bit = (wv[q] == static_cast<uint64_t>(j)) ? 1.f : 0.f;
+                else bit = static_cast<float>(bits[r * H + h0 + j]);
+                acc[j].x = __builtin_fmaf(bit, t.x, acc[j].x);
+                acc[j].y = __builtin_fmaf(bit, t.y, acc[j].y);
+                acc[j].z = __builtin_fmaf(bit, t.z, acc[j].z);
+                acc[j].w = __builtin_fmaf(bit, t.w, acc[j].w);
+              }
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < kBwdH; ++j) *reinterpret_cast<float4*>(red + (gr * kBwdH + j) * DP + e) = acc[j];
+      }
+      __syncthreads();
+      for (int i = threadIdx.x; i < nh * D; i += kBlock) {
+        const int j = i / static_cast<int>(D), d = i % static_cast<int>(D);
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += red[(q * kBwdH + j) * DP + d];
+        partial[(part * HP + h0 + j) * D + d] = s;
+      }
+      __syncthreads();
+    }
+  }
+  // publish: every partial of this workgroup is visible device-wide before its ticket is
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned G = gridDim.x;
+  const unsigned ticket = s_ticket;
+  if (ticket + static_cast<unsigned>(nfin) < G) return;  // not one of the last nfin to arrive
+  const int f = static_cast<int>(ticket - (G - static_cast<unsigned>(nfin)));
+  if (threadIdx.x == 0)
+    while (__hip_atomic_load(&counters[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < G) __builtin_amdgcn_s_sleep(2);
+  __syncthreads();
+  __threadfence();  // (acquire for every thread of the workgroup: the partials are read below, not by thread 0 alone)
+  const int64_t cols = H * D;  // flattened (plane, column): plane h, column d at h * D + d of a partial row of HP * D floats
+  const int64_t nchunks = (cols + kFinCols - 1) / kFinCols;
+  float* lanes = red;  // [64][kFinCols]
+  const int cl = threadIdx.x & (kFinCols - 1), lsub = threadIdx.x >> 4;
+  for (int64_t ch = f; ch < nchunks; ch += nfin) {
+    const int64_t col = ch * kFinCols + cl;
+    const float* src = partial + (col < cols ? col : 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int l = lsub + 16 * q;
+      float s = 0.f;
+      for (int64_t p = l; p < P; p += 64) s += src[p * HP * D];
+      lanes[l * kFinCols + cl] = s;
+    }
+    __syncthreads();
+    for (int stride = 32; stride >= 1; stride >>= 1) {
+      for (int i = threadIdx.x; i < stride * kFinCols; i += kBlock) lanes[i] = lanes[i] + lanes[i + stride * kFinCols];
+      __syncthreads();
+    }
+    if (threadIdx.x < kFinCols && col < cols) gradW[col] = lanes[cl];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {  // the last finisher leaves the counters at zero for the next launch
+    const unsigned done = __hip_atomic_fetch_add(&counters[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (done + 1u == static_cast<unsigned>(nfin)) {
+      __hip_atomic_store(&counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&counters[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // ---- context models: fused-table token gather with the user/item OOV splice ---------------------
 // InductiveContextRecommender.embed_token_fields (abstract_recommender.py:794-842) and
 // InductiveFMFirstOrderLinear.embed_token_fields (layers.py:1634-1693): row (b, f) is
@@ -562,6 +699,58 @@ extern "C" int mi_oov_slsh_embed_backward(const int64_t* idx, const float* grad_
 extern "C" int mi_oov_lsh_embed_backward(const uint8_t* bits, const float* grad_out, int64_t B, int64_t H, int64_t D,
                                          float* grad_buckets, float* workspace, void* stream) {
   return run_lsh_bwd(bits, nullptr, grad_out, B, H, D, grad_buckets, workspace, static_cast<hipStream_t>(stream));
+}
+
+// one launch: partials + last-workgroups-done final reduction (lsh_bwd_fused_kernel)
+extern "C" int64_t mi_oov_lsh_backward_fused_workspace(int64_t B, int64_t H, int64_t D) {
+  if (B <= 0 || H <= 0 || D <= 0) return 0;
+  const int64_t RP = col_part_rows(B);
+  return ((B + RP - 1) / RP) * ((H + kBwdH - 1) / kBwdH * kBwdH) * D;  // floats
+}
+
+static int run_lsh_bwd_fused(const uint8_t* bits, const int64_t* idx, const float* grad_out, int64_t B, int64_t H, int64_t D,
+                             float* grad_buckets, float* workspace, uint32_t* counters, hipStream_t st) {
+  if (B < 0 || H <= 0 || D <= 0 || D > 256) return MI_OOV_ERR_SHAPE;
+  if (!grad_buckets) return MI_OOV_ERR_NULL;
+  if (B == 0) {
+    if (hipMemsetAsync(grad_buckets, 0, static_cast<size_t>(H * D) * sizeof(float), st) != hipSuccess) {
+      check_launch();
+      return MI_OOV_ERR_LAUNCH;
+    }
+    return MI_OOV_OK;
+  }
+  if ((!bits && !idx) || !grad_out || !workspace || !counters) return MI_OOV_ERR_NULL;
+  const int64_t RP = col_part_rows(B);
+  const int64_t P = (B + RP - 1) / RP;
+  const int dchunks = static_cast<int>((D + 63) / 64);
+  size_t lds = static_cast<size_t>(16) * kBwdH * dchunks * 64 * sizeof(float);
+  if (lds < 64 * kFinCols * sizeof(float)) lds = 64 * kFinCols * sizeof(float);
+  const bool vec = (D % 4 == 0) && aligned16(grad_out);
+  const bool fast8 = !idx && H == 8 && vec && (reinterpret_cast<uintptr_t>(bits) & 7u) == 0;
+  const int64_t nchunks = (H * D + kFinCols - 1) / kFinCols;
+  int nfin = static_cast<int>(nchunks < kFinMax ? nchunks : kFinMax);
+  if (nfin > P) nfin = static_cast<int>(P);
+  auto k = idx ? (vec ? lsh_bwd_fused_kernel<true, true, false> : lsh_bwd_fused_kernel<false, true, false>)
+               : fast8 ? lsh_bwd_fused_kernel<true, false, true>
+                       : (vec ? lsh_bwd_fused_kernel<true, false, false> : lsh_bwd_fused_kernel<false, false, false>);
+  if (int rc = set_lds(k, lds)) return rc;
+  hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(P)), dim3(kBlock), lds, st, bits, idx, grad_out, B, H, D, workspace, counters, nfin,
+                     grad_buckets);
+  return check_launch();
+}
+
+extern "C" int mi_oov_lsh_embed_backward_fused(const uint8_t* bits, const float* grad_out, int64_t B, int64_t H, int64_t D,
+                                               float* grad_buckets, float* workspace, uint32_t* counters, void* stream) {
+  return run_lsh_bwd_fused(bits, nullptr, grad_out, B, H, D, grad_buckets, workspace, counters, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mi_oov_slsh_embed_backward_fused(const int64_t* idx, const float* grad_out, int64_t B, int64_t n_buckets, int64_t D,
+                                                float* grad_buckets, float* workspace, uint32_t* counters, void* stream) {
+  if (B < 0 || n_buckets <= 0 || D <= 0) return MI_OOV_ERR_SHAPE;
+  if (!grad_buckets) return MI_OOV_ERR_NULL;
+  if (n_buckets <= 64 && D <= 256)
+    return run_lsh_bwd_fused(nullptr, idx, grad_out, B, n_buckets, D, grad_buckets, workspace, counters, static_cast<hipStream_t>(stream));
+  return mi_oov_slsh_embed_backward(idx, grad_out, B, n_buckets, D, grad_buckets, workspace, stream);  // memset + float atomics
 }
 
 static int run_lsh_bwd(const uint8_t* bits, const int64_t* idx, const float* grad_out, int64_t B, int64_t H, int64_t D,

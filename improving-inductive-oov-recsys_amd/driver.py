@@ -306,16 +306,15 @@ def evaluate(model, users, items, tot_items, cfg, n_users, n_items, device, gen)
     order = torch.argsort(users, stable=True)
     su, si = users[order], items[order]
     uniq, counts = torch.unique_consecutive(su, return_counts=True)
-    counts_h = counts.tolist()  # the run's one device -> host copy: the batch plan is made on the host
+    cum_h = np.cumsum(counts.cpu().numpy())  # the run's one device -> host copy: the batch plan is made on the host
     budget = int(cfg["eval_batch_size"])
     group_rows = max(budget, int(cfg["eval_rows_per_launch"] or (1 << 22)))
-    # plan: batches of whole users with at most `budget` rows (a user with more rows is a batch of its own) ...
-    batches, lo_u, pos_lo = [], 0, 0
-    while lo_u < len(counts_h):
-        hi_u, npos = lo_u + 1, counts_h[lo_u]
-        while hi_u < len(counts_h) and (npos + counts_h[hi_u]) * (1 + nneg) <= budget:
-            npos += counts_h[hi_u]
-            hi_u += 1
+    # plan: batches of whole users with at most `budget` rows (a user with more rows is a batch of its own): one binary
+    # search per BATCH over the cumulative counts (a Python loop over the users was 15 ms of a 10 M-row evaluation) ...
+    batches, lo_u, pos_lo, per_batch = [], 0, 0, budget // (1 + nneg)
+    while lo_u < len(cum_h):
+        hi_u = max(lo_u + 1, int(np.searchsorted(cum_h, pos_lo + per_batch, side="right")))
+        npos = int(cum_h[hi_u - 1]) - pos_lo
         batches.append((lo_u, hi_u, pos_lo, npos))
         lo_u, pos_lo = hi_u, pos_lo + npos
     # ... and groups of consecutive batches of at most `group_rows` rows, each ONE model.predict / evaluator call

@@ -71,17 +71,46 @@ class _LshEmbed(torch.autograd.Function):
         return None, None, None, lsh_embed_backward(bits, g)
 
 
+_BWD_COUNTERS = {}  # (device index, raw stream) -> u32[2] zeros: the fused backward kernels leave them at zero
+
+
+def _bwd_counters(t):
+    """The two ticket words of mi_oov_*_embed_backward_fused for the current stream of t's device: zero at first use, left
+    zero by every launch, one pair per stream (launches on one stream are ordered; on two streams they may overlap).
+    While a HIP graph is being captured a fresh zeroed pair is made inside the capture instead (the cached pair must not
+    end up in a graph's private pool)."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.zeros((2,), dtype=torch.int32, device=t.device)
+    key = (t.device.index, C.stream_of(t))
+    c = _BWD_COUNTERS.get(key)
+    if c is None:
+        c = _BWD_COUNTERS[key] = torch.zeros((2,), dtype=torch.int32, device=t.device)
+    return c
+
+
+def _bwd_fused():
+    return os.environ.get("MI_OOV_BWD_FUSED", "1") != "0"  # developer A/B knob: 0 = the two-launch reductions
+
+
 def lsh_embed_backward(bits, grad_out):
     """d/dW of (bits @ W) / bits.sum(1): grad_W = bits^T @ (g / popcount); a popcount-0 row gives NaN like the
-    reference's autograd.  Deterministic two-pass kernel (mi_oov_lsh_embed_backward)."""
+    reference's autograd.  Deterministic; ONE launch (mi_oov_lsh_embed_backward_fused: partial sums per row partition,
+    the last workgroups to arrive add them up) -- bit-identical to the two-launch mi_oov_lsh_embed_backward."""
     bits = C.dev_tensor(bits, torch.uint8, "bits")
     g = _f32(grad_out, "grad_out")
     (B, H), D = bits.shape, g.shape[1]
     if g.shape[0] != B:
         raise ValueError(f"grad_out has {g.shape[0]} rows, bits {B}")
     lib = C.lib()
-    ws = torch.empty((max(int(lib.mi_oov_lsh_backward_workspace(B, H, D)), 1),), dtype=torch.float32, device=g.device)
     out = torch.empty((H, D), dtype=torch.float32, device=g.device)
+    if _bwd_fused():
+        ws = torch.empty((max(int(lib.mi_oov_lsh_backward_fused_workspace(B, H, D)), 1),), dtype=torch.float32, device=g.device)
+        cnt = _bwd_counters(g)
+        with C.on_device(g):
+            rc = lib.mi_oov_lsh_embed_backward_fused(C.ptr(bits), C.ptr(g), B, H, D, C.ptr(out), C.ptr(ws), C.ptr(cnt), C.stream_of(g))
+        C.check(rc, "mi_oov_lsh_embed_backward_fused")
+        return out
+    ws = torch.empty((max(int(lib.mi_oov_lsh_backward_workspace(B, H, D)), 1),), dtype=torch.float32, device=g.device)
     with C.on_device(g):
         rc = lib.mi_oov_lsh_embed_backward(C.ptr(bits), C.ptr(g), B, H, D, C.ptr(out), C.ptr(ws), C.stream_of(g))
     C.check(rc, "mi_oov_lsh_embed_backward")
@@ -687,13 +716,21 @@ class _SlshEmbed(torch.autograd.Function):
 
 
 def slsh_embed_backward(idx, grad_out, n_buckets):
-    """grad of buckets[idx] w.r.t. buckets (mi_oov_slsh_embed_backward): deterministic for n_buckets <= 64."""
+    """grad of buckets[idx] w.r.t. buckets: deterministic for n_buckets <= 64 -- one launch for every bucket
+    (mi_oov_slsh_embed_backward_fused; the two-launch form walks the batch once per eight buckets) --, float atomics above."""
     idx, g = _ids(idx, "idx"), _f32(grad_out, "grad_out")
     B, D = g.shape
     lib = C.lib()
+    out = torch.empty((n_buckets, D), dtype=torch.float32, device=g.device)
+    if _bwd_fused():
+        ws = torch.empty((max(int(lib.mi_oov_lsh_backward_fused_workspace(B, min(n_buckets, 64), D)), 1),), dtype=torch.float32, device=g.device)
+        cnt = _bwd_counters(g)
+        with C.on_device(g):
+            rc = lib.mi_oov_slsh_embed_backward_fused(C.ptr(idx), C.ptr(g), B, n_buckets, D, C.ptr(out), C.ptr(ws), C.ptr(cnt), C.stream_of(g))
+        C.check(rc, "mi_oov_slsh_embed_backward_fused")
+        return out
     ws = torch.empty((max(int(lib.mi_oov_lsh_backward_workspace(B, min(n_buckets, 64), D)), 1),), dtype=torch.float32,
                      device=g.device)
-    out = torch.empty((n_buckets, D), dtype=torch.float32, device=g.device)
     with C.on_device(g):
         rc = lib.mi_oov_slsh_embed_backward(C.ptr(idx), C.ptr(g), B, n_buckets, D, C.ptr(out), C.ptr(ws), C.stream_of(g))
     C.check(rc, "mi_oov_slsh_embed_backward")
@@ -1349,6 +1386,35 @@ def eval_rows_build(pos_ptr, user_ids, pos_items, neg_items, n_neg, want_pos_use
                                             C.ptr(row_user), C.ptr(row_item), C.ptr(seg_ptr), C.ptr(pos_user), C.stream_of(pos_items))
     C.check(rc, "mi_oov_eval_rows_build")
     return (row_user, row_item, seg_ptr, pos_user) if want_pos_user else (row_user, row_item, seg_ptr)
+
+
+METRIC_IDS = {"recall": 0, "hit": 1, "precision": 2, "ndcg": 3, "mrr": 4, "map": 5}
+
+
+def topk_metric_sums(rec, disc, idcg_base, uids=None, n_old_users=0):
+    """Column sums of the TopkMetric curves of a rec.topk block over its users, in user order (mi_oov_topk_metric_sums;
+    R/evaluator/metrics.py:36-235): rec i32[U, K+1] on the device, disc / idcg_base f64[K] device tensors made from the
+    host's NumPy values -> (sums f64[n_sides, 6, K], counts i64[n_sides, 6]) on the device; n_sides = 3 (all users, users
+    with uids < n_old_users, the others) when uids is given, else 1.  sums / counts are the means NumPy computes, bit for
+    bit."""
+    rec = C.dev_tensor(rec, torch.int32, "rec")
+    disc, idcg_base = C.dev_tensor(disc, torch.float64, "disc"), C.dev_tensor(idcg_base, torch.float64, "idcg_base")
+    U, K = rec.shape[0], rec.shape[1] - 1
+    if disc.numel() != K or idcg_base.numel() != K:
+        raise ValueError(f"disc and idcg_base must have {K} entries")
+    n_sides = 1 if uids is None else 3
+    if uids is not None:
+        uids = _ids(uids, "uids")
+        if uids.numel() != U:
+            raise ValueError(f"uids has {uids.numel()} entries, rec {U} rows")
+    sums = torch.empty((n_sides, 6, K), dtype=torch.float64, device=rec.device)
+    counts = torch.empty((n_sides, 6), dtype=torch.int64, device=rec.device)
+    ws = torch.empty((max(int(C.lib().mi_oov_topk_metric_sums_workspace(U, K)), 8),), dtype=torch.uint8, device=rec.device)
+    with C.on_device(rec):
+        rc = C.lib().mi_oov_topk_metric_sums(C.ptr(rec), U, K, C.ptr(disc), C.ptr(idcg_base), C.ptr(uids), int(n_old_users), n_sides,
+                                             C.ptr(sums), C.ptr(counts), C.ptr(ws), C.stream_of(rec))
+    C.check(rc, "mi_oov_topk_metric_sums")
+    return sums, counts
 
 
 def segment_dedup(cols, seg_ptr):

@@ -92,6 +92,20 @@ int mi_oov_lsh_embed_backward(const uint8_t* bits, const float* grad_out, int64_
 int mi_oov_slsh_embed_backward(const int64_t* idx, const float* grad_out, int64_t B, int64_t n_buckets, int64_t D,
                                float* grad_buckets, float* workspace, void* stream);
 
+/* The same two gradients in ONE launch (round 4): a workgroup writes the partial sums of its row partitions for every
+ * plane, and the last workgroups to arrive add the partials up -- the same values in the same order, so the results are
+ * bit-identical to the two-launch entry points above (and to oracle/oov_oracle.c).
+ *   workspace f32[mi_oov_lsh_backward_fused_workspace(B, H or n_buckets, D)];
+ *   counters u32[2], caller-owned device memory that is ZERO at the first launch and is left zero by every launch (the
+ *   last workgroup resets it): allocate once, zero once, reuse -- also across HIP-graph replays.  Two launches that may
+ *   run at the same time (different streams) need different counters.
+ * slsh with more than 64 buckets or D > 256: as mi_oov_slsh_embed_backward (memset + float atomics; counters unused). */
+int64_t mi_oov_lsh_backward_fused_workspace(int64_t B, int64_t H, int64_t D); /* number of floats */
+int mi_oov_lsh_embed_backward_fused(const uint8_t* bits, const float* grad_out, int64_t B, int64_t H, int64_t D,
+                                    float* grad_buckets, float* workspace, uint32_t* counters, void* stream);
+int mi_oov_slsh_embed_backward_fused(const int64_t* idx, const float* grad_out, int64_t B, int64_t n_buckets, int64_t D,
+                                     float* grad_buckets, float* workspace, uint32_t* counters, void* stream);
+
 /* out[idx[m],:] += g[m,:] with hardware float atomics (summation order not fixed): the backward of every
  * row gather on the path (mi_oov_gather_rows, mi_oov_splice_rows, knn's gather_mean after scaling).
  *   idx i64[M] (entries outside [0,N) are skipped); g f32[M,D]; out f32[N,D] (accumulated into).       */
@@ -448,6 +462,19 @@ int mi_oov_eval_rows_build(const int64_t* pos_ptr, int64_t n_users, const int64_
  * negative columns whenever it is given a column range, e.g. [0, 2^62 - 1)).  cols i64[M], seg_ptr i64[S+1] -> out i64[M];
  * out must not be cols (MI_OOV_ERR_ALIAS).  Any segment length, no workspace.                                      */
 int mi_oov_segment_dedup(const int64_t* cols, const int64_t* seg_ptr, int64_t S, int64_t* out, void* stream);
+
+/* The TopkMetric family (R/evaluator/metrics.py:36-235, base_metric.py:60-84) on a rec.topk block rec i32[U, K+1]
+ * (mi_oov_topk_hits): per-user curves for k = 1..K in float64, summed over users IN USER ORDER -- the order of NumPy's
+ * reduction over the leading axis, so sums[...] / counts[...] are the float64 means the reference's Evaluator computes, bit
+ * for bit.  disc f64[K] = 1 / log2(rank + 1) and idcg_base f64[K] = its cumulative sum, both computed by the caller with
+ * NumPy (the reference's expressions) so that no libm ulp differs.  Metric m: 0 recall, 1 hit, 2 precision, 3 ndcg, 4 mrr,
+ * 5 map.  n_sides 1: all users; 3: all users, users with uids[u] < n_old_users, the others (uids i64[U]).
+ *   -> sums f64[n_sides, 6, K], counts i64[n_sides, 6] (users whose curve holds no NaN: recall drops users without a positive)
+ *   workspace: mi_oov_topk_metric_sums_workspace(U, K) bytes, 8-byte aligned.  K <= 256.                           */
+int64_t mi_oov_topk_metric_sums_workspace(int64_t U, int64_t K);
+int mi_oov_topk_metric_sums(const int32_t* rec, int64_t U, int64_t K, const double* disc, const double* idcg_base,
+                            const int64_t* uids, int64_t n_old_users, int n_sides, double* sums, int64_t* counts,
+                            void* workspace, void* stream);
 
 /* mi_oov_score_topk with per-user exclusions: what the collector's topk sees after InductiveEvaluator.eval_batch has
  * set scores[:,0] and scores[history_index] to -inf (R/inductive/evaluator.py:92-95).  excl_ptr i64[B+1] / excl_cols

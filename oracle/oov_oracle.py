@@ -314,6 +314,20 @@ def segment_dedup(cols, seg_ptr):
     return out
 
 
+def topk_metric_sums(rec, disc, idcg_base, uids=None, n_old_users=0):
+    """-> (sums f64[n_sides, 6, K], counts i64[n_sides, 6]); n_sides = 3 when uids is given (all / old / new users)"""
+    rec = np.ascontiguousarray(rec, dtype=np.int32)
+    disc = np.ascontiguousarray(disc, dtype=np.float64)
+    idcg_base = np.ascontiguousarray(idcg_base, dtype=np.float64)
+    U, K = rec.shape[0], rec.shape[1] - 1
+    n_sides = 1 if uids is None else 3
+    uids = None if uids is None else np.ascontiguousarray(uids, dtype=np.int64)
+    sums, counts = np.empty((n_sides, 6, K), np.float64), np.empty((n_sides, 6), np.int64)
+    lib().oov_topk_metric_sums(_p(rec), _c(U), _c(K), _p(disc), _p(idcg_base), _p(uids), _c(n_old_users), ctypes.c_int(n_sides),
+                               _p(sums), _p(counts))
+    return sums, counts
+
+
 def score_topk_excl(U, E, k, excl_ptr, excl_cols, n_skip_low=0):
     U, E = _f32(U), _f32(E)
     excl_ptr = np.ascontiguousarray(excl_ptr, dtype=np.int64)

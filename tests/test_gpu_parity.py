@@ -767,10 +767,12 @@ def test_gather_splice_vs_oracle(oracle, ops, dev):
             assert bits_equal(got, oracle.gather_mean(idx, table, g))
 
 
-@pytest.mark.parametrize("B,H,D", [(1, 8, 64), (300, 8, 64), (70000, 8, 64), (5000, 12, 64), (999, 3, 22), (4097, 40, 50)])
-def test_lsh_backward_vs_oracle(B, H, D, oracle, ops, dev):
+@pytest.mark.parametrize("fused", ["1", "0"])  # one launch with a last-workgroups-done reduction (round 4) / the two launches
+@pytest.mark.parametrize("B,H,D", [(1, 8, 64), (300, 8, 64), (70000, 8, 64), (5000, 12, 64), (999, 3, 22), (4097, 40, 50), (1 << 20, 8, 64), (65536, 17, 128)])
+def test_lsh_backward_vs_oracle(B, H, D, fused, oracle, ops, dev, monkeypatch):
     """grad of (bits @ W)/popcount w.r.t. W: bit-exact against the oracle (same two-pass order), within 1e-5
     of torch autograd on the reference's op sequence (lsh_embedder.py:158,178), NaN rows as in the reference."""
+    monkeypatch.setenv("MI_OOV_BWD_FUSED", fused)
     rng = np.random.default_rng(B + H)
     bits = (rng.random((B, H)) < 0.5).astype(np.uint8)
     bits[bits.sum(1) == 0, 0] = 1
@@ -787,21 +789,28 @@ def test_lsh_backward_vs_oracle(B, H, D, oracle, ops, dev):
         assert bits_equal(got, oracle.lsh_embed_backward(bits, g)) and np.isnan(got).all()
 
 
-@pytest.mark.parametrize("B,nb,D", [(1, 8, 64), (3000, 9, 64), (70000, 64, 64), (5000, 777, 24), (4097, 65, 50)])
-def test_slsh_backward_and_scatter(B, nb, D, oracle, ops, dev):
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("B,nb,D", [(1, 8, 64), (3000, 9, 64), (70000, 64, 64), (5000, 777, 24), (4097, 65, 50), (65536, 9, 64), (300000, 33, 128)])
+def test_slsh_backward_and_scatter(B, nb, D, fused, oracle, ops, dev, monkeypatch):
+    monkeypatch.setenv("MI_OOV_BWD_FUSED", fused)
     rng = np.random.default_rng(B + nb)
     idx = rng.integers(0, nb, B)
+    if B > 100:
+        idx[::13] = -1  # in-vocabulary rows of the training lookup: skipped
     g = rng.standard_normal((B, D)).astype(np.float32)
     got = ops.slsh_embed_backward(T(idx, dev), T(g, dev), nb).cpu().numpy()
+    live = idx >= 0
     want = np.zeros((nb, D), np.float64)
-    np.add.at(want, idx, g.astype(np.float64))
+    np.add.at(want, idx[live], g[live].astype(np.float64))
     assert np.abs(got - want).max() <= RTOL * np.abs(want).max()
-    if nb <= 64:  # deterministic path: identical to the lsh backward on one-hot codes
-        onehot = (idx[:, None] == np.arange(nb)[None]).astype(np.uint8)
-        assert bits_equal(got, oracle.lsh_embed_backward(onehot, g))
+    if nb <= 64:  # deterministic path: identical to the lsh backward on one-hot codes (a skipped row = a zero row somewhere:
+        # adding +0 changes no bit, and the oracle's 0 / popcount-0 would be NaN where the kernel simply has no bucket)
+        g0 = np.where(live[:, None], g, np.float32(0.0)).astype(np.float32)
+        onehot = (np.where(live, idx, 0)[:, None] == np.arange(nb)[None]).astype(np.uint8)
+        assert bits_equal(got, oracle.lsh_embed_backward(onehot, g0))
         assert bits_equal(got, ops.slsh_embed_backward(T(idx, dev), T(g, dev), nb).cpu().numpy())
     # generic scatter: out-of-range entries are skipped, accumulation goes into the given tensor
-    idx2 = idx.copy()
+    idx2 = np.where(live, idx, 0)
     idx2[::7] = nb + 5
     idx2[1::11] = -1
     base = rng.standard_normal((nb, D)).astype(np.float32)

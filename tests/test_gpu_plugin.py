@@ -104,6 +104,18 @@ def test_slsh_embedder_class(mi, golden, dev):
     assert np.array_equal(model.user_oov_buckets.weight.grad[:, 0].cpu().numpy(), want)
 
 
+def _net_f64(x, Ws, bs):
+    """The hash net (Linear / erf-GELU ... Linear, dh_embedder.py:70-89) evaluated in float64: the witness of how far any
+    float32 evaluation order -- the reference's BLAS included -- is from the exact pre-sigmoid activations."""
+    from scipy.special import erf
+    x = np.asarray(x, np.float64)
+    for j, (W, b) in enumerate(zip(Ws, bs)):
+        x = x @ np.asarray(W, np.float64).T + np.asarray(b, np.float64)
+        if j < len(Ws) - 1:
+            x = 0.5 * x * (1.0 + erf(x / np.sqrt(2.0)))
+    return x
+
+
 @pytest.mark.parametrize("x3", ["0", "1"])  # the f32 matrix instruction (MI_OOV_LINEAR_X3=0) / the split-bf16 layers (what inference runs)
 def test_dhe_embedder_class(mi, golden, dev, tmp_path, monkeypatch, x3):
     z, s = golden("dhe.npz"), golden("siphash.json")
@@ -124,9 +136,16 @@ def test_dhe_embedder_class(mi, golden, dev, tmp_path, monkeypatch, x3):
         pre = mi.ops.hash_net_forward(emb.item_hash_net[:-1], hashes)
         out = emb.embed_item_ids(ids, None)
     assert np.array_equal(hashes.cpu().numpy(), z["hashes"])  # bit-exact integer work
-    # raw hashes (~1e7) feed the first Linear un-normalised: compare pre-sigmoid with a GEMM-order tolerance
+    # Pre-sigmoid activations (raw hashes of ~1e7 feed the first Linear un-normalised; entries of 2e4 .. 8e5) against the
+    # reference's own output at north_star's tolerance, 1e-5 RELATIVE per element.  Measured (tools/dhe_error.py,
+    # gpurun_out/r04_dhe_error.log): f32 chain 6.3e-6, split bf16 7.9e-6 per element (7.0e-7 / 8.4e-7 of the largest entry);
+    # the reference itself sits 4.7e-6 per element from an f64 evaluation of the net, this library 7.7e-6 / 9.0e-6.
     ref = z["item_pre_sigmoid"]
-    assert np.abs(pre.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max()
+    got = pre.cpu().numpy()
+    assert np.all(np.abs(got - ref) <= 1e-5 * np.abs(ref))
+    assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max()
+    f64 = _net_f64(z["hashes"], [z[f"item_hash_net__{i}__weight"] for i in (0, 2, 4, 6)], [z[f"item_hash_net__{i}__bias"] for i in (0, 2, 4, 6)])
+    assert np.all(np.abs(got - f64) <= 1e-5 * np.abs(f64))  # within 1e-5 relative of the EXACT value as well
     assert np.abs(out.cpu().numpy() - z["item_out"]).max() <= 1e-5
 
 
@@ -713,8 +732,19 @@ def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkey
             assert torch.equal(ids, keep)  # fdhe strips a COPY (feat_dh_embedder.py:182-185)
             assert np.array_equal(hashes.cpu().numpy(), z[f"{mode}_{side}_hashes"])
             assert np.allclose(x.cpu().numpy(), z[f"{mode}_{side}_input"], rtol=1e-6, atol=1e-7)
+            # Pre-sigmoid activations.  Here a per-element relative bound of 1e-5 against the reference is NOT meaningful,
+            # and the f64 witness says why: entries of magnitude ~10 sit beside sums of 1e6 (cancellation), and the
+            # reference's OWN output is up to 8.1e-5 per element away from an f64 evaluation of the same net (1.4e-7 ..
+            # 3.2e-7 of the largest entry).  So: within 1e-6 of the largest entry of the reference (measured 0 on the f32
+            # chain -- identical bits -- and <= 5.9e-7 on the split-bf16 layers; the bound before round 4 was 2e-5), and not
+            # further from the exact value than twice the reference itself (measured 1.0 x / <= 1.5 x).  The OUTPUTS, what
+            # the plugin returns, meet north_star's 1e-5.  Numbers: tools/dhe_error.py, gpurun_out/r04_dhe_error.log.
             ref = z[f"{mode}_{side}_pre_sigmoid"]
-            assert np.abs(pre.cpu().numpy() - ref).max() <= 2e-5 * np.abs(ref).max(), (mode, side)
+            got = pre.cpu().numpy()
+            assert np.abs(got - ref).max() <= 1e-6 * np.abs(ref).max(), (mode, side)
+            f64 = _net_f64(z[f"{mode}_{side}_input"], [z[f"sd__{side}_hash_net__{i}__weight"] for i in (0, 2, 4, 6)],
+                           [z[f"sd__{side}_hash_net__{i}__bias"] for i in (0, 2, 4, 6)])
+            assert np.abs(got - f64).max() <= 2.0 * np.abs(ref - f64).max(), (mode, side)
             assert np.abs(out.cpu().numpy() - z[f"{mode}_{side}_out"]).max() <= 1e-5, (mode, side)
 
 
