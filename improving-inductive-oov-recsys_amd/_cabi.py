@@ -31,6 +31,7 @@ _SIGNATURES = {
     "mi_oov_lsh_backward_workspace": (_i64, [_i64, _i64, _i64]),
     "mi_oov_lsh_embed_backward": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp]),
     "mi_oov_lsh_backward_fused_workspace": (_i64, [_i64, _i64, _i64]),
+    "mi_oov_lsh_backward_fused_counters": (_i64, []),
     "mi_oov_lsh_embed_backward_fused": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_slsh_embed_backward_fused": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_score_topk_excl_workspace": (_i64, [_i64, _i64, _i64, _i64]),

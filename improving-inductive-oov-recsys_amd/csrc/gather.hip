@@ -415,18 +415,21 @@ __global__ __launch_bounds__(kBlock) void lsh_bwd_final_kernel(const float* __re
 // of every partial row), thread (lsub, c) adding the partials p = l, l + 64, ... of sum-lanes l = lsub, lsub + 16,
 // lsub + 32, lsub + 48 in increasing p, then the oracle's stride-halving tree over the 64 lane sums in LDS.  Same values
 // added in the same order as the two-launch form (and as oracle/oov_oracle.c::oov_lsh_embed_backward): bit-identical.
-// A finisher that arrives early spins on the ticket counter; at most nfin - 1 <= 63 workgroups ever wait, each for
-// workgroups that are running or still to be dispatched, so the grid always drains.  `counters` (u32[2], caller-owned) must
-// be zero at launch and is zero again when the kernel ends: the last finisher resets it.
+// Partials cross XCDs through device-coherent stores and loads (no fence: a release fence here writes back the whole L2).
+// A finisher that is done early spins on the root counter; at most nfin <= 64 workgroups ever wait, each for workgroups
+// that are running or still to be dispatched, so the grid always drains.  `counters` (u32[mi_oov_lsh_backward_fused_counters()],
+// caller-owned) must be zero at launch and is zero again when the kernel ends: the last finisher resets it.
 constexpr int kFinCols = 16, kFinMax = 64;
+constexpr int kFinSub = 16, kCtrStride = 64;  // arrival counters, words between them; + the finishers' own counter behind them
 
+// (four workgroups per CU -- 128 registers -- so that the 1024 partitions of a 65536-row batch are ONE round: left to itself
+//  the compiler gave the finishers' 64 loads in flight 64-bit addresses each, 340 registers, one workgroup per CU, four rounds)
 template <bool VEC, bool ONEHOT, bool FAST8>
-__global__ __launch_bounds__(kBlock) void lsh_bwd_fused_kernel(const uint8_t* __restrict__ bits, const int64_t* __restrict__ idx,
+__global__ __launch_bounds__(kBlock, 4) void lsh_bwd_fused_kernel(const uint8_t* __restrict__ bits, const int64_t* __restrict__ idx,
                                                                const float* __restrict__ g, int64_t B, int64_t H, int64_t D,
                                                                float* partial, unsigned* counters, int nfin,
                                                                float* __restrict__ gradW) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [16][kBwdH][DP]; the finishers' [64][kFinCols] lane sums
-  __shared__ unsigned s_ticket;
   const int gr = threadIdx.x >> 4, l16 = threadIdx.x & 15;
   const int dchunks = static_cast<int>((D + 63) / 64);
   const int DP = dchunks * 64;
@@ -494,38 +497,64 @@ __global__ __launch_bounds__(kBlock) void lsh_bwd_fused_kernel(const uint8_t* __
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 16; ++q) s += red[(q * kBwdH + j) * DP + d];
-        partial[(part * HP + h0 + j) * D + d] = s;
+        // device-coherent (write-through) store: a finisher on another XCD reads it, and a release FENCE on this chip is a
+        // write-back of the whole L2 (122 us per launch when every workgroup issued one) -- no fence anywhere below
+        if (nfin > 0) __hip_atomic_store(&partial[(part * HP + h0 + j) * D + d], s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else partial[(part * HP + h0 + j) * D + d] = s;  // (two-launch form: the final reduction is the next kernel)
       }
       __syncthreads();
     }
   }
-  // publish: every partial of this workgroup is visible device-wide before its ticket is
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) s_ticket = __hip_atomic_fetch_add(&counters[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // publish: the partial stores of every thread are acknowledged (vmcnt) before the workgroup reports in.  Arrivals are
+  // counted on kFinSub counters (workgroup b on counter b mod kFinSub, 256 bytes apart): one address takes ~90 atomics per us.
+  if (nfin <= 0) return;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const unsigned G = gridDim.x;
-  const unsigned ticket = s_ticket;
-  if (ticket + static_cast<unsigned>(nfin) < G) return;  // not one of the last nfin to arrive
-  const int f = static_cast<int>(ticket - (G - static_cast<unsigned>(nfin)));
+  unsigned* root = counters + kFinSub * kCtrStride;
   if (threadIdx.x == 0)
-    while (__hip_atomic_load(&counters[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < G) __builtin_amdgcn_s_sleep(2);
+    __hip_atomic_fetch_add(counters + (blockIdx.x % kFinSub) * kCtrStride, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (blockIdx.x + static_cast<unsigned>(nfin) < G) return;  // the finishers are the nfin workgroups dispatched last
+  const int f = static_cast<int>(blockIdx.x - (G - static_cast<unsigned>(nfin)));
+  // thread r < kFinSub of a finisher waits for counter r to hold all of its members (the workgroups b < G with b mod kFinSub
+  // == r): the finishers read the arrival counters themselves -- a root counter bumped by each counter's last arrival was
+  // one more memory round trip on the critical path
+  if (threadIdx.x < kFinSub && threadIdx.x < G) {
+    const unsigned members = (G - 1u - threadIdx.x) / kFinSub + 1u;
+    while (__hip_atomic_load(counters + threadIdx.x * kCtrStride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < members)
+      __builtin_amdgcn_s_sleep(1);
+  }
   __syncthreads();
-  __threadfence();  // (acquire for every thread of the workgroup: the partials are read below, not by thread 0 alone)
   const int64_t cols = H * D;  // flattened (plane, column): plane h, column d at h * D + d of a partial row of HP * D floats
   const int64_t nchunks = (cols + kFinCols - 1) / kFinCols;
   float* lanes = red;  // [64][kFinCols]
   const int cl = threadIdx.x & (kFinCols - 1), lsub = threadIdx.x >> 4;
   for (int64_t ch = f; ch < nchunks; ch += nfin) {
     const int64_t col = ch * kFinCols + cl;
-    const float* src = partial + (col < cols ? col : 0);
+    // address = (wave-uniform row of the partials) + (a 32-bit per-thread offset): one register per load in flight, not three
+    const uint32_t toff = static_cast<uint32_t>(static_cast<int64_t>(lsub) * HP * D + (col < cols ? col : 0));
+    // device-coherent loads (never a line this XCD's L2 kept from an earlier launch), 16 partials of each of the thread's
+    // four sum-lanes requested together -- issued one by one behind their additions they were a chain of 64 memory round
+    // trips per thread (39 us per launch) -- then added in increasing p
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int64_t pb = 0; pb < P; pb += 64 * 16) {
+      float x[4][16];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int l = lsub + 16 * q;
-      float s = 0.f;
-      for (int64_t p = l; p < P; p += 64) s += src[p * HP * D];
-      lanes[l * kFinCols + cl] = s;
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int64_t prow = pb + static_cast<int64_t>(i) * 64 + 16 * q;  // uniform; the thread's partial is prow + lsub
+          const float* rowbase = partial + (prow < P ? prow : 0) * HP * D;
+          x[q][i] = (prow + lsub < P) ? __hip_atomic_load(rowbase + toff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (pb + static_cast<int64_t>(i) * 64 + lsub + 16 * q < P) s4[q] += x[q][i];
     }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) lanes[(lsub + 16 * q) * kFinCols + cl] = s4[q];
     __syncthreads();
     for (int stride = 32; stride >= 1; stride >>= 1) {
       for (int i = threadIdx.x; i < stride * kFinCols; i += kBlock) lanes[i] = lanes[i] + lanes[i + stride * kFinCols];
@@ -535,12 +564,48 @@ __global__ __launch_bounds__(kBlock) void lsh_bwd_fused_kernel(const uint8_t* __
     __syncthreads();
   }
   if (threadIdx.x == 0) {  // the last finisher leaves the counters at zero for the next launch
-    const unsigned done = __hip_atomic_fetch_add(&counters[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-    if (done + 1u == static_cast<unsigned>(nfin)) {
-      __hip_atomic_store(&counters[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&counters[0], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned done = __hip_atomic_fetch_add(root, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // finishers that are done
+    if (done + 1u == static_cast<unsigned>(nfin)) {  // every finisher is past its wait: zero for the next launch
+      // (read-modify-writes, not stores: performed where every XCD's atomics are; a plain store could sit in this XCD's L2)
+      for (int i = 0; i < kFinSub + 1; ++i) __hip_atomic_fetch_and(counters + i * kCtrStride, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
+}
+
+// The final reduction as a launch of its own, in the finishers' layout (16 consecutive columns per workgroup, 64 partials
+// per thread requested together, the tree in LDS): what follows `lsh_bwd_fused_kernel` launched with nfin = 0, which then
+// only writes the partials of every plane (plain stores: a kernel boundary lies between the two).
+__global__ __launch_bounds__(kBlock) void lsh_bwd_final_cols_kernel(const float* __restrict__ partial, int64_t P, int64_t HPD, int64_t cols,
+                                                                    float* __restrict__ gradW) {
+  __shared__ float lanes[64 * kFinCols];
+  const int cl = threadIdx.x & (kFinCols - 1), lsub = threadIdx.x >> 4;
+  const int64_t col = static_cast<int64_t>(blockIdx.x) * kFinCols + cl;
+  const uint32_t toff = static_cast<uint32_t>(static_cast<int64_t>(lsub) * HPD + (col < cols ? col : 0));
+  float s4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t pb = 0; pb < P; pb += 64 * 16) {
+    float x[4][16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t prow = pb + static_cast<int64_t>(i) * 64 + 16 * q;
+        const float* rowbase = partial + (prow < P ? prow : 0) * HPD;
+        x[q][i] = (prow + lsub < P) ? rowbase[toff] : 0.f;
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (pb + static_cast<int64_t>(i) * 64 + lsub + 16 * q < P) s4[q] += x[q][i];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) lanes[(lsub + 16 * q) * kFinCols + cl] = s4[q];
+  __syncthreads();
+  for (int stride = 32; stride >= 1; stride >>= 1) {
+    for (int i = threadIdx.x; i < stride * kFinCols; i += kBlock) lanes[i] = lanes[i] + lanes[i + stride * kFinCols];
+    __syncthreads();
+  }
+  if (threadIdx.x < kFinCols && col < cols) gradW[col] = lanes[cl];
 }
 
 // ---- context models: fused-table token gather with the user/item OOV splice ---------------------
@@ -708,6 +773,8 @@ extern "C" int64_t mi_oov_lsh_backward_fused_workspace(int64_t B, int64_t H, int
   return ((B + RP - 1) / RP) * ((H + kBwdH - 1) / kBwdH * kBwdH) * D;  // floats
 }
 
+extern "C" int64_t mi_oov_lsh_backward_fused_counters(void) { return (kFinSub + 1) * kCtrStride; }  // 32-bit words
+
 static int run_lsh_bwd_fused(const uint8_t* bits, const int64_t* idx, const float* grad_out, int64_t B, int64_t H, int64_t D,
                              float* grad_buckets, float* workspace, uint32_t* counters, hipStream_t st) {
   if (B < 0 || H <= 0 || D <= 0 || D > 256) return MI_OOV_ERR_SHAPE;
@@ -719,7 +786,7 @@ static int run_lsh_bwd_fused(const uint8_t* bits, const int64_t* idx, const floa
     }
     return MI_OOV_OK;
   }
-  if ((!bits && !idx) || !grad_out || !workspace || !counters) return MI_OOV_ERR_NULL;
+  if ((!bits && !idx) || !grad_out || !workspace) return MI_OOV_ERR_NULL;  // counters == NULL: partials, then a final launch
   const int64_t RP = col_part_rows(B);
   const int64_t P = (B + RP - 1) / RP;
   const int dchunks = static_cast<int>((D + 63) / 64);
@@ -730,12 +797,17 @@ static int run_lsh_bwd_fused(const uint8_t* bits, const int64_t* idx, const floa
   const int64_t nchunks = (H * D + kFinCols - 1) / kFinCols;
   int nfin = static_cast<int>(nchunks < kFinMax ? nchunks : kFinMax);
   if (nfin > P) nfin = static_cast<int>(P);
+  if (!counters) nfin = 0;
   auto k = idx ? (vec ? lsh_bwd_fused_kernel<true, true, false> : lsh_bwd_fused_kernel<false, true, false>)
                : fast8 ? lsh_bwd_fused_kernel<true, false, true>
                        : (vec ? lsh_bwd_fused_kernel<true, false, false> : lsh_bwd_fused_kernel<false, false, false>);
   if (int rc = set_lds(k, lds)) return rc;
   hipLaunchKernelGGL(k, dim3(static_cast<unsigned>(P)), dim3(kBlock), lds, st, bits, idx, grad_out, B, H, D, workspace, counters, nfin,
                      grad_buckets);
+  if (int rc = check_launch()) return rc;
+  if (nfin > 0) return MI_OOV_OK;
+  const int64_t HP = (H + kBwdH - 1) / kBwdH * kBwdH;
+  hipLaunchKernelGGL(lsh_bwd_final_cols_kernel, dim3(static_cast<unsigned>(nchunks)), dim3(kBlock), 0, st, workspace, P, HP * D, H * D, grad_buckets);
   return check_launch();
 }
 

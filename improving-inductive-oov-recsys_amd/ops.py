@@ -71,25 +71,30 @@ class _LshEmbed(torch.autograd.Function):
         return None, None, None, lsh_embed_backward(bits, g)
 
 
-_BWD_COUNTERS = {}  # (device index, raw stream) -> u32[2] zeros: the fused backward kernels leave them at zero
+_BWD_COUNTERS = {}  # (device index, raw stream) -> zeroed arrival counters: the fused backward kernels leave them at zero
 
 
 def _bwd_counters(t):
-    """The two ticket words of mi_oov_*_embed_backward_fused for the current stream of t's device: zero at first use, left
+    """The arrival counters of mi_oov_*_embed_backward_fused for the current stream of t's device: zero at first use, left
     zero by every launch, one pair per stream (launches on one stream are ordered; on two streams they may overlap).
     While a HIP graph is being captured a fresh zeroed pair is made inside the capture instead (the cached pair must not
     end up in a graph's private pool)."""
+    n = int(C.lib().mi_oov_lsh_backward_fused_counters())
     if torch.cuda.is_current_stream_capturing():
-        return torch.zeros((2,), dtype=torch.int32, device=t.device)
+        return torch.zeros((n,), dtype=torch.int32, device=t.device)
     key = (t.device.index, C.stream_of(t))
     c = _BWD_COUNTERS.get(key)
     if c is None:
-        c = _BWD_COUNTERS[key] = torch.zeros((2,), dtype=torch.int32, device=t.device)
+        c = _BWD_COUNTERS[key] = torch.zeros((n,), dtype=torch.int32, device=t.device)
     return c
 
 
-def _bwd_fused():
-    return os.environ.get("MI_OOV_BWD_FUSED", "1") != "0"  # developer A/B knob: 0 = the two-launch reductions
+def _bwd_mode():
+    """MI_OOV_BWD_FUSED (developer A/B knob): 2 (default) = every plane's partials in one launch + the coalesced final launch;
+    1 = ONE launch (the last workgroups to arrive finish; needs the zeroed counters); 0 = round 3's launches (eight planes
+    per pass over the batch, one wave per column in the final one).  Bit-identical results."""
+    v = os.environ.get("MI_OOV_BWD_FUSED", "2")
+    return int(v) if v in ("0", "1", "2") else 2
 
 
 def lsh_embed_backward(bits, grad_out):
@@ -103,9 +108,9 @@ def lsh_embed_backward(bits, grad_out):
         raise ValueError(f"grad_out has {g.shape[0]} rows, bits {B}")
     lib = C.lib()
     out = torch.empty((H, D), dtype=torch.float32, device=g.device)
-    if _bwd_fused():
+    if _bwd_mode():
         ws = torch.empty((max(int(lib.mi_oov_lsh_backward_fused_workspace(B, H, D)), 1),), dtype=torch.float32, device=g.device)
-        cnt = _bwd_counters(g)
+        cnt = _bwd_counters(g) if _bwd_mode() == 1 else None
         with C.on_device(g):
             rc = lib.mi_oov_lsh_embed_backward_fused(C.ptr(bits), C.ptr(g), B, H, D, C.ptr(out), C.ptr(ws), C.ptr(cnt), C.stream_of(g))
         C.check(rc, "mi_oov_lsh_embed_backward_fused")
@@ -722,9 +727,9 @@ def slsh_embed_backward(idx, grad_out, n_buckets):
     B, D = g.shape
     lib = C.lib()
     out = torch.empty((n_buckets, D), dtype=torch.float32, device=g.device)
-    if _bwd_fused():
+    if _bwd_mode():
         ws = torch.empty((max(int(lib.mi_oov_lsh_backward_fused_workspace(B, min(n_buckets, 64), D)), 1),), dtype=torch.float32, device=g.device)
-        cnt = _bwd_counters(g)
+        cnt = _bwd_counters(g) if _bwd_mode() == 1 else None
         with C.on_device(g):
             rc = lib.mi_oov_slsh_embed_backward_fused(C.ptr(idx), C.ptr(g), B, n_buckets, D, C.ptr(out), C.ptr(ws), C.ptr(cnt), C.stream_of(g))
         C.check(rc, "mi_oov_slsh_embed_backward_fused")

@@ -96,11 +96,14 @@ int mi_oov_slsh_embed_backward(const int64_t* idx, const float* grad_out, int64_
  * plane, and the last workgroups to arrive add the partials up -- the same values in the same order, so the results are
  * bit-identical to the two-launch entry points above (and to oracle/oov_oracle.c).
  *   workspace f32[mi_oov_lsh_backward_fused_workspace(B, H or n_buckets, D)];
- *   counters u32[2], caller-owned device memory that is ZERO at the first launch and is left zero by every launch (the
- *   last workgroup resets it): allocate once, zero once, reuse -- also across HIP-graph replays.  Two launches that may
- *   run at the same time (different streams) need different counters.
+ *   counters u32[mi_oov_lsh_backward_fused_counters()], caller-owned device memory that is ZERO at the first launch and is
+ *   left zero by every launch (the last workgroup resets it): allocate once, zero once, reuse -- also across HIP-graph
+ *   replays.  Two launches that may run at the same time (different streams) need different counters.  counters == NULL:
+ *   the same partials for every plane in one launch, then the final reduction as a second launch (16 consecutive columns per
+ *   workgroup, 64 partials per thread in flight) -- two launches, no counters, the same bits.
  * slsh with more than 64 buckets or D > 256: as mi_oov_slsh_embed_backward (memset + float atomics; counters unused). */
 int64_t mi_oov_lsh_backward_fused_workspace(int64_t B, int64_t H, int64_t D); /* number of floats */
+int64_t mi_oov_lsh_backward_fused_counters(void);                            /* number of 32-bit words */
 int mi_oov_lsh_embed_backward_fused(const uint8_t* bits, const float* grad_out, int64_t B, int64_t H, int64_t D,
                                     float* grad_buckets, float* workspace, uint32_t* counters, void* stream);
 int mi_oov_slsh_embed_backward_fused(const int64_t* idx, const float* grad_out, int64_t B, int64_t n_buckets, int64_t D,

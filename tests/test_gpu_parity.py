@@ -767,7 +767,7 @@ def test_gather_splice_vs_oracle(oracle, ops, dev):
             assert bits_equal(got, oracle.gather_mean(idx, table, g))
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])  # one launch with a last-workgroups-done reduction (round 4) / the two launches
+@pytest.mark.parametrize("fused", ["2", "1", "0"])  # round 4: all planes + coalesced final (default) / ONE launch, the last workgroups finish / round 3's launches
 @pytest.mark.parametrize("B,H,D", [(1, 8, 64), (300, 8, 64), (70000, 8, 64), (5000, 12, 64), (999, 3, 22), (4097, 40, 50), (1 << 20, 8, 64), (65536, 17, 128)])
 def test_lsh_backward_vs_oracle(B, H, D, fused, oracle, ops, dev, monkeypatch):
     """grad of (bits @ W)/popcount w.r.t. W: bit-exact against the oracle (same two-pass order), within 1e-5
@@ -789,7 +789,7 @@ def test_lsh_backward_vs_oracle(B, H, D, fused, oracle, ops, dev, monkeypatch):
         assert bits_equal(got, oracle.lsh_embed_backward(bits, g)) and np.isnan(got).all()
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("fused", ["2", "1", "0"])
 @pytest.mark.parametrize("B,nb,D", [(1, 8, 64), (3000, 9, 64), (70000, 64, 64), (5000, 777, 24), (4097, 65, 50), (65536, 9, 64), (300000, 33, 128)])
 def test_slsh_backward_and_scatter(B, nb, D, fused, oracle, ops, dev, monkeypatch):
     monkeypatch.setenv("MI_OOV_BWD_FUSED", fused)
