@@ -1469,6 +1469,20 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 2 : (EPI == EPI_TILEMAX ? 3 : 4))
 // E in fragment order (eb_chunk: contiguous 1 KB per load instruction instead of 32 quarter-used lines) 49.2 -> 48.7,
 // kept; s_setprio 1 while testing and pushing 48.4 -> 47.8, kept; s_setprio on the MFMA phase instead: no change.
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+// Developer knock-outs of this kernel (tools/build_variant.sh <name> "-DMI_FD_KNOCK=1" score.hip; tools/topk_chain_libs.sh), round 4,
+// 4096 x 50 000, k = 20, D = 64, kernel time in the launch chain (41.4 us as built; an EMPTY kernel of this grid: 4.8 us):
+//   MI_FD_KNOCK=2  no epilogue, no loads in the loop   24.3 us  (28 k matrix-pipe cycles = 11.3 us are the instructions themselves)
+//   MI_FD_KNOCK=1  no epilogue                          32.0     (the loads, with no epilogue to hide behind)
+//   as built                                            41.4     (the epilogue: ~60 vector + ~50 scalar instructions per wave and block)
+//   MI_FD_KNOCK=2 -DMI_FD_PAD=40 / 80                    + 3.7 / + 7.9 us: independent vector instructions do NOT hide behind
+//                   the matrix pipe on this chip -- each costs ~2.4 cycles of the SIMD whether or not the pipe is busy -- so
+//                   the kernel's time is (matrix instructions) + (everything else), and "matrix cores busy" can only rise by
+//                   issuing fewer other instructions per matrix instruction.  The sampling stride of pass 1 (2 / 3 / 4 / 6:
+//                   40.1 / 39.9 / 41.4 / 43.7 us here) moves this kernel little: the tests of all 32 accumulators of a lane, not
+//                   the pushes of the few that pass, are most of the epilogue.
+#ifndef MI_FD_KNOCK
+#define MI_FD_KNOCK 0
+#endif
 #ifndef MI_FD_PRIO
 #define MI_FD_PRIO 1  // issue priority of a wave while it tests and pushes (its partner is then mostly issuing MFMAs): 48.4 -> 47.8 us
 #endif
@@ -1586,8 +1600,14 @@ __global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_fil
   for (int j = strip; j < nvisit; j += nstrip) {
     {
       const int64_t n1 = static_cast<int64_t>(j + nstrip < nvisit ? j + nstrip : j) * BN;  // (the last block re-reads itself)
+#if MI_FD_KNOCK == 2  // developer knock-out: no loads in the loop either
+      (void)n1;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) bn[ks] = bq[ks];
+#else
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks) bn[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n1 + ccol, ks * 2 + hh));
+#endif
     }
     f32x16 acc[MT];
 #pragma unroll
@@ -1611,6 +1631,30 @@ __global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_fil
     // it may not hold another block's records (a block leaves ~9): what matters in this kernel is the NUMBER of
     // vector instructions next to the 20 MFMAs of a block (they share the SIMD's issue: knocking the epilogue out
     // took 70 us to 34), and a drain costs ~100 of them whether 9 lanes have a record or 64.
+#if MI_FD_KNOCK == 1 || MI_FD_KNOCK == 2  // developer knock-out: no epilogue (the accumulators stay alive through an impossible store)
+    {
+      int keepi = 0;
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 16; r += 3) keepi |= __float_as_uint(acc[m][r]) == 0x12345678u;
+      if (keepi) rowcnt[0] = 1;
+#ifdef MI_FD_PAD  // developer probe: MI_FD_PAD independent vector instructions per block -- do they hide behind the matrix pipe?
+      {
+        int pad0 = lane, pad1 = lane + 1;
+#pragma unroll
+        for (int q = 0; q < MI_FD_PAD / 2; ++q) {
+          asm volatile("v_add_u32 %0, %0, %1" : "+v"(pad0) : "v"(j));
+          asm volatile("v_add_u32 %0, %0, %1" : "+v"(pad1) : "v"(j));
+        }
+        if ((pad0 ^ pad1) == 0x7FFFFFFF) rowcnt[1] = 1;
+      }
+#endif
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) bq[ks] = bn[ks];
+      continue;
+    }
+#endif
     if (qpos > kDirectQueue - 128) drain();
 #if MI_FD_PRIO
     __builtin_amdgcn_s_setprio(MI_FD_PRIO);
@@ -1758,7 +1802,24 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
 #pragma unroll
       for (int q = 0; q < 4; ++q) mykey[q] = (q * 64 + lane < n) ? static_cast<uint32_t>(entry(q * 64 + lane) >> 32) : 0u;
       uint32_t T = 0u;
-      if (kk > 0) {
+      if (kk > 0 && kk <= 64) {
+        // Any LOWER bound of the k-th best key serves (a lower cut only lets a few more candidates through to the exact
+        // re-score, which decides).  The kk-th best of the 64 per-lane maxima is one -- the lanes' maxima are kk distinct
+        // candidates at least as good -- and so is that value with its low 16 bits cleared (2^-7 relative of a shifted
+        // score: far inside the 2 eps the cut gives away anyway): 16 steps of ONE ballot instead of 32 steps of four.
+        // (round 4: this search was 5.8 of the kernel's 21.4 us at 4096 x 50 000, k = 20.)
+        uint32_t lmax = mykey[0];
+#pragma unroll
+        for (int q = 1; q < 4; ++q) lmax = mykey[q] > lmax ? mykey[q] : lmax;
+        for (int b = 256; b < n; b += 64) {  // lists longer than 256 entries (rare): from LDS / the overflow list
+          const uint32_t kx = b + lane < n ? static_cast<uint32_t>(entry(b + lane) >> 32) : 0u;
+          lmax = kx > lmax ? kx : lmax;
+        }
+        for (int bit = 31; bit >= 16; --bit) {
+          const uint32_t c = T | (1u << bit);
+          if (__popcll(__ballot(lmax >= c)) >= kk) T = c;  // (a lane without a candidate holds 0 and never counts: c > 0)
+        }
+      } else if (kk > 0) {  // k > 64: the exact k-th best key, bit by bit over every candidate
         for (int bit = 31; bit >= 0; --bit) {
           const uint32_t c = T | (1u << bit);
           int have = 0;

@@ -9,7 +9,7 @@ make -C csrc -j8 >/dev/null
 /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -amdgpu-kernarg-preload-count=16 \
   -I../include -Wall -Wno-unused-function $2 -c csrc/$src -o lib/ab/$1.o
 objs=""
-for o in api.cpp lsh.hip lsh64.hip lsh64p.hip exchange.hip mlp.hip hash.hip gather.hip score.hip linear3.hip; do
+for o in api.cpp lsh.hip lsh64.hip lsh64p.hip exchange.hip mlp.hip hash.hip gather.hip score.hip linear3.hip evalrows.hip; do
   if [ "$o" = "$src" ]; then objs="$objs lib/ab/$1.o"; else objs="$objs lib/obj/$o.o"; fi
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o lib/ab/$1.so $objs
