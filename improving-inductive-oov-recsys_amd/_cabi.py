@@ -62,6 +62,8 @@ _SIGNATURES = {
     "mi_oov_gather_mean_multi": (ctypes.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _vp]),
     "mi_oov_slsh_embed_multi": (ctypes.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _i64, _vp]),
     "mi_oov_bucket_by_owner": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "mi_oov_bucket_by_owner_scratch": (_i64, []),
+    "mi_oov_bucket_by_owner_fused": (ctypes.c_int, [_vp, _i64, _i64, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_codes_embed": (ctypes.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _vp, _vp, _vp]),
     "mi_oov_lsh_lookup": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "mi_oov_lsh_lookup_score": (ctypes.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _vp, _i64, _vp, _i64, _vp, _vp,

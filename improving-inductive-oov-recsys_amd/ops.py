@@ -28,7 +28,7 @@ def _f32(t, name):
 # ------------------------------------------------------------------------------------------
 # raw forwards
 # ------------------------------------------------------------------------------------------
-def _lsh_forward(ids, feat, planes, buckets, want_out=True, want_bits=False):
+def _lsh_forward(ids, feat, planes, buckets, want_out=True, want_bits=False, bits_out=None):
     ids, feat, planes = _ids(ids), _f32(feat, "feat"), _f32(planes, "planes")
     B, (N, F), H = ids.numel(), feat.shape, planes.shape[0]
     if planes.shape[1] != F:
@@ -41,7 +41,11 @@ def _lsh_forward(ids, feat, planes, buckets, want_out=True, want_bits=False):
             raise ValueError(f"lsh needs one bucket row per plane: {buckets.shape[0]} vs {H}")
         D = buckets.shape[1]
         out = torch.empty((B, D), dtype=torch.float32, device=ids.device)
-    if want_bits:
+    if want_bits and bits_out is not None:
+        if bits_out.dtype != torch.uint8 or not bits_out.is_contiguous() or bits_out.numel() != B * H or bits_out.device != ids.device:
+            raise ValueError(f"out must be a contiguous u8[{B}, {H}] tensor on {ids.device}")
+        bits = bits_out
+    elif want_bits:
         bits = torch.empty((B, H), dtype=torch.uint8, device=ids.device)
     with C.on_device(ids):
         rc = C.lib().mi_oov_lsh_embed(C.ptr(ids), B, C.ptr(feat), N, F, C.ptr(planes), H,
@@ -51,9 +55,10 @@ def _lsh_forward(ids, feat, planes, buckets, want_out=True, want_bits=False):
     return out, bits
 
 
-def lsh_bits(ids, feat, planes):
-    """TorchLSHash.hash_points(planes, feat[ids]) as u8[B,H] (R/inductive/torch_hash.py:55-60)."""
-    return _lsh_forward(ids, feat, planes, None, want_out=False, want_bits=True)[1]
+def lsh_bits(ids, feat, planes, out=None):
+    """TorchLSHash.hash_points(planes, feat[ids]) as u8[B,H] (R/inductive/torch_hash.py:55-60); `out`: a contiguous u8[B,H]
+    buffer (a view into a larger one: the sharded exchange appends its local share's codes to the exchanged ones)."""
+    return _lsh_forward(ids, feat, planes, None, want_out=False, want_bits=True, bits_out=out)[1]
 
 
 class _LshEmbed(torch.autograd.Function):
@@ -543,16 +548,43 @@ def slsh_embed_multi(ids_list, feat, planes, buckets, want_idx=False, out=None):
     return (outs, idxs) if want_idx else outs
 
 
-def bucket_by_owner(ids, n_rows, rows_per_rank, world, cap, overflow=None):
-    """Requester side of a sharded lookup (mi_oov_bucket_by_owner): -> (send int64[world, cap] of owner-local rows,
-    -1 padded; slot int32[B]; counts int32[world]).  `overflow` (int32 scalar tensor, optional) accumulates the largest
-    excess of a segment over `cap`.  Device only, no host synchronisation."""
+_BUCKET_SCRATCH = {}  # (device index, raw stream) -> zeroed reservation words of mi_oov_bucket_by_owner_fused (left zero by every launch)
+
+
+def _bucket_scratch(t):
+    n = int(C.lib().mi_oov_bucket_by_owner_scratch())
+    if torch.cuda.is_current_stream_capturing():  # (a cached tensor must not end up in a graph's private pool)
+        return torch.zeros((n,), dtype=torch.int32, device=t.device)
+    key = (t.device.index, C.stream_of(t))
+    c = _BUCKET_SCRATCH.get(key)
+    if c is None:
+        c = _BUCKET_SCRATCH[key] = torch.zeros((n,), dtype=torch.int32, device=t.device)
+    return c
+
+
+def bucket_by_owner(ids, n_rows, rows_per_rank, world, cap, overflow=None, my_rank=None):
+    """Requester side of a sharded lookup: -> (send int64[world, cap] of owner-local rows, -1 padded; slot int32[B];
+    counts int32[world]).  `overflow` (int32 scalar tensor, optional) accumulates the largest excess of a segment over
+    `cap`.  Device only, no host synchronisation.  One launch for a single-node world (mi_oov_bucket_by_owner_fused; the
+    three-operation mi_oov_bucket_by_owner for world > 16 or under MI_OOV_BUCKET_FUSED=0).
+    my_rank (world <= 16): the lookups this rank owns are COMPACTED instead of sent -- a fourth result local_rows int64[cap]
+    (their local row numbers, -1 padded), their slots are world * cap + position, the send segment of my_rank is empty."""
     ids = _ids(ids)
     B = ids.numel()
     send = torch.empty((world, cap), dtype=torch.int64, device=ids.device)
     slot = torch.empty((B,), dtype=torch.int32, device=ids.device)
     counts = torch.empty((world,), dtype=torch.int32, device=ids.device)
+    fused = world <= 16 and B > 0 and (my_rank is not None or os.environ.get("MI_OOV_BUCKET_FUSED", "1") != "0")
+    if my_rank is not None and not fused:
+        raise ValueError("bucket_by_owner(my_rank=...) needs 1 <= world <= 16 and a non-empty batch")
     with C.on_device(ids):
+        if fused:
+            local_rows = torch.empty((cap,), dtype=torch.int64, device=ids.device) if my_rank is not None else None
+            rc = C.lib().mi_oov_bucket_by_owner_fused(C.ptr(ids), B, n_rows, rows_per_rank, world, cap, -1 if my_rank is None else int(my_rank),
+                                                      C.ptr(send), C.ptr(slot), C.ptr(counts), C.ptr(overflow), C.ptr(local_rows),
+                                                      C.ptr(_bucket_scratch(ids)), C.stream_of(ids))
+            C.check(rc, "mi_oov_bucket_by_owner_fused")
+            return (send, slot, counts, local_rows) if my_rank is not None else (send, slot, counts)
         rc = C.lib().mi_oov_bucket_by_owner(C.ptr(ids), B, n_rows, rows_per_rank, world, cap, C.ptr(send), C.ptr(slot),
                                             C.ptr(counts), C.ptr(overflow), C.stream_of(ids))
     C.check(rc, "mi_oov_bucket_by_owner")

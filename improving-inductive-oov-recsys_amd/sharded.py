@@ -52,11 +52,17 @@ class HipPrims:
         return ops.bucket_by_owner(ids, n_rows, per, world, cap, overflow)
 
     @staticmethod
-    def codes(local_ids, feat_local, planes):
+    def bucket_local(ids, n_rows, per, world, cap, overflow, my_rank):
+        """bucket + the lookups of my_rank compacted into local_rows (slots world * cap + position): one launch."""
+        from . import ops
+        return ops.bucket_by_owner(ids, n_rows, per, world, cap, overflow, my_rank=my_rank)
+
+    @staticmethod
+    def codes(local_ids, feat_local, planes, out=None):
         from . import ops
         if feat_local.shape[0] == 0:  # more ranks than rows: this rank owns nothing and is never asked
             return torch.full((local_ids.numel(), planes.shape[0]), 255, dtype=torch.uint8, device=local_ids.device)
-        return ops.lsh_bits(local_ids, feat_local, planes)
+        return ops.lsh_bits(local_ids, feat_local, planes, out=out)
 
     @staticmethod
     def codes_embed(codes, slot, buckets, other, want_emb, score_out=None):
@@ -119,7 +125,7 @@ def _all_to_all(out, inp, group, async_op=False):
 
 class _Pending:
     """One lookup batch on its way through the exchange."""
-    __slots__ = ("B", "cap", "slot", "counts", "recv", "back", "w_ids", "w_back", "width", "dtype")
+    __slots__ = ("B", "cap", "slot", "counts", "recv", "back", "w_ids", "w_back", "width", "dtype", "back_ext")
 
 
 class _ShardedBase:
@@ -169,15 +175,35 @@ class _ShardedBase:
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return self.capacity(int(t.item()))
 
-    def begin(self, ids, async_op=False):
-        """Bucket `ids` (global rows, int64[B]) by owner and send every owner its segment."""
+    def can_compact_local(self, ids):
+        """The one-launch bucketing with the local share compacted (mi_oov_bucket_by_owner_fused) serves single-node
+        worlds; a rank that owns no rows, or an empty batch, has nothing to compact."""
+        return hasattr(self.prims, "bucket_local") and self.world <= 16 and self.hi > self.lo and ids.numel() > 0
+
+    def begin(self, ids, async_op=False, local_planes=None):
+        """Bucket `ids` (global rows, int64[B]) by owner and send every owner its segment.
+        local_planes (lsh, `can_compact_local`): the lookups whose row this rank owns are NOT sent -- the bucketing kernel
+        compacts them, their codes are computed here (1 / world of a uniform batch, while the remote ids travel) and stored
+        behind the world * cap exchanged codes, where their slots point."""
         p = _Pending()
         p.B = ids.numel()
         p.cap = self._agreed_capacity(p.B)
-        send, p.slot, p.counts = self.prims.bucket(ids, self.n_rows, self.per, self.world, p.cap, self.overflow)
+        p.back_ext = None
+        if local_planes is not None:
+            send, p.slot, p.counts, local_rows = self.prims.bucket_local(ids, self.n_rows, self.per, self.world, p.cap, self.overflow,
+                                                                         self.rank)
+        else:
+            send, p.slot, p.counts = self.prims.bucket(ids, self.n_rows, self.per, self.world, p.cap, self.overflow)
         p.recv = torch.empty_like(send)
         p.w_ids = _all_to_all(p.recv, send, self.group, async_op)
         p.w_back = None
+        if local_planes is not None:
+            H = local_planes.shape[0]
+            p.back_ext = torch.empty(((self.world + 1) * p.cap, H), dtype=torch.uint8, device=send.device)
+            tail = p.back_ext[self.world * p.cap:]
+            got = self.prims.codes(local_rows, self.feat_local, local_planes, out=tail)
+            if got.data_ptr() != tail.data_ptr():  # (a prims without an `out`: the oracle of the CPU tests)
+                tail.copy_(got)
         return p
 
     def _reply(self, p, payload, async_op):
@@ -208,11 +234,16 @@ class ShardedLSHTable(_ShardedBase):
     def owner(self, p, planes, async_op=False):
         """Owner side: sign bits of the rows this rank was asked for (0xFF rows for the -1 padding), sent back."""
         self._wait(p.w_ids)
-        self._reply(p, self.prims.codes(p.recv.view(-1), self.feat_local, planes), async_op)
+        codes = self.prims.codes(p.recv.view(-1), self.feat_local, planes)
+        if p.back_ext is None:
+            self._reply(p, codes, async_op)
+        else:  # the exchanged codes land in front of the local share's (begin)
+            p.back = p.back_ext[: self.world * p.cap]
+            p.w_back = _all_to_all(p.back, codes, self.group, async_op)
 
     def finish(self, p, buckets, other=None, want_emb=True, score_out=None):
         self._wait(p.w_back)
-        return self.prims.codes_embed(p.back, p.slot, buckets, other, want_emb, score_out)
+        return self.prims.codes_embed(p.back if p.back_ext is None else p.back_ext, p.slot, buckets, other, want_emb, score_out)
 
     def embed(self, ids, planes, buckets):
         p = self.begin(ids)
@@ -226,6 +257,10 @@ class ShardedLSHTable(_ShardedBase):
         same bits, so the result is unchanged.  1 / world of a uniform batch is local."""
         if not local_fast or self.hi == self.lo:
             p = self.begin(ids)
+            self.owner(p, planes)
+            return self.finish(p, buckets, other, want_emb=False, score_out=score_out)[0]
+        if self.can_compact_local(ids):  # round 4: the local share compacted by the bucketing kernel (1 / world of the batch)
+            p = self.begin(ids, async_op=_backend(self.group) == "nccl", local_planes=planes)
             self.owner(p, planes)
             return self.finish(p, buckets, other, want_emb=False, score_out=score_out)[0]
         local = (ids >= self.lo) & (ids < self.hi)
@@ -277,6 +312,8 @@ class LshPipeline:
         def begin_step(t):
             if not self.local_fast:
                 return t_.begin(ids[t], async_op=True), None, None
+            if t_.can_compact_local(ids[t]):  # the bucketing kernel compacts the local share; its codes join the exchanged ones
+                return t_.begin(ids[t], async_op=True, local_planes=self.planes), None, None
             local = (ids[t] >= t_.lo) & (ids[t] < t_.hi)
             p = t_.begin(torch.where(local, torch.full_like(ids[t], -1), ids[t]), async_op=True)
             return p, local, t_.prims.lsh_embed_score(ids[t] - t_.lo, t_.feat_local, self.planes, self.buckets, others[t])
@@ -311,6 +348,9 @@ class LshPipeline:
         def owner(p):
             with torch.cuda.stream(s_owner):
                 p.recv.record_stream(s_owner)  # allocated on the bucket stream, read here
+                if p.back_ext is not None:     # (allocated and partly written on the bucket stream; the exchange fills the rest)
+                    s_owner.wait_stream(s_bucket)
+                    p.back_ext.record_stream(s_owner)
                 t_.owner(p, self.planes, async_op=True)
 
         def finish(p, local, sc_local, t):
@@ -319,6 +359,8 @@ class LshPipeline:
                 t_._wait(p.w_back)
                 p.w_back = None
                 p.back.record_stream(s_req)  # owner stream -> here
+                if p.back_ext is not None:
+                    p.back_ext.record_stream(s_req)
                 if local is not None:
                     s_req.wait_stream(s_bucket)  # the local share was scored on the bucket stream
                     local.record_stream(s_req)

@@ -148,6 +148,19 @@ int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_rows, int64_
                            int64_t cap, int64_t* send, int32_t* slot, int32_t* counts, int32_t* overflow,
                            void* stream);
 
+/* The same in ONE launch (round 4; world <= 16, B > 0): no memset, no second kernel for the segments' tails -- the
+ * reservations are made in `scratch` (u32[mi_oov_bucket_by_owner_scratch()], caller-owned, ZERO at the first launch and left
+ * zero by every launch: allocate once per stream), and the last workgroup to finish writes counts[], fills the unused
+ * entries with -1 and resets the scratch.  my_rank >= 0 also COMPACTS the lookups whose row this rank owns itself:
+ * local_rows i64[cap] receives their local row numbers (-1 behind the last), their slots are world * cap + position -- a
+ * caller that appends the codes it computes for local_rows behind the world * cap exchanged ones hands the whole array to
+ * mi_oov_lsh_codes_embed (M = (world + 1) * cap) -- and the send segment of my_rank stays empty (-1).  my_rank < 0:
+ * exactly mi_oov_bucket_by_owner's outputs.  MI_OOV_ERR_SHAPE for world > 16 or B = 0 (use mi_oov_bucket_by_owner).   */
+int64_t mi_oov_bucket_by_owner_scratch(void); /* number of 32-bit words */
+int mi_oov_bucket_by_owner_fused(const int64_t* ids, int64_t B, int64_t n_rows, int64_t rows_per_rank, int64_t world,
+                                 int64_t cap, int64_t my_rank, int64_t* send, int32_t* slot, int32_t* counts,
+                                 int32_t* overflow, int64_t* local_rows, uint32_t* scratch, void* stream);
+
 /* Requester side of a sharded lsh lookup: the owners returned codes u8[M,H] (mi_oov_lsh_embed with bits only,
  * 0xFF rows for ids outside their shard); lookup b's code sits at row slot[b].
  *   emb[b] = (code @ buckets) / popcount  -- same fmaf chain and division as mi_oov_lsh_embed, bit-identical --

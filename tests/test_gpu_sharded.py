@@ -68,6 +68,53 @@ def test_bucket_by_owner_properties(B, N, world, cap, oracle, ops, dev):
         assert np.array_equal(np.sort(send[w, :n]), np.sort(o_send[w, :n])) or o_counts[w] > cap
 
 
+@pytest.mark.parametrize("B,N,world,cap,me", [(1, 10, 2, 1, 1), (1000, 777, 8, 1000, 0), (65536, 1_000_003, 8, 9000, 5), (5000, 64, 3, 100, 2),
+                                              (70000, 500, 7, 70000, 3), (300000, 40_000_000, 16, 20000, 15), (4097, 9001, 1, 4097, 0)])
+def test_bucket_by_owner_one_launch_and_local_compaction(B, N, world, cap, me, oracle, ops, dev, monkeypatch):
+    """mi_oov_bucket_by_owner_fused (round 4): ONE launch -- reservations in caller-owned scratch words that every launch leaves
+    at zero, the last workgroup publishes the counts and fills the tails -- gives what the three-operation form gives
+    (same counts, same segments up to the order inside a segment, same -1 tails), launch after launch on the same scratch;
+    with my_rank the lookups this rank owns are compacted into local_rows with slots behind the exchanged ones."""
+    rng = np.random.default_rng(B + world)
+    per = -(-N // world)
+    for rep in range(3):  # the same scratch words serve every launch
+        ids = rng.integers(-3, N + 3, size=B).astype(np.int64)
+        o_send, o_slot, o_counts = oracle.bucket_by_owner(ids, N, per, world, cap)
+        valid = (ids >= 0) & (ids < N)
+        owner = np.minimum(ids // per, world - 1)
+        over = torch.zeros((1,), dtype=torch.int32, device=dev)
+        send, slot, counts = (t.cpu().numpy() for t in ops.bucket_by_owner(T(ids, dev), N, per, world, cap, over))
+        monkeypatch.setenv("MI_OOV_BUCKET_FUSED", "0")
+        send3, slot3, counts3 = (t.cpu().numpy() for t in ops.bucket_by_owner(T(ids, dev), N, per, world, cap))
+        monkeypatch.delenv("MI_OOV_BUCKET_FUSED")
+        assert np.array_equal(counts, o_counts) and np.array_equal(counts3, o_counts)
+        assert int(over.item()) == max(0, int(o_counts.max()) - cap)
+        assert np.array_equal(np.sort(send, axis=1), np.sort(send3, axis=1))   # the same rows in every segment, the same padding
+        assert np.array_equal(slot < 0, slot3 < 0) and np.array_equal(slot[slot < 0], slot3[slot3 < 0])
+        placed = slot >= 0
+        assert np.array_equal(send.reshape(-1)[slot[placed]], ids[placed] - owner[placed] * per)
+        # ... and with the local share compacted
+        send_l, slot_l, counts_l, local_rows = (t.cpu().numpy() for t in ops.bucket_by_owner(T(ids, dev), N, per, world, cap, None, my_rank=me))
+        assert np.array_equal(counts_l, o_counts)
+        mine = valid & (owner == me)
+        n_me = min(int(o_counts[me]), cap)
+        assert (send_l[me] == -1).all()                                         # nothing of mine is sent
+        assert (local_rows[:n_me] >= 0).all() and (local_rows[n_me:] == -1).all()
+        kept = mine & (slot_l >= 0)
+        assert kept.sum() == n_me and (slot_l[mine & ~kept] == -1).all()
+        assert (slot_l[kept] >= world * cap).all() and (slot_l[kept] < (world + 1) * cap).all()
+        assert len(np.unique(slot_l[kept])) == n_me
+        assert np.array_equal(local_rows[slot_l[kept] - world * cap], ids[kept] - me * per)
+        others = valid & (owner != me)
+        assert np.array_equal(slot_l[others] < 0, slot[others] < 0)
+        po = others & (slot_l >= 0)
+        assert np.array_equal(send_l.reshape(-1)[slot_l[po]], ids[po] - owner[po] * per) and (slot_l[po] // cap == owner[po]).all()
+        assert (slot_l[~valid] == -2).all()
+        for w in range(world):
+            if w != me:
+                assert np.array_equal(np.sort(send_l[w]), np.sort(send[w]))
+
+
 @pytest.mark.parametrize("B,H,D", [(1, 8, 64), (777, 8, 64), (4099, 3, 64), (500, 16, 36), (333, 27, 128), (129, 40, 50),
                                    (64, 12, 256), (257, 5, 1)])
 def test_lsh_codes_embed_vs_oracle(B, H, D, oracle, ops, dev):

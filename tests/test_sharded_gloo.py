@@ -29,7 +29,21 @@ class OraclePrims:
         return torch.from_numpy(send), torch.from_numpy(slot), torch.from_numpy(counts)
 
     @staticmethod
-    def codes(local_ids, feat_local, planes):
+    def bucket_local(ids, n_rows, per, world, cap, overflow, my_rank):
+        """mi_oov_bucket_by_owner_fused with my_rank, restated on the oracle's bucketing: the lookups of my_rank leave their
+        send segment for local_rows and take slots world * cap + position."""
+        from oracle import oov_oracle as oracle
+        send, slot, counts = oracle.bucket_by_owner(ids.numpy(), n_rows, per, world, cap)
+        overflow[0] = max(int(overflow[0]), int(counts.max()) - cap, 0)
+        local_rows = send[my_rank].copy()
+        send[my_rank] = -1
+        mine = (slot >= my_rank * cap) & (slot < (my_rank + 1) * cap)
+        slot = slot.copy()
+        slot[mine] += (world - my_rank) * cap
+        return torch.from_numpy(send), torch.from_numpy(slot), torch.from_numpy(counts), torch.from_numpy(local_rows)
+
+    @staticmethod
+    def codes(local_ids, feat_local, planes, out=None):
         from oracle import oov_oracle as oracle
         H = planes.shape[0]
         if feat_local.shape[0] == 0:
