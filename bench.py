@@ -237,6 +237,12 @@ def main():
         args.table = "sharded"
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(spawn_ranks(args))
+    # stdout carries ONE JSON line and nothing else: RCCL prints a version banner to stdout when its first communicator is
+    # made (seen with --force-sharded: "RCCL version : 2.26.6 ..." in front of the line), so file descriptor 1 points at
+    # stderr for the whole run and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -583,7 +589,8 @@ def main():
             except Exception as e:  # noqa: BLE001 -- the GPU line is still worth printing
                 out["cpu_baseline"] = {"value": None, "unit": "lookups/s", "cores": host_cores(), "kind": "port",
                                        "sample": f"failed: {type(e).__name__}: {e}"}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if world > 1 or args.force_sharded:
         dist.barrier()
         dist.destroy_process_group()

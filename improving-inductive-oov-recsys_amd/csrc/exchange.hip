@@ -44,7 +44,7 @@ __device__ __forceinline__ int owner_of(int64_t id, int64_t per, double inv_per,
 // no other workgroup ever wrote) and resets the scratch.  my_rank >= 0 additionally COMPACTS the lookups this rank owns
 // itself into `local_rows` (their answers never cross a link): they get slots world * cap + position, behind the slots
 // of the exchanged answers, and the send segment of my_rank stays empty.
-constexpr int kSmallWorld = 16, kUnroll = 4;
+constexpr int kSmallWorld = 16, kUnroll = 4, kFillers = 32;
 template <bool FUSED>
 __global__ __launch_bounds__(256) void bucket_by_owner_small_kernel(const int64_t* __restrict__ ids, int64_t B, int64_t n_rows,
                                                                    int64_t per, int world, int64_t cap, int64_t chunk,
@@ -67,12 +67,15 @@ __global__ __launch_bounds__(256) void bucket_by_owner_small_kernel(const int64_
   for (int w = 0; w < kSmallWorld; ++w) wcnt[w] = 0;
   // kUnroll ids per thread are requested together (the ballots make the iterations dependent: without this one load
   // round trip per 256 lookups is exposed)
+  const bool one_round = iters <= kUnroll;  // (a 65536-lookup call: 1024 per workgroup) the ids stay in registers for pass 2
+  int64_t idkeep[kUnroll];
   for (int64_t it = 0; it < iters; it += kUnroll) {
     int64_t idv[kUnroll];
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
       const int64_t b = lo + (it + j) * 256 + threadIdx.x;
       idv[j] = (b < hi) ? ids[b] : -1;
+      idkeep[j] = idv[j];
     }
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(256) void bucket_by_owner_small_kernel(const int64_
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
       const int64_t b = lo + (it + j) * 256 + threadIdx.x;
-      idv[j] = (b < hi) ? ids[b] : -1;
+      idv[j] = one_round ? idkeep[j] : ((b < hi) ? ids[b] : -1);
     }
 #pragma unroll
     for (int j = 0; j < kUnroll; ++j) {
@@ -148,26 +151,39 @@ __global__ __launch_bounds__(256) void bucket_by_owner_small_kernel(const int64_
     }
   }
   if constexpr (FUSED) {
-    // the last workgroup to get here sees every reservation (they are atomics, performed in one place for all XCDs)
+    // The last nfill workgroups to get here fill the tails together, once EVERY workgroup has made its reservations (they
+    // are atomics, performed in one place for all XCDs; at most nfill - 1 workgroups wait, for workgroups that are running
+    // or still to be dispatched); one workgroup alone took 5 us for the 64 K tail entries of a 1 M-lookup call.
     __syncthreads();
+    const unsigned G = gridDim.x;
+    const unsigned nfill = G < static_cast<unsigned>(kFillers) ? G : static_cast<unsigned>(kFillers);
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(scratch + kSmallWorld, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const unsigned ticket = s_last;
+    if (ticket + nfill < G) return;
+    const unsigned f = ticket - (G - nfill);
     if (threadIdx.x == 0)
-      s_last = __hip_atomic_fetch_add(scratch + kSmallWorld, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+      while (__hip_atomic_load(scratch + kSmallWorld, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < G) __builtin_amdgcn_s_sleep(1);
     __syncthreads();
-    if (!s_last) return;
     if (threadIdx.x < kSmallWorld)
       s_cnt[threadIdx.x] = threadIdx.x < world ? static_cast<int32_t>(__hip_atomic_load(scratch + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
     __syncthreads();
-    if (threadIdx.x < world) counts[threadIdx.x] = s_cnt[threadIdx.x];
+    if (f == 0 && threadIdx.x < world) counts[threadIdx.x] = s_cnt[threadIdx.x];
+    const int64_t step = static_cast<int64_t>(nfill) * 256;
     for (int w = 0; w < world; ++w) {  // unused entries of a segment are -1: positions nobody wrote
       const int64_t from = (w == my_rank) ? 0 : (s_cnt[w] < cap ? s_cnt[w] : cap);
       int64_t* seg = send + static_cast<int64_t>(w) * cap;
-      for (int64_t q = from + threadIdx.x; q < cap; q += 256) seg[q] = -1;
+      for (int64_t q = from + static_cast<int64_t>(f) * 256 + threadIdx.x; q < cap; q += step) seg[q] = -1;
     }
     if (my_rank >= 0 && my_rank < world) {
       const int64_t from = s_cnt[my_rank] < cap ? s_cnt[my_rank] : cap;
-      for (int64_t q = from + threadIdx.x; q < cap; q += 256) local_rows[q] = -1;
+      for (int64_t q = from + static_cast<int64_t>(f) * 256 + threadIdx.x; q < cap; q += step) local_rows[q] = -1;
     }
-    if (threadIdx.x <= kSmallWorld) __hip_atomic_fetch_and(scratch + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // (this workgroup has read the counters)
+    if (threadIdx.x == 0 &&
+        __hip_atomic_fetch_add(scratch + kSmallWorld + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nfill - 1)
+      for (int i = 0; i < kSmallWorld + 2; ++i)  // every filler is past the counters: zero for the next launch
+        __hip_atomic_fetch_and(scratch + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -364,7 +380,7 @@ extern "C" int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_r
   return check_launch();
 }
 
-extern "C" int64_t mi_oov_bucket_by_owner_scratch(void) { return mi_oov::kSmallWorld + 1; }  // 32-bit words
+extern "C" int64_t mi_oov_bucket_by_owner_scratch(void) { return mi_oov::kSmallWorld + 2; }  // 32-bit words
 
 extern "C" int mi_oov_bucket_by_owner_fused(const int64_t* ids, int64_t B, int64_t n_rows, int64_t rows_per_rank, int64_t world,
                                             int64_t cap, int64_t my_rank, int64_t* send, int32_t* slot, int32_t* counts,

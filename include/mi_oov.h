@@ -150,8 +150,8 @@ int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_rows, int64_
 
 /* The same in ONE launch (round 4; world <= 16, B > 0): no memset, no second kernel for the segments' tails -- the
  * reservations are made in `scratch` (u32[mi_oov_bucket_by_owner_scratch()], caller-owned, ZERO at the first launch and left
- * zero by every launch: allocate once per stream), and the last workgroup to finish writes counts[], fills the unused
- * entries with -1 and resets the scratch.  my_rank >= 0 also COMPACTS the lookups whose row this rank owns itself:
+ * zero by every launch: allocate once per stream), and the last workgroups to finish write counts[], fill the unused
+ * entries with -1 and reset the scratch.  my_rank >= 0 also COMPACTS the lookups whose row this rank owns itself:
  * local_rows i64[cap] receives their local row numbers (-1 behind the last), their slots are world * cap + position -- a
  * caller that appends the codes it computes for local_rows behind the world * cap exchanged ones hands the whole array to
  * mi_oov_lsh_codes_embed (M = (world + 1) * cap) -- and the send segment of my_rank stays empty (-1).  my_rank < 0:
