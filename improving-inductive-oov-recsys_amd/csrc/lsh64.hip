@@ -615,8 +615,11 @@ int launch_lsh64_persistent_single(const int64_t* ids, int64_t B, const float* f
 constexpr int64_t kCodesMinB = 262144;
 // One batch of scores from this many lookups on: the persistent, software-pipelined kernel (a wave then walks several
 // tile pairs; below, the one-tile-per-wave launch of this file is faster).  MI_OOV_PERSIST_MIN_B: developer knob.
+// Round 4 sweep (tools/single_sizes.py under MI_OOV_PERSIST_MIN_B = 65536 ... 524288, us per call, this kernel / the persistent
+// one): 65536 lookups 8.9 / 10.9, 131072: 14.7 / 16.5, 262144: 28.5 / 27.4, 524288: 50.7 / 49.9 -- the persistent kernel's
+// head (pointer hop, table load, first burst) is only paid back from a quarter of a million lookups on.
 static int64_t persist_min_b() {
-  static const int64_t v = env_knob("MI_OOV_PERSIST_MIN_B", 524288, 1, int64_t(1) << 40);
+  static const int64_t v = env_knob("MI_OOV_PERSIST_MIN_B", 262144, 1, int64_t(1) << 40);
   return v;
 }
 static bool codes_persistent_enabled() {

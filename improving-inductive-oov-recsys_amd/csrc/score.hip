@@ -1170,11 +1170,22 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // (pass 1 runs ~3 workgroups per CU anyway -- 800 working workgroups -- and at 128 registers it spills: the reload's
 // s_waitcnt vmcnt(0) then also waits for the block prefetch)
-template <int EPI, bool MASKED, int KH = 1>
+// F32A (round 4; pass 1 against a PREPARED catalogue, rows of exactly 64 KH aligned floats): the user rows are staged straight
+// from the caller's f32 matrix -- converted while they go to LDS, the rounding of to_bf16_norm_kernel -- and the workgroups
+// of strip 0 leave what the later kernels read: the bf16 copy (filter pass), the squared norms (tau kernel) and the zeroed
+// overflow counters.  The call is then four launches instead of five: with the catalogue prepared the conversion launch
+// had 1 MB to convert and cost its 5.4 us of kernel boundary all the same.
+struct FoldU {
+  const float* U;   // [B, 64 KH] f32 user rows (null: the bf16 copy Ub is read, as before)
+  __bf16* Ub_out;   // [B, 64 KH]
+  float* u2;        // [B]
+  int* zero_rows;   // [B] overflow counters
+};
+template <int EPI, bool MASKED, int KH = 1, bool F32A = false>
 __global__ __launch_bounds__(kBlock, KH == 2 ? 2 : (EPI == EPI_TILEMAX ? 3 : 4)) void bf16_tile_kernel(const __bf16* __restrict__ Ub, int64_t B,
                                                              const __bf16* __restrict__ Eb, int64_t N,
                                                              const float* __restrict__ thr, TopkArgs ta, StripLists sl,
-                                                             int nvisit) {
+                                                             int nvisit, FoldU fold = FoldU{}) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   __bf16* sA = reinterpret_cast<__bf16*>(smem);  // [KH][BM][BLD]
   __bf16* sB = sA + KH * BM * BLD;               // [KH][BN][BLD]
@@ -1198,6 +1209,39 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 2 : (EPI == EPI_TILEMAX ? 3 : 4))
   const int brow = tid & 31, bchunk = tid >> 5;     // ... of E (fragment order, eb_chunk): thread = (row of a 32-row tile, chunk)
   u32x4 pf[KH][4];  // the next block of E (a native vector type: an array of HIP's uint4 struct lands in scratch)
 
+  if constexpr (F32A) {
+    // thread (erow, eoff): eight consecutive floats of a row per half, rows erow, erow + 32, ...; the eight threads of a row
+    // (a DPP row's lanes 8 i .. 8 i + 7) add their squares up for the norm
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int r = erow + 32 * q;
+      const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
+      float sq = 0.f;
+#pragma unroll
+      for (int h = 0; h < KH; ++h) {
+        const float4* src = reinterpret_cast<const float4*>(fold.U + ra * (64 * KH) + h * 64 + eoff);
+        const float4 x0 = src[0], x1 = src[1];
+        u32x4 pk;
+        pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x0.x), static_cast<__bf16>(x0.y)});
+        pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x0.z), static_cast<__bf16>(x0.w)});
+        pk.z = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x1.x), static_cast<__bf16>(x1.y)});
+        pk.w = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x1.z), static_cast<__bf16>(x1.w)});
+        *reinterpret_cast<u32x4*>(sA + (h * BM + r) * BLD + eoff) = pk;
+        if (strip == 0 && r < rows_here) *reinterpret_cast<u32x4*>(fold.Ub_out + ra * (64 * KH) + h * 64 + eoff) = pk;
+        sq = __builtin_fmaf(x0.x, x0.x, sq); sq = __builtin_fmaf(x0.y, x0.y, sq);
+        sq = __builtin_fmaf(x0.z, x0.z, sq); sq = __builtin_fmaf(x0.w, x0.w, sq);
+        sq = __builtin_fmaf(x1.x, x1.x, sq); sq = __builtin_fmaf(x1.y, x1.y, sq);
+        sq = __builtin_fmaf(x1.z, x1.z, sq); sq = __builtin_fmaf(x1.w, x1.w, sq);
+      }
+      sq = sq + __shfl_xor(sq, 1, 64);
+      sq = sq + __shfl_xor(sq, 2, 64);
+      sq = sq + __shfl_xor(sq, 4, 64);
+      if (strip == 0 && r < rows_here && (tid & 7) == 0) {
+        fold.u2[ra] = sq;
+        fold.zero_rows[ra] = 0;
+      }
+    }
+  }
 #pragma unroll
   for (int h = 0; h < KH; ++h)
 #pragma unroll
@@ -1205,7 +1249,8 @@ __global__ __launch_bounds__(kBlock, KH == 2 ? 2 : (EPI == EPI_TILEMAX ? 3 : 4))
       const int r = erow + 32 * q;
       const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
       const int64_t n0 = static_cast<int64_t>(strip) * stride * BN;
-      *reinterpret_cast<u32x4*>(sA + (h * BM + r) * BLD + eoff) = *reinterpret_cast<const u32x4*>(Ub + ra * (64 * KH) + h * 64 + eoff);
+      if constexpr (!F32A)
+        *reinterpret_cast<u32x4*>(sA + (h * BM + r) * BLD + eoff) = *reinterpret_cast<const u32x4*>(Ub + ra * (64 * KH) + h * 64 + eoff);
       *reinterpret_cast<u32x4*>(sB + (h * BN + brow + 32 * q) * BLD + bchunk * 8) =
           *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n0 + brow + 32 * q, h * 8 + bchunk));
     }
@@ -2185,23 +2230,34 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       int64_t gu = grid_for(B, kBlock / 16);
       const int64_t ge = catalogue_parts(N);
       if (gu > kNormGrid) gu = kNormGrid;
-      if (kh == 2)
-        hipLaunchKernelGGL(to_bf16_norm_kernel<2>, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
-                           sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max, static_cast<int>(D));
-      else
-        hipLaunchKernelGGL(to_bf16_norm_kernel<1>, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
-                           sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max, static_cast<int>(D));
-      if ((rc = check_launch())) return rc;
+      // prepared catalogue + rows of exactly 64 / 128 aligned floats: pass 1 converts the user rows itself (FoldU)
+      static const bool fold_on = env_knob("MI_OOV_TOPK_FOLD_U", 1, 0, 1) != 0;  // developer A/B knob
+      const bool fold_u = fold_on && catalogue && D == 64 * kh && vec;
+      if (!fold_u) {
+        if (kh == 2)
+          hipLaunchKernelGGL(to_bf16_norm_kernel<2>, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
+                             sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max, static_cast<int>(D));
+        else
+          hipLaunchKernelGGL(to_bf16_norm_kernel<1>, dim3(static_cast<unsigned>(gu + (catalogue ? 0 : ge))), dim3(kBlock), 0, st, U, B, Ub, u2,
+                             sl.ovf_cnt, static_cast<int>(gu), E, N, Eb, e2max, static_cast<int>(D));
+        if ((rc = check_launch())) return rc;
+      }
       const size_t lds_ops = static_cast<size_t>(BM + BN) * BLD * sizeof(__bf16) * kh;
       const size_t lds_filter = lds_ops + BM * (sizeof(float) + sizeof(int)) + 4 * kWaveQueue * 6;
+      const FoldU fold{fold_u ? U : nullptr, Ub, u2, sl.ovf_cnt};
       auto launch_tile = [&](auto kern, size_t lds, int64_t ns, const float* thr_arg, int64_t nvisit) -> int {
         if (int rc2 = set_lds(kern, lds)) return rc2;  // (two k-halves: 73.7 KiB of operands)
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(ns), static_cast<unsigned>(rb)), dim3(kBlock), lds, st, Ub, B, Eb, N, thr_arg, ta, sl,
-                           static_cast<int>(nvisit));
+                           static_cast<int>(nvisit), fold);
         return MI_OOV_OK;
       };
-      if (kh == 2) rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 2>, lds_ops, ns1, nullptr, nvisit1)
-                             : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 2>, lds_ops, ns1, nullptr, nvisit1);
+      if (fold_u) {
+        if (kh == 2) rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 2, true>, lds_ops, ns1, nullptr, nvisit1)
+                               : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 2, true>, lds_ops, ns1, nullptr, nvisit1);
+        else rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 1, true>, lds_ops, ns1, nullptr, nvisit1)
+                       : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 1, true>, lds_ops, ns1, nullptr, nvisit1);
+      } else if (kh == 2) rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 2>, lds_ops, ns1, nullptr, nvisit1)
+                                    : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 2>, lds_ops, ns1, nullptr, nvisit1);
       else rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 1>, lds_ops, ns1, nullptr, nvisit1)
                      : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 1>, lds_ops, ns1, nullptr, nvisit1);
       if (rc) return rc;
