@@ -1540,7 +1540,13 @@ __device__ __forceinline__ uint32_t bf16_bits_rne(float v) {  // finite v
   return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
 
-template <bool MASKED, int MT, int KH = 1>  // MT 32-row tiles = the workgroup's user rows (every wave holds all of them)
+// RARE (round 4): for searches in which a wave's block of 64 x 32 scores seldom holds a single passing one -- small k over a
+// big catalogue: the 10 M-row knn search lets ~8 in a million through -- ONE test of the lane's whole set of accumulators
+// comes first (a max3 tree: 16 vector instructions and a ballot) and the per-group tests, ballots and branches run only if
+// some lane passes.  Vector and scalar instructions do not hide behind the matrix pipe in this kernel (MI_FD_PAD above), so
+// ~40 fewer of them per block is time: 6.32 -> X ms for 4096 x 10 M, k = 2.  Chosen by the host from the expected number of
+// passing scores per wave and block.
+template <bool MASKED, int MT, int KH = 1, bool RARE = false>  // MT 32-row tiles = the workgroup's user rows (every wave holds all of them)
 __global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
                                                                        const __bf16* __restrict__ Eb, int64_t N,
                                                                        const float* __restrict__ thr, TopkArgs ta, StripLists sl,
@@ -1706,6 +1712,37 @@ __global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_fil
 #endif
     const uint32_t tag0 = (static_cast<uint32_t>(j) << 12) | static_cast<uint32_t>(lane);
     auto bits = [&](int v) { return v < NV ? static_cast<int>(__float_as_uint(acc[v >> 4][v & 15])) : kNegInfBits; };
+    if constexpr (RARE) {
+      // the largest of the lane's NV images (as signed integers: see below) by a tree of three-input maxima
+      int t[NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int x0 = bits(3 * g), x1 = bits(3 * g + 1), x2 = bits(3 * g + 2);
+        int mx = x0 > x1 ? x0 : x1;
+        t[g] = mx > x2 ? mx : x2;
+      }
+      int n = NG;
+#pragma unroll
+      for (int level = 0; level < 3; ++level) {  // 11 (22) -> 4 (8) -> 2 (3) -> 1
+        const int m3 = (n + 2) / 3;
+#pragma unroll
+        for (int q = 0; q < NG; ++q)
+          if (q < m3) {
+            const int a = t[3 * q], b = 3 * q + 1 < n ? t[3 * q + 1] : kNegInfBits, c = 3 * q + 2 < n ? t[3 * q + 2] : kNegInfBits;
+            int mx = a > b ? a : b;
+            t[q] = mx > c ? mx : c;
+          }
+        n = m3;
+      }
+      if (__ballot(t[0] > kNegInfBits) == 0) {
+#if MI_FD_PRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) bq[ks] = bn[ks];
+        continue;
+      }
+    }
     uint64_t gm[NG];
     uint64_t any = 0;
 #pragma unroll
@@ -2196,8 +2233,13 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       const bool direct = direct_on && nblk < (1 << 20);  // (a queue record has 20 bits for the block)
       // direct pass 2: workgroups of 64 user rows (2 tiles of 32: 123 registers, 4 waves per SIMD) and one round of 1024;
       // MI_OOV_FILTER_TILES=4: 128 rows, 211 registers, 2 waves per SIMD, 512 workgroups (48 us instead of 41)
-      static const int mt_env = env_knob("MI_OOV_FILTER_TILES", 2, 2, 4) == 4 ? 4 : 2;  // 2 or 4 tiles of 32 user rows
-      const int mt = kh == 2 ? 2 : ((B + 63) / 64 > 65535 ? 4 : mt_env);  // (grid.y; two k-halves: 64-row workgroups only)
+      // Rows per workgroup: 64 (four waves per SIMD) while the bf16 catalogue is served by the L2s -- every strip's blocks are
+      // read by all B / 64 row blocks, 13 TB/s of L2 -> CU traffic at 10 M rows --; 128 (half that traffic, two waves per
+      // SIMD) once an XCD's share of the copy no longer fits its 4 MB: 4096 x 10 M, k = 2: 6.24 -> 5.33 ms; 4096 x 50 000:
+      // 85 -> 92 us, so not there.  MI_OOV_FILTER_TILES (developer knob): 2 or 4 = force, 0 = by size.
+      static const int mt_env = static_cast<int>(env_knob("MI_OOV_FILTER_TILES", 0, 0, 4));
+      const int mt_auto = eb_rows(N) * 128 / 8 > (4 << 20) ? 4 : 2;
+      const int mt = kh == 2 ? 2 : ((B + 63) / 64 > 65535 ? 4 : (mt_env == 4 ? 4 : (mt_env == 2 ? 2 : mt_auto)));  // (grid.y; two k-halves: 64-row workgroups only)
       static const int64_t target_env = env_knob("MI_OOV_STRIP_WGS2", 0, 0, 65536);
       const int64_t target_d = target_env > 0 ? target_env : (mt == 2 ? 1024 : 512);
       const int64_t rbd = (B + mt * 32 - 1) / (mt * 32);
@@ -2279,14 +2321,22 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rbd)), dim3(kBlock), lds_direct, st, Ub, B, Eb, N, thr, ta, sl,
                            static_cast<int>(nblk));
       };
+      // expected passing scores per wave and block: ~1.3 k stride candidates (+ the 2 eps slack) per row of N scores, 64 rows
+      // x 32 columns per wave and block; below a quarter the whole-lane test comes first (RARE)
+      static const int64_t rare_env = env_knob("MI_OOV_FILTER_RARE", -1, -1, 1);  // developer knob: force off / on
+      const double lam = 2048.0 * 2.0 * 1.3 * static_cast<double>(k) * static_cast<double>(L.stride) / static_cast<double>(N);
+      const bool rare = rare_env >= 0 ? rare_env == 1 : lam < 0.25;
       if (direct && kh == 2) {  // 128-k rows: the user fragments alone are 64 registers per 64 rows -- workgroups of 64 rows
         if (mask) launch_direct(bf16_filter_direct_kernel<true, 2, 2>);
+        else if (rare) launch_direct(bf16_filter_direct_kernel<false, 2, 2, true>);
         else launch_direct(bf16_filter_direct_kernel<false, 2, 2>);
       } else if (direct && mask) {
         if (mt == 2) launch_direct(bf16_filter_direct_kernel<true, 2>);
         else launch_direct(bf16_filter_direct_kernel<true, 4>);
       } else if (direct) {
-        if (mt == 2) launch_direct(bf16_filter_direct_kernel<false, 2>);
+        if (mt == 2 && rare) launch_direct(bf16_filter_direct_kernel<false, 2, 1, true>);
+        else if (mt == 2) launch_direct(bf16_filter_direct_kernel<false, 2>);
+        else if (rare) launch_direct(bf16_filter_direct_kernel<false, 4, 1, true>);
         else launch_direct(bf16_filter_direct_kernel<false, 4>);
       } else if (kh == 2) {
         rc = mask ? launch_tile(bf16_tile_kernel<EPI_FILTER, true, 2>, lds_filter, ns2, thr, nblk)
