@@ -160,12 +160,13 @@ constexpr int kNumMetrics = 6;
 
 __global__ __launch_bounds__(kBlock) void topk_metric_curves_kernel(const int32_t* __restrict__ rec, int64_t U, int K,
                                                                     const double* __restrict__ disc, const double* __restrict__ idcg_base,
+                                                                    const int64_t* __restrict__ uids, int64_t n_old_users,
                                                                     double* __restrict__ val, uint8_t* __restrict__ nanrow) {
   for (int64_t u = static_cast<int64_t>(blockIdx.x) * kBlock + threadIdx.x; u < U; u += static_cast<int64_t>(gridDim.x) * kBlock) {
     const int32_t* r = rec + u * (K + 1);
     const int64_t pos_len = r[K];
     const int64_t n = pos_len < K ? pos_len : K;  // np.minimum(pos_len, K)
-    nanrow[u] = pos_len == 0 ? 1 : 0;
+    nanrow[u] = (pos_len == 0 ? 1 : 0) | ((uids && uids[u] < n_old_users) ? 2 : 0);  // flags: no positive | old user
     int64_t cum = 0;
     int first = -1;
     double dcg = 0.0, sum_pre = 0.0;
@@ -189,43 +190,103 @@ __global__ __launch_bounds__(kBlock) void topk_metric_curves_kernel(const int32_
   }
 }
 
-// side 0: every user; 1: users with id < n_old_users; 2: the others
-__global__ __launch_bounds__(64) void topk_metric_sums_kernel(const double* __restrict__ val, const uint8_t* __restrict__ nanrow,
-                                                              const int64_t* __restrict__ uids, int64_t n_old_users, int64_t U, int K,
-                                                              double* __restrict__ sums, int64_t* __restrict__ counts) {
+// side 0: every user; 1: users with id < n_old_users (flag bit 1 of phase 1); 2: the others.
+// One workgroup per (side, metric): wave 0 is the CHAIN -- user after user, one float64 addition per user and rank, that is
+// the point -- and waves 1-3 feed it: they copy the curves of the next chunk of users (up to 32 KB, contiguous in memory) into
+// the other LDS buffer, all of a thread's loads in flight together, a user that does not count landing as +0.0 (x + 0.0 == x
+// for these sums: no curve value is negative or -0 and a sum that starts at +0.0 stays >= +0.0), so the chain reads one double
+// per user and nothing else.  History of this kernel at 36 000 users x 10 ranks (one evaluation calls it three times): eight
+// users' loads per round trip 10.7 ms; chunks staged through LDS 5.3; no branch per user 2.1; everything in ONE wave --
+// requesting, landing and adding each cost ~0.4 ms of a lone wave's issue slots -- 1.2; feeders beside the chain: 0.40 ms (the chain itself: ~25 cycles per user).
+constexpr int kSumChunk = 4096;   // doubles per LDS buffer
+constexpr int kFeeders = 192;     // threads of waves 1-3
+__global__ __launch_bounds__(256) void topk_metric_sums_kernel(const double* __restrict__ val, const uint8_t* __restrict__ flags,
+                                                               int64_t U, int K, double* __restrict__ sums, int64_t* __restrict__ counts) {
+  __shared__ double buf[2][kSumChunk];
+  __shared__ int s_cnt;
   const int side = blockIdx.x / kNumMetrics, m = blockIdx.x % kNumMetrics;
-  const int lane = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const bool feeder = tid >= 64;
+  const int p = tid - 64;  // feeder index
   const double* v = val + static_cast<int64_t>(m) * U * K;
-  double acc[4] = {0.0, 0.0, 0.0, 0.0};  // ranks lane, lane + 64, lane + 128, lane + 192 (K <= 256)
-  int64_t cnt = 0;
-  constexpr int R = 8;  // users whose loads are in flight together
-  for (int64_t u0 = 0; u0 < U; u0 += R) {
-    double x[R][4];
-    bool sel[R];
+  const int CH = kSumChunk / K;  // users per chunk (K <= 256: at least 16)
+  constexpr int R = (kSumChunk + kFeeders - 1) / kFeeders;  // elements of a chunk per feeder
+  if (tid == 0) s_cnt = 0;
+  auto counts_user = [&](uint8_t f) {
+    bool s_ = true;
+    if (side != 0) s_ = ((f & 2) != 0) == (side == 1);
+    if (m == 0) s_ = s_ && (f & 1) == 0;
+    return s_;
+  };
+  int my_cnt = 0;
+  auto stage = [&](int64_t u0, int b) {  // feeders: users [u0, u0 + CH) -> buf[b]
+    const int64_t nu = U - u0 < CH ? U - u0 : CH;
+    const int64_t n = nu * K;
+    const double* src = v + u0 * K;
+    double x[R];
+    uint8_t f[R];
+    // element i = j kFeeders + p belongs to user i / K, followed incrementally
+    int uu = p / K, rr = p % K;
+    const int du = kFeeders / K, dr = kFeeders % K;
+    int uj = uu, rj = rr;
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-      const int64_t u = u0 + j;
-      const bool live = u < U;
-      const int64_t uc = live ? u : U - 1;
-      bool s = live;
-      if (side != 0) s = s && ((uids[uc] < n_old_users) == (side == 1));
-      if (m == 0) s = s && nanrow[uc] == 0;
-      sel[j] = s;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) x[j][q] = (lane + 64 * q < K) ? v[uc * K + lane + 64 * q] : 0.0;
+      const int64_t i = static_cast<int64_t>(j) * kFeeders + p;
+      x[j] = i < n ? src[i] : 0.0;
+      f[j] = i < n ? flags[u0 + uj] : 0;
+      uj += du;
+      rj += dr;
+      if (rj >= K) { rj -= K; ++uj; }
     }
 #pragma unroll
-    for (int j = 0; j < R; ++j)
-      if (sel[j]) {  // wave-uniform
-        ++cnt;
+    for (int j = 0; j < R; ++j) {
+      const int64_t i = static_cast<int64_t>(j) * kFeeders + p;
+      const bool s_ = i < n && counts_user(f[j]);
+      if (i < kSumChunk) buf[b][i] = s_ ? x[j] : 0.0;
+      if (s_ && rr == 0) ++my_cnt;  // (the element of rank 0 stands for its user)
+      uu += du;
+      rr += dr;
+      if (rr >= K) { rr -= K; ++uu; }
+    }
+  };
+  if (feeder && U > 0) stage(0, 0);
+  __syncthreads();
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};  // ranks lane, lane + 64, lane + 128, lane + 192
+  int b = 0;
+  for (int64_t u0 = 0; u0 < U; u0 += CH, b ^= 1) {
+    if (feeder) {
+      if (u0 + CH < U) stage(u0 + CH, b ^ 1);
+    } else {
+      const int64_t nu = U - u0 < CH ? U - u0 : CH;
+      if (K <= 64) {
+        const int kl = lane < K ? lane : 0;
+        constexpr int G = 16;  // users whose LDS reads are issued together, then added in order
+        int64_t j = 0;
+        for (; j + G <= nu; j += G) {
+          double xv[G];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = acc[q] + x[j][q];
+          for (int t = 0; t < G; ++t) xv[t] = buf[b][(j + t) * K + kl];
+#pragma unroll
+          for (int t = 0; t < G; ++t) acc[0] = acc[0] + xv[t];
+        }
+        for (; j < nu; ++j) acc[0] = acc[0] + buf[b][j * K + kl];
+      } else {
+        for (int64_t j = 0; j < nu; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (lane + 64 * q < K) acc[q] = acc[q] + buf[b][j * K + lane + 64 * q];
       }
+    }
+    __syncthreads();
   }
+  if (feeder && my_cnt) atomicAdd(&s_cnt, my_cnt);
+  __syncthreads();
+  if (!feeder) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q)
-    if (lane + 64 * q < K) sums[(static_cast<int64_t>(side) * kNumMetrics + m) * K + lane + 64 * q] = acc[q];
-  if (lane == 0) counts[side * kNumMetrics + m] = cnt;
+    for (int q = 0; q < 4; ++q)
+      if (lane + 64 * q < K) sums[(static_cast<int64_t>(side) * kNumMetrics + m) * K + lane + 64 * q] = acc[q];
+    if (lane == 0) counts[side * kNumMetrics + m] = s_cnt;
+  }
 }
 
 }  // namespace mi_oov
@@ -256,10 +317,10 @@ extern "C" int mi_oov_topk_metric_sums(const int32_t* rec, int64_t U, int64_t K,
   double* val = static_cast<double*>(workspace);
   uint8_t* nanrow = reinterpret_cast<uint8_t*>(val + kNumMetrics * U * K);
   hipLaunchKernelGGL(topk_metric_curves_kernel, dim3(grid_for(U, kBlock)), dim3(kBlock), 0, st, rec, U, static_cast<int>(K), disc, idcg_base,
-                     val, nanrow);
+                     n_sides == 3 ? uids : static_cast<const int64_t*>(nullptr), n_old_users, val, nanrow);
   if (int rc = check_launch()) return rc;
-  hipLaunchKernelGGL(topk_metric_sums_kernel, dim3(static_cast<unsigned>(n_sides * kNumMetrics)), dim3(64), 0, st, val, nanrow, uids,
-                     n_old_users, U, static_cast<int>(K), sums, counts);
+  hipLaunchKernelGGL(topk_metric_sums_kernel, dim3(static_cast<unsigned>(n_sides * kNumMetrics)), dim3(256), 0, st, val, nanrow, U,
+                     static_cast<int>(K), sums, counts);
   return check_launch();
 }
 

@@ -1544,7 +1544,7 @@ __device__ __forceinline__ uint32_t bf16_bits_rne(float v) {  // finite v
 // big catalogue: the 10 M-row knn search lets ~8 in a million through -- ONE test of the lane's whole set of accumulators
 // comes first (a max3 tree: 16 vector instructions and a ballot) and the per-group tests, ballots and branches run only if
 // some lane passes.  Vector and scalar instructions do not hide behind the matrix pipe in this kernel (MI_FD_PAD above), so
-// ~40 fewer of them per block is time: 6.32 -> X ms for 4096 x 10 M, k = 2.  Chosen by the host from the expected number of
+// ~40 fewer of them per block is time: 6.46 -> 6.33 ms for 4096 x 10 M, k = 2 with 64-row workgroups -- little: that search is bound by the L2s feeding B, see the rows-per-workgroup choice in score_topk_impl.  Chosen by the host from the expected number of
 // passing scores per wave and block.
 template <bool MASKED, int MT, int KH = 1, bool RARE = false>  // MT 32-row tiles = the workgroup's user rows (every wave holds all of them)
 __global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
