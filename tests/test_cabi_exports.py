@@ -28,7 +28,7 @@ def test_every_header_symbol_is_exported(lib):
 def test_version_and_strerror(lib):
     assert lib.mi_oov_version() == 100
     assert lib.mi_oov_strerror(0) == b"ok"
-    for code in range(-6, 0):
+    for code in range(-7, 0):
         assert lib.mi_oov_strerror(code) != b"unknown error code"
     assert lib.mi_oov_strerror(-99) == b"unknown error code"
 
@@ -88,6 +88,37 @@ def test_argument_validation_of_the_widened_entry_points(lib):
     assert lib.mi_oov_linear_x3(None, 4, 16, None, None, 8, 7, None, None) == -3              # unknown activation
     assert lib.mi_oov_linear_x3(None, 4, 16, None, None, 8, 1, None, None) == -1 and lib.mi_oov_linear_x3(None, 0, 16, None, None, 8, 1, None, None) == 0
     assert lib.mi_oov_last_hip_error() == 0                                                  # nothing touched the GPU
+
+
+def test_argument_validation_of_the_round4_entry_points(lib):
+    """Evaluation rows / duplicates / metric sums, the dense exclusion route, the fused backward and the fused bucketing: sizes
+    and error codes, all checked before any HIP call."""
+    assert lib.mi_oov_eval_rows_build(None, -1, None, None, None, 5, None, None, None, None, None) == -2
+    assert lib.mi_oov_eval_rows_build(None, 3, None, None, None, 5, None, None, None, None, None) == -1   # seg_ptr NULL
+    assert lib.mi_oov_segment_dedup(None, None, 0, None, None) == 0 and lib.mi_oov_segment_dedup(None, None, 3, None, None) == -1
+    assert lib.mi_oov_segment_dedup(None, None, -1, None, None) == -2
+    assert lib.mi_oov_topk_hits_range(None, 3, 0, None, None, 0, 10, None, None) == -2
+    assert lib.mi_oov_topk_hits_range(None, 3, 10, None, None, 0, 10, None, None) == -1
+    assert lib.mi_oov_topk_metric_sums_workspace(36000, 10) >= 6 * 36000 * 10 * 8 + 36000 and lib.mi_oov_topk_metric_sums_workspace(0, 10) == 0
+    assert lib.mi_oov_topk_metric_sums(None, 5, 300, None, None, None, 0, 1, None, None, None, None) == -2      # K > 256
+    assert lib.mi_oov_topk_metric_sums(None, 5, 10, None, None, None, 0, 2, None, None, None, None) == -2       # sides: 1 or 3
+    assert lib.mi_oov_topk_metric_sums(None, 5, 10, None, None, None, 0, 1, None, None, None, None) == -1
+    assert lib.mi_oov_score_topk_excl_dense_workspace(100, 1000) >= 100 * 1000 * 4 + 100 * 16 * 8
+    assert lib.mi_oov_score_topk_excl_dense_workspace(0, 1000) == 0
+    assert lib.mi_oov_score_topk_excl_dense(None, 4, None, 0, 64, 10, 0, None, None, None, None, None, None) == -2
+    assert lib.mi_oov_score_topk_excl_dense(None, 4, None, 100, 64, 10, 0, None, None, None, None, None, None) == -1
+    assert lib.mi_oov_score_topk_excl_dense(None, 0, None, 100, 64, 10, 0, None, None, None, None, None, None) == 0
+    assert lib.mi_oov_lsh_backward_fused_workspace(65536, 9, 64) == 1024 * 16 * 64             # planes padded to groups of eight
+    assert lib.mi_oov_lsh_backward_fused_counters() >= 17
+    assert lib.mi_oov_lsh_embed_backward_fused(None, None, 5, 8, 300, None, None, None, None) == -2
+    assert lib.mi_oov_lsh_embed_backward_fused(None, None, 5, 8, 64, None, None, None, None) == -1
+    assert lib.mi_oov_slsh_embed_backward_fused(None, None, 5, 0, 64, None, None, None, None) == -2
+    assert lib.mi_oov_bucket_by_owner_scratch() >= 17
+    assert lib.mi_oov_bucket_by_owner_fused(None, 5, 100, 50, 17, 8, -1, None, None, None, None, None, None, None) == -2   # world > 16
+    assert lib.mi_oov_bucket_by_owner_fused(None, 0, 100, 50, 2, 8, -1, None, None, None, None, None, None, None) == -2    # empty batch
+    assert lib.mi_oov_bucket_by_owner_fused(None, 5, 100, 50, 2, 8, 2, None, None, None, None, None, None, None) == -2     # my_rank >= world
+    assert lib.mi_oov_bucket_by_owner_fused(None, 5, 100, 50, 2, 8, -1, None, None, None, None, None, None, None) == -1
+    assert lib.mi_oov_last_hip_error() == 0
 
 
 def test_header_is_plain_c(tmp_path):
