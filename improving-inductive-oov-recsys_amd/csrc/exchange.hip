@@ -342,6 +342,16 @@ int launch_lsh64_from_codes(const uint8_t* codes, int64_t M, const int32_t* slot
 
 }  // namespace mi_oov
 
+// Workgroups a bucketing launch aims at (chunks are a multiple of 1024 lookups, so small calls get fewer): every workgroup makes one
+// reservation per owner counter, ~11 ns each at the memory side whoever issues it, against which stands the parallelism of
+// the two passes.  Round 4 sweep, one launch alone on the GPU, us: 1 M ids 512 / 2048 workgroups 24.0 / 28.9; 4 M ids 512 /
+// 1024 / 2048 / 4096: 57.7 / 47.3 / 58.5 / 78.8.  MI_OOV_BUCKET_WGS (developer knob) forces a count.
+static int64_t bucket_wgs(int64_t B) {
+  static const int64_t v = mi_oov::env_knob("MI_OOV_BUCKET_WGS", 0, 0, 8192);
+  return v > 0 ? v : (B >= (int64_t(1) << 21) ? 1024 : 512);
+}
+#define kBucketWgs bucket_wgs(B)
+
 extern "C" int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_rows, int64_t rows_per_rank, int64_t world,
                                       int64_t cap, int64_t* send, int32_t* slot, int32_t* counts, int32_t* overflow,
                                       void* stream) {
@@ -363,9 +373,8 @@ extern "C" int mi_oov_bucket_by_owner(const int64_t* ids, int64_t B, int64_t n_r
     return check_launch();
   }
   if (!ids || !slot) return MI_OOV_ERR_NULL;
-  // chunks of a multiple of 1024 lookups, at most ~512 workgroups: <= 512 reservations per owner counter (an
-  // atomic on one address costs ~11 ns at the memory side whoever issues it)
-  int64_t chunk = (B + 511) / 512;
+  // chunks of a multiple of 1024 lookups, at most ~bucket_wgs() workgroups (reservations per owner counter)
+  int64_t chunk = (B + kBucketWgs - 1) / kBucketWgs;
   chunk = (chunk < 1024) ? 1024 : (chunk + 1023) / 1024 * 1024;
   const int grid = static_cast<int>((B + chunk - 1) / chunk);
   if (world <= kSmallWorld)
@@ -390,7 +399,7 @@ extern "C" int mi_oov_bucket_by_owner_fused(const int64_t* ids, int64_t B, int64
     return MI_OOV_ERR_SHAPE;  // (B = 0 and larger worlds: mi_oov_bucket_by_owner)
   if ((world + 1) * cap > (int64_t(1) << 31) - 1 || my_rank >= world) return MI_OOV_ERR_SHAPE;  // slots are int32
   if (!ids || !send || !slot || !counts || !scratch || (my_rank >= 0 && !local_rows)) return MI_OOV_ERR_NULL;
-  int64_t chunk = (B + 511) / 512;
+  int64_t chunk = (B + kBucketWgs - 1) / kBucketWgs;
   chunk = (chunk < 1024) ? 1024 : (chunk + 1023) / 1024 * 1024;
   const int grid = static_cast<int>((B + chunk - 1) / chunk);
   hipLaunchKernelGGL(bucket_by_owner_small_kernel<true>, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), ids, B, n_rows,
