@@ -397,7 +397,19 @@ static int launch64g(const int64_t* ids, int64_t B, const float* feat, int64_t N
 // dependent hop ids -> feature row -> bucket row through HBM (n_buckets = N: 12.95 -> see DESIGN.md section 5; the
 // rows are copies, so the output is the same bits).  The tile's 16 bucket ids leave in one store, the output rows with
 // non-temporal stores.  TAB: ids_src / out_src / idx_src are DEVICE arrays of K pointers (mi_oov_slsh_embed_multi).
-template <int DCH, bool TAB>
+// Pipeline (round 4): a wave that has more than one tile keeps the gathered rows of its NEXT tile and the ids of the one after
+// that in flight while it reduces the current one (ids(i+2) requested, rows(i+1) requested, tile i reduced and stored, in
+// that issue order -- the scheme of lsh64p.hip): with one tile's rows in flight per wave, 16 waves per CU hold 4 MB of
+// requests chip-wide, less than the ~10 MB that 5 TB/s x 2 us of latency want.  20 x 65536 lookups, same box, before -> after:
+// 24 planes, D = 64 (n_buckets = N): 146.7 -> 129.6 us; 10 planes, D = 128: 185 -> 176 us (0.72 of the HBM peak on moved
+// bytes); a single 65536-lookup launch, where a wave has one tile, is unchanged (11.4 -> 11.8, 11.8 -> 11.9).  At 24 planes
+// the projections are ~660 vector instructions per tile, ~88 us of issue per launch next to ~106 us of row traffic.  The steady-state loop holds no conditional
+// memory instruction (a load or store issued on one path only turns the waits behind it into vmcnt(0)): rows of a partial
+// tile beyond the batch are stored ONTO its last row -- their lanes were given the last row's id by the clamped id loads, so
+// they hold the same bits -- and what is stored at all is a template parameter (ROWS, IDX).  The ids of a tile are dead once
+// its rows are requested (validity is kept as a 4-bit mask), which is what lets the loop rotate without moving registers
+// that are still in flight.
+template <int DCH, bool TAB, bool ROWS, bool IDX>
 __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const void* __restrict__ ids_src, unsigned B, unsigned K,
                                                         const float* __restrict__ feat, int64_t N,
                                                         const float* __restrict__ planes, int H,
@@ -405,21 +417,55 @@ __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const void* __restrict_
                                                         void* __restrict__ out_src, void* __restrict__ idx_src) {
   constexpr int R = 4;
   typedef float v4f_ __attribute__((ext_vector_type(4)));
-  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4;
+  const unsigned wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned tpb = (B + 15) / 16;
   const unsigned ntiles = tpb * (TAB ? K : 1u);
   const unsigned tstep = gridDim.x * kWpb;
   const int G = (H + 7) / 8, HP = G * 8;
-  unsigned gtile = blockIdx.x * kWpb + wv;
-  auto ids_of = [&](unsigned t) -> const int64_t* {
-    return TAB ? reinterpret_cast<const int64_t* const*>(ids_src)[t / tpb] : static_cast<const int64_t*>(ids_src);
+  struct Tile {
+    unsigned batch, local;
   };
-  int64_t idc[4];
-  if (gtile < ntiles) load_tile_ids(ids_of(gtile), TAB ? gtile % tpb : gtile, B, l16, grp, idc);
+  auto tile_of = [&](unsigned t) {
+    Tile p;
+    p.batch = TAB ? t / tpb : 0u;
+    p.local = TAB ? t - p.batch * tpb : t;
+    return p;
+  };
+  // (pointers out of the tables are cast to the GLOBAL address space: through a generic pointer the compiler emits flat_load /
+  //  flat_store, which count against lgkmcnt as well as vmcnt and may return out of order -- every wait becomes vmcnt(0))
+  typedef const int64_t __attribute__((address_space(1))) * gptr_ci64;
+  typedef int64_t __attribute__((address_space(1))) * gptr_i64w;
+  typedef v4f_ __attribute__((address_space(1))) * gptr_v4w;
+  typedef const v4f_ __attribute__((address_space(1))) * gptr_cv4;
+  auto load_ids = [&](unsigned t, int64_t (&id)[4]) {
+    const Tile p = tile_of(t);
+    gptr_ci64 src = TAB ? (gptr_ci64) reinterpret_cast<const int64_t* const*>(ids_src)[p.batch] : (gptr_ci64)ids_src;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const unsigned row = p.local * 16u + r * 4u + grp;
+      id[r] = src[row < B ? row : B - 1u];  // clamped: tail groups recompute the last row (B >= 1 here)
+    }
+  };
+  // the 4 gathered rows of a tile; returns which of its 4 rounds address a row (the ids are not needed after this)
+  auto gather = [&](const int64_t (&id)[4], float4 (&x)[R]) -> unsigned {
+    unsigned ok = 0;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const bool v = static_cast<uint64_t>(id[r]) < static_cast<uint64_t>(N);
+      ok |= v ? (1u << r) : 0u;
+      const v4f_ g = *(gptr_cv4)(feat + (v ? id[r] : 0) * 64 + l16 * 4);
+      x[r] = make_float4(g.x, g.y, g.z, g.w);
+    }
+    return ok;
+  };
+  unsigned ta = blockIdx.x * kWpb + wv, tb = ta + tstep;
+  int64_t ida[4] = {0, 0, 0, 0}, idb[4] = {0, 0, 0, 0};
+  if (ta < ntiles) load_ids(ta, ida);
+  if (tb < ntiles) load_ids(tb, idb);
 
   extern __shared__ __attribute__((aligned(16))) float sw[];  // [HP][64] planes (rows >= H zero), [H + 1][64 DCH] reachable bucket rows
   float* srows = sw + HP * 64;
-  const bool want_rows = out_src != nullptr;
   {
     // every staging load first, then the LDS stores: one memory round trip in front of the barrier, not two
     constexpr int kPl = (32 * 16 + kBlk - 1) / kBlk, kRw = (33 * 16 * DCH + kBlk - 1) / kBlk;
@@ -433,7 +479,7 @@ __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const void* __restrict_
     for (int q = 0; q < kRw; ++q) {
       const int i = q * kBlk + static_cast<int>(threadIdx.x);
       rv[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (want_rows && i < (H + 1) * 16 * DCH) {
+      if (ROWS && i < (H + 1) * 16 * DCH) {
         const int c = i / (16 * DCH), e = i - c * (16 * DCH);
         const int64_t v = H + c;
         const int64_t b = v < n_buckets ? v : static_cast<int64_t>(static_cast<uint32_t>(v) % static_cast<uint32_t>(n_buckets));
@@ -448,35 +494,22 @@ __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const void* __restrict_
 #pragma unroll
     for (int q = 0; q < kRw; ++q) {
       const int i = q * kBlk + static_cast<int>(threadIdx.x);
-      if (want_rows && i < (H + 1) * 16 * DCH) *reinterpret_cast<float4*>(srows + i * 4) = rv[q];
+      if (ROWS && i < (H + 1) * 16 * DCH) *reinterpret_cast<float4*>(srows + i * 4) = rv[q];
     }
   }
   __syncthreads();
+  if (ta >= ntiles) return;
   const int bank = l16 >> 2;
   const int pl = ((bank & 1) << 1) | (bank >> 1);
   const int hl = H - (G - 1) * 8;
   const float last0 = (pl < hl) ? 1.f : 0.f, last1 = (4 + pl < hl) ? 1.f : 0.f;
 
-  while (gtile < ntiles) {
-    const unsigned batch = TAB ? gtile / tpb : 0u;
-    const unsigned tile = TAB ? gtile - batch * tpb : gtile;
-    float* out = want_rows ? (TAB ? reinterpret_cast<float* const*>(out_src)[batch] : static_cast<float*>(out_src)) : nullptr;
-    int64_t* idx = idx_src ? (TAB ? reinterpret_cast<int64_t* const*>(idx_src)[batch] : static_cast<int64_t*>(idx_src)) : nullptr;
-    unsigned row[R];
-    bool valid[R];
-    float4 x[R];
+  // one tile whose rows were requested an iteration ago: popcounts, bucket ids, stores
+  auto process = [&](unsigned t, unsigned ok, const float4 (&x)[R]) {
+    const Tile p = tile_of(t);
     float cnt[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      row[r] = tile * (4 * R) + r * 4 + grp;
-      valid[r] = static_cast<uint64_t>(idc[r]) < static_cast<uint64_t>(N);
-      x[r] = *reinterpret_cast<const float4*>(feat + (valid[r] ? idc[r] : 0) * 64 + l16 * 4);
-      cnt[r] = 0.f;
-    }
-    // the ids of the wave's next tile go out behind this tile's gathers (they are needed one tile from now)
-    const unsigned gnext = gtile + tstep;
-    int64_t idn[4] = {0, 0, 0, 0};
-    if (gnext < ntiles) load_tile_ids(ids_of(gnext), TAB ? gnext % tpb : gnext, B, l16, grp, idn);
+    for (int r = 0; r < R; ++r) cnt[r] = 0.f;
     for (int g = 0; g < G; ++g) {
       float4 pw[8];
 #pragma unroll
@@ -484,11 +517,11 @@ __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const void* __restrict_
       const float m0 = (g == G - 1) ? last0 : 1.f, m1 = (g == G - 1) ? last1 : 1.f;
 #pragma unroll
       for (int r = 0; r < R; ++r) {
-        float p[8];
+        float q[8];
 #pragma unroll
-        for (int h = 0; h < 8; ++h) p[h] = dot4_fma(x[r], pw[h], 0.f);
+        for (int h = 0; h < 8; ++h) q[h] = dot4_fma(x[r], pw[h], 0.f);
         float t0, t1;
-        rows8_sum(p, t0, t1);
+        rows8_sum(q, t0, t1);
         cnt[r] = cnt[r] + (((t0 < 0.f) ? 0.f : 1.f) * m0 + ((t1 < 0.f) ? 0.f : 1.f) * m1);
       }
     }
@@ -502,39 +535,82 @@ __global__ __launch_bounds__(kBlk, 4) void slsh64_kernel(const void* __restrict_
       c = c + dpp_f32<0x128>(c);
       pc[r] = static_cast<int>(c);  // 0..H
       const int64_t v = H + pc[r];  // <= 64
-      bkt[r] = valid[r] ? (v < n_buckets ? v : static_cast<int64_t>(static_cast<uint32_t>(v) % static_cast<uint32_t>(n_buckets)))
-                        : -1;
+      bkt[r] = ((ok >> r) & 1u) ? (v < n_buckets ? v : static_cast<int64_t>(static_cast<uint32_t>(v) % static_cast<uint32_t>(n_buckets)))
+                                : -1;
     }
-    const bool full = tile * 16 + 16 <= B;
-    if (out) {
+    if constexpr (ROWS) {
+      float* out = TAB ? reinterpret_cast<float* const*>(out_src)[p.batch] : static_cast<float*>(out_src);
 #pragma unroll
-      for (int r = 0; r < R; ++r)
+      for (int r = 0; r < R; ++r) {
+        unsigned row = p.local * (4 * R) + r * 4 + grp;
+        row = row < B ? row : B - 1u;  // (a tail row lands on the batch's last row with that row's own value)
 #pragma unroll
         for (int c = 0; c < DCH; ++c) {
-          float4 v = *reinterpret_cast<const float4*>(srows + ((pc[r] * DCH + c) * 16 + l16) * 4);
-          if (!valid[r]) v = make_float4(qnan(), qnan(), qnan(), qnan());
-          if (row[r] < B)
-            __builtin_nontemporal_store(v4f_{v.x, v.y, v.z, v.w},
-                                        reinterpret_cast<v4f_*>(out + static_cast<size_t>(row[r]) * (64 * DCH) + c * 64 + l16 * 4));
+          const float4 v = *reinterpret_cast<const float4*>(srows + ((pc[r] * DCH + c) * 16 + l16) * 4);
+          const bool good = (ok >> r) & 1u;
+          __builtin_nontemporal_store(v4f_{good ? v.x : qnan(), good ? v.y : qnan(), good ? v.z : qnan(), good ? v.w : qnan()},
+                                      (gptr_v4w)(out + static_cast<size_t>(row) * (64 * DCH) + c * 64 + l16 * 4));
         }
-    }
-    if (idx) {
-      if (full) {
-        int64_t mine = bkt[0];
-        if (l16 == 1) mine = bkt[1];
-        if (l16 == 2) mine = bkt[2];
-        if (l16 == 3) mine = bkt[3];
-        if (l16 < 4) idx[tile * 16u + l16 * 4u + grp] = mine;
-      } else {
-#pragma unroll
-        for (int r = 0; r < R; ++r)
-          if (l16 == 0 && row[r] < B) idx[row[r]] = bkt[r];
       }
     }
-    gtile = gnext;
-#pragma unroll
-    for (int r = 0; r < R; ++r) idc[r] = idn[r];
+    if constexpr (IDX) {
+      int64_t* idx = TAB ? reinterpret_cast<int64_t* const*>(idx_src)[p.batch] : static_cast<int64_t*>(idx_src);
+      // the tile's 16 bucket ids in one store: lane r of a group keeps round r's
+      int64_t mine = bkt[0];
+      if (l16 == 1) mine = bkt[1];
+      if (l16 == 2) mine = bkt[2];
+      if (l16 == 3) mine = bkt[3];
+      unsigned row = p.local * 16u + (l16 & 3) * 4u + grp;
+      row = row < B ? row : B - 1u;
+      if (l16 < 4) ((gptr_i64w)idx)[row] = mine;
+    }
+  };
+
+  float4 xa[R], xb[R];
+  unsigned oka = gather(ida, xa), okb = 0;
+  // steady state: the two tiles after b exist
+  while (tb + 2 * tstep < ntiles) {
+    const unsigned tn = tb + tstep, tm = tn + tstep;
+    int64_t idn[4];
+    load_ids(tn, idn);
+    asm volatile("" ::: "memory");
+    okb = gather(idb, xb);
+    asm volatile("" ::: "memory");
+    process(ta, oka, xa);
+    load_ids(tm, idb);
+    asm volatile("" ::: "memory");
+    oka = gather(idn, xa);
+    asm volatile("" ::: "memory");
+    process(tb, okb, xb);
+    ta = tn;
+    tb = tm;
   }
+  // drain: a (rows in flight), then b and the tile after it where they exist
+  const bool has_b = tb < ntiles, has_n = has_b && tb + tstep < ntiles;
+  int64_t idn[4] = {0, 0, 0, 0};
+  if (has_n) load_ids(tb + tstep, idn);
+  if (has_b) okb = gather(idb, xb);
+  process(ta, oka, xa);
+  if (has_b) {
+    if (has_n) oka = gather(idn, xa);
+    process(tb, okb, xb);
+    if (has_n) process(tb + tstep, oka, xa);
+  }
+}
+
+template <bool TAB>
+static void slsh64_launch(int dch, int grid, size_t lds, hipStream_t st, const void* ids, unsigned B, unsigned K, const float* feat,
+                          int64_t N, const float* planes, int H, const float* buckets, int64_t n_buckets, void* out, void* idx) {
+#define MI_SLSH_GO(DC, RW, IX) \
+  hipLaunchKernelGGL((slsh64_kernel<DC, TAB, RW, IX>), dim3(grid), dim3(kBlk), lds, st, ids, B, K, feat, N, planes, H, buckets, n_buckets, out, idx)
+  if (out && idx) {
+    if (dch == 2) MI_SLSH_GO(2, true, true); else MI_SLSH_GO(1, true, true);
+  } else if (out) {
+    if (dch == 2) MI_SLSH_GO(2, true, false); else MI_SLSH_GO(1, true, false);
+  } else {
+    MI_SLSH_GO(1, false, true);
+  }
+#undef MI_SLSH_GO
 }
 
 // Host entry used by mi_oov_slsh_embed / mi_oov_slsh_embed_multi (lsh.hip) when F = 64, H <= 32 and D is 64 or 128 (or no
@@ -544,16 +620,13 @@ int launch_slsh64(const void* ids, int64_t B, int64_t K, bool tab, const float* 
   constexpr int64_t kMaxRows = int64_t(1) << 22;  // 32-bit row arithmetic inside the kernel
   const int HP = (H + 7) / 8 * 8;
   const int dch = (out && D == 128) ? 2 : 1;
+  if (!out && !idx) return MI_OOV_OK;  // nothing asked for
   const size_t lds = (static_cast<size_t>(HP) * 64 + (out ? static_cast<size_t>(H + 1) * 64 * dch : 0)) * sizeof(float);
   if (tab) {
     if (B > kMaxRows || K * ((B + 15) / 16) >= (int64_t(1) << 31)) return MI_OOV_ERR_SHAPE;
+    // (2048 workgroups of 4 waves, ~10 tiles per wave at 20 x 65536 lookups: 512 ... 2048 measured within 5 %)
     const int grid = grid_for(K * ((B + 15) / 16) * 16, 16 * kWpb);
-    if (dch == 2)
-      hipLaunchKernelGGL((slsh64_kernel<2, true>), dim3(grid), dim3(kBlk), lds, st, ids, static_cast<unsigned>(B), static_cast<unsigned>(K),
-                         feat, N, planes, H, buckets, n_buckets, out, idx);
-    else
-      hipLaunchKernelGGL((slsh64_kernel<1, true>), dim3(grid), dim3(kBlk), lds, st, ids, static_cast<unsigned>(B), static_cast<unsigned>(K),
-                         feat, N, planes, H, buckets, n_buckets, out, idx);
+    slsh64_launch<true>(dch, grid, lds, st, ids, static_cast<unsigned>(B), static_cast<unsigned>(K), feat, N, planes, H, buckets, n_buckets, out, idx);
     return check_launch();
   }
   for (int64_t b0 = 0; b0 < B; b0 += kMaxRows) {
@@ -562,12 +635,7 @@ int launch_slsh64(const void* ids, int64_t B, int64_t K, bool tab, const float* 
     const void* ids_b = static_cast<const int64_t*>(ids) + b0;
     void* out_b = out ? static_cast<void*>(static_cast<float*>(out) + b0 * D) : nullptr;
     void* idx_b = idx ? static_cast<void*>(static_cast<int64_t*>(idx) + b0) : nullptr;
-    if (dch == 2)
-      hipLaunchKernelGGL((slsh64_kernel<2, false>), dim3(grid), dim3(kBlk), lds, st, ids_b, static_cast<unsigned>(nb), 1u, feat, N, planes, H,
-                         buckets, n_buckets, out_b, idx_b);
-    else
-      hipLaunchKernelGGL((slsh64_kernel<1, false>), dim3(grid), dim3(kBlk), lds, st, ids_b, static_cast<unsigned>(nb), 1u, feat, N, planes, H,
-                         buckets, n_buckets, out_b, idx_b);
+    slsh64_launch<false>(dch, grid, lds, st, ids_b, static_cast<unsigned>(nb), 1u, feat, N, planes, H, buckets, n_buckets, out_b, idx_b);
     if (int rc = check_launch()) return rc;
   }
   return MI_OOV_OK;

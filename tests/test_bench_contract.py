@@ -1,4 +1,4 @@
-"""CPU: the bench line's schema (driver contract) on the committed round-3 line, the PMC traffic lookup against
+"""CPU: the bench line's schema (driver contract) on the committed round-4 line, the PMC traffic lookup against
 the committed rocprof summary, and bench.py's defaults.  bench.py itself needs an MI355X and is run by the driver."""
 import importlib.util
 import json
@@ -16,7 +16,7 @@ def _bench():
     return mod
 
 
-def _line(name="r03_bench_line.json"):
+def _line(name="r04_bench_line.json"):
     return json.load(open(os.path.join(ROOT, "profiles", name)))
 
 
@@ -52,13 +52,13 @@ def test_committed_bench_line_has_the_contract_fields():
 
 def test_pmc_traffic_and_rocprof_duration_agree_with_the_line():
     bench = _bench()
-    line, under = _line(), _line("r03_bench_line_under_rocprof.json")
-    summary = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_summary.json")))
+    line, under = _line(), _line("r04_bench_line_under_rocprof.json")
+    summary = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_summary.json")))
     kernel = line["roofline"]["kernel"]
     c = line["config"]
     args = types.SimpleNamespace(items=c["items"], feat=c["feat"], dim=c["dim"], hashes=c["hashes"], batch=c["batch_per_gpu"])
     per_batch, src = bench.pmc_traffic(kernel, args)
-    assert src == "profiles/r03_bench_summary.json"
+    assert src == "profiles/r04_bench_summary.json"
     alg = line["roofline"]["bytes_per_lookup"] * c["batch_per_gpu"]
     assert 0.95 < per_batch / alg < 1.05  # FETCH x 2 + WRITE ~ algorithmic bytes: no wasted re-reads
     other = types.SimpleNamespace(items=c["items"] // 2, feat=c["feat"], dim=c["dim"], hashes=c["hashes"], batch=c["batch_per_gpu"])
