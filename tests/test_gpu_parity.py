@@ -1274,6 +1274,40 @@ def test_slsh_multi_and_lds_bucket_rows_vs_oracle(K, B, H, D, nb, oracle, ops, d
         assert np.array_equal(ops.slsh_index(i[k], f, p, nb).cpu().numpy(), o_idx)
 
 
+@pytest.mark.parametrize("H,D,nb", [(3, 64, 8), (27, 128, 100_000), (24, 64, 20_000)])
+def test_slsh_pipelined_waves_equal_one_tile_per_wave_launches(H, D, nb, oracle, ops, dev):
+    """slsh64_kernel keeps the rows of a wave's next tile and the ids of the one after in flight (round 4): launches whose
+    waves walk 4-5 tiles each (12 queued batches of 50001 lookups; one call over their concatenation) against launches
+    whose waves have a single tile (one batch per call: no pipeline), ragged last tiles and invalid ids included; batch 0
+    against the oracle."""
+    g = torch.Generator(device=dev).manual_seed(H + D)
+    N, K, B = 20_000, 12, 50_001
+    feat = torch.randn((N, 64), generator=g, device=dev)
+    planes = torch.randn((H, 64), generator=g, device=dev)
+    big = torch.randn((nb, D), generator=g, device=dev)
+    ids = [torch.randint(0, N, (B,), generator=g, device=dev) for _ in range(K)]
+    for k in range(K):
+        ids[k][k::997] = N + k
+        ids[k][B - 1 - k] = -1
+
+    def same(a, b):
+        return torch.equal(torch.nan_to_num(a, 7.0), torch.nan_to_num(b, 7.0))
+
+    single = [ops.slsh_embed(i, feat, planes, big) for i in ids]
+    single_idx = [ops.slsh_index(i, feat, planes, nb) for i in ids]
+    rows, idx = ops.slsh_embed_multi(ids, feat, planes, big, want_idx=True)
+    rows_only = ops.slsh_embed_multi(ids, feat, planes, big)
+    for k in range(K):
+        assert same(rows[k], single[k]) and same(rows_only[k], single[k]), k
+        assert torch.equal(idx[k], single_idx[k]), k
+    flat = torch.cat(ids)
+    assert same(ops.slsh_embed(flat, feat, planes, big), torch.cat(single))
+    assert torch.equal(ops.slsh_index(flat, feat, planes, nb), torch.cat(single_idx))
+    want, widx = oracle.slsh_embed(ids[0].cpu().numpy(), feat.cpu().numpy(), planes.cpu().numpy(), big.cpu().numpy())
+    assert bits_equal(single[0].cpu().numpy(), want) and np.array_equal(single_idx[0].cpu().numpy(), widx)
+    assert int((single_idx[0] == -1).sum()) >= 50
+
+
 @pytest.mark.parametrize("B,N,D,k,skip", [(300, 128 * 40 + 1, 64, 20, 1), (64, 128 * 129 + 1, 64, 5, 0), (130, 50_000, 22, 20, 1),
                                           (65, 128 * 9 + 127, 64, 2, 3)])
 @pytest.mark.parametrize("poison", [0xFF, 0x7F, 0x00])
