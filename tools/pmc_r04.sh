@@ -83,3 +83,21 @@ if [ "$what" = all ] || [ "$what" = x3 ]; then
     summarize $out "linear_x3"; } | tee gpurun_out/r04_pmc_x3.txt
   rm -rf $out
 fi
+
+# 3. the gather kernels on ONE large call (2 M lookups, tools/large_calls.py): what bounds slsh64_kernel at 24 planes, lsh64g at
+#    16 / 32 planes and the persistent kernel -- vector-ALU activity against wave cycles and waiting
+#                                                                              -> gpurun_out/r04_pmc_lsh.txt
+if [ "$what" = all ] || [ "$what" = lsh ]; then
+  out=gpurun_out/r04_pmc_lsh_raw
+  rm -rf $out && mkdir -p $out
+  i=0
+  for set in "SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" \
+             "SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY"; do
+    i=$((i+1))
+    timeout -k 10 300 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 tools/large_calls.py > "$out/pass$i.log" 2>&1 || { echo "lsh pass $i failed"; tail -3 "$out/pass$i.log"; }
+  done
+  { echo "# rocprofv3 --pmc <set> -- python3 tools/large_calls.py   (one call of 2 097 152 lookups per op, 10 M x 64 table)";
+    echo "# SQ_* are summed over the chip's 1024 SIMDs; SQ_ACTIVE_INST_VALU / SQ_BUSY_CYCLES x (1024 / 4 per CU ...) is read as a RATIO between kernels";
+    summarize $out "slsh64_kernel,lsh64g_kernel,lsh64_persistent,lsh_kernel,row_copy,gather_mean,rowdot"; } | tee gpurun_out/r04_pmc_lsh.txt
+  rm -rf $out
+fi
