@@ -53,9 +53,11 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2000)
     ap.add_argument("--batches-per-launch", type=int, default=1000,
                     help="steps queued to one persistent launch (the whole run when --steps is smaller)")
-    ap.add_argument("--ramp-seconds", type=float, default=1.0,
-                    help="untimed pre-warm-up that lets the GPU leave its idle clock (sclk idles at ~500 MHz and "
-                         "needs tens of ms of load to ramp); runs on id batches and user rows of its own")
+    ap.add_argument("--ramp-seconds", type=float, default=5.0,
+                    help="untimed pre-warm-up under load, on id batches and user rows of its own.  sclk leaves its ~500 MHz "
+                         "idle state within tens of ms, but a box that has been idle reaches its steady state only after "
+                         "~4 s of load: ten back-to-back `--steps 20` runs on a fresh box with a 1 s ramp gave 0.757, 0.766, "
+                         "then 0.777-0.784 of the HBM peak; with a 6 s ramp the FIRST run gives 0.785 (round 4)")
     ap.add_argument("--items", type=int, default=10_000_000)
     ap.add_argument("--feat", type=int, default=64)
     ap.add_argument("--dim", type=int, default=64)
@@ -314,7 +316,7 @@ def main():
                 settled = prev is not None and abs(burst - prev) <= 0.02 * burst
                 prev = burst
                 j += 1
-                done = (settled and now - t_ramp >= args.ramp_seconds) or now - t_ramp >= 5 * args.ramp_seconds
+                done = (settled and now - t_ramp >= args.ramp_seconds) or now - t_ramp >= 2 * args.ramp_seconds
                 # the ranks must leave the ramp TOGETHER: a step of the sharded path is a collective, and a rank that
                 # has settled earlier would otherwise go on to the warm-up exchange while another repeats the ramp's
                 if reduce_max(0.0 if done else 1.0) == 0.0:
