@@ -173,8 +173,52 @@ def _general_tables(model):
     raise ValueError("Unknown model type")
 
 
+_HOT_F = 64  # feature-row width of the hot kernels (csrc/lsh64.hip, lsh64p.hip): a 256-byte row per 16-lane group
+_PAD_FEATURES = os.environ.get("MI_OOV_PAD_FEATURES", "1") != "0"
+_PAD_MAX_BYTES = int(float(os.environ.get("MI_OOV_PAD_FEATURES_MAX_GIB", "32")) * (1 << 30))
+
+
 class _FeatureEmbedder(AbstractInductiveEmbedder):
     """Shared ctor fields of the feature-driven embedders."""
+
+    def hot_operands(self, side):
+        """(feature matrix, hyperplanes) of `side` ("user" / "item") as the lsh / slsh kernels are to be given them.
+
+        The hot kernels are laid out for 64-float feature rows; a narrower matrix -- the hstack of a real dataset's
+        non-id columns (lsh_embedder.py:77-106) is a few dozen floats wide -- takes the generic kernels, which run 1.5-2x
+        slower although they move fewer bytes (2 M lookups on a 10 M-row table, F = 20: 334 us against 188 us padded;
+        tools/fpad_probe.py).  So a matrix narrower than 64 columns is kept ZERO-PADDED to 64 beside the original, and
+        the hyperplanes are padded to match.  The results are the same bits: in the canonical summation order a lane
+        owns elements e with (e / 4) % 16 == lane, so the padding lives in lanes and chain positions that add +0 -- a
+        projection can at most turn from -0 to +0, which `x < 0` does not see (tests/test_gpu_plugin.py).  The public
+        attributes user_feature_mat / item_feature_mat and uniform_planes keep the reference's shapes.
+        MI_OOV_PAD_FEATURES=0 turns this off; matrices whose padded copy would exceed MI_OOV_PAD_FEATURES_MAX_GIB (32)
+        stay as they are."""
+        user = side == "user"
+        feat = self.user_feature_mat if user else self.item_feature_mat
+        planes = (self.user_lsh if user else self.item_lsh).uniform_planes[0].data
+        width = feat.size(1)
+        if (not _PAD_FEATURES or width >= _HOT_F or planes.size(0) > 32 or not self._hot_dims()
+                or feat.size(0) * _HOT_F * 4 > _PAD_MAX_BYTES or not feat.is_cuda):
+            return feat, planes
+        cache = self.__dict__.setdefault("_hot", {})
+        ent = cache.get(side)
+        if ent is None or ent[0] is not feat or ent[1] != feat._version:
+            ent = cache[side] = [feat, feat._version, F.pad(feat, (0, _HOT_F - width)).contiguous(), None, -1, None]
+        if ent[3] is not planes or ent[4] != planes._version:
+            ent[3], ent[4], ent[5] = planes, planes._version, F.pad(planes, (0, _HOT_F - width)).contiguous()
+        return ent[2], ent[5]
+
+    def _hot_dims(self):
+        return False  # which embedding widths have a hot tile: per embedder
+
+    def _operands_of(self, lsh, feature_mat):
+        """hot_operands for the reference's private `_hash_node(nodes, lsh, feature_mat)` signature."""
+        if lsh is self.user_lsh and feature_mat is self.user_feature_mat:
+            return self.hot_operands("user")
+        if lsh is self.item_lsh and feature_mat is self.item_feature_mat:
+            return self.hot_operands("item")
+        return feature_mat, lsh.uniform_planes[0].data
 
     def _common(self, n_original_users, n_original_items, n_user_oov_buckets, n_item_oov_buckets, embedding_size,
                 device, prime_pad):
@@ -216,9 +260,13 @@ class LSHInductiveEmbedder(_FeatureEmbedder):
         self.item_lsh = TorchLSHash(hash_size=n_item_oov_buckets, input_dim=self.item_feature_mat.size(1),
                                     device=device)
 
+    def _hot_dims(self):
+        return self.embedding_size == 64  # lsh64 / lsh64g / the persistent kernel: F = D = 64
+
     def _hash_node(self, nodes, lsh, feature_mat):
         assert lsh.uniform_planes is not None
-        return ops.lsh_bits(nodes, feature_mat, lsh.uniform_planes[0].data).to(torch.float32)
+        feat, planes = self._operands_of(lsh, feature_mat)
+        return ops.lsh_bits(nodes, feat, planes).to(torch.float32)
 
     def _hash_users(self, users):
         return self._hash_node(users, self.user_lsh, self.user_feature_mat)
@@ -229,14 +277,14 @@ class LSHInductiveEmbedder(_FeatureEmbedder):
     def embed_user_ids(self, user_ids, model):
         if self.training:
             _strip_prime_pad_(user_ids, self.prime_pad)
-        return ops.lsh_embed(user_ids, self.user_feature_mat, self.user_lsh.uniform_planes[0].data,
-                             model.user_oov_buckets.weight)
+        feat, planes = self.hot_operands("user")
+        return ops.lsh_embed(user_ids, feat, planes, model.user_oov_buckets.weight)
 
     def embed_item_ids(self, item_ids, model):
         if self.training:
             _strip_prime_pad_(item_ids, self.prime_pad)
-        return ops.lsh_embed(item_ids, self.item_feature_mat, self.item_lsh.uniform_planes[0].data,
-                             model.item_oov_buckets.weight)
+        feat, planes = self.hot_operands("item")
+        return ops.lsh_embed(item_ids, feat, planes, model.item_oov_buckets.weight)
 
     # ---- K queued batches in one persistent launch (csrc/lsh64p.hip; not part of the reference surface) ----------
     def lsh_table(self, side, model):
@@ -254,8 +302,7 @@ class LSHInductiveEmbedder(_FeatureEmbedder):
         if self.training:
             for ids in ids_list:
                 _strip_prime_pad_(ids, self.prime_pad)
-        feat = self.user_feature_mat if user else self.item_feature_mat
-        planes = (self.user_lsh if user else self.item_lsh).uniform_planes[0].data
+        feat, planes = self.hot_operands(side)
         buckets = (model.user_oov_buckets if user else model.item_oov_buckets).weight
         if torch.is_grad_enabled() and buckets.requires_grad:  # training: the per-batch autograd path
             return [ops.lsh_embed(ids, feat, planes, buckets) for ids in ids_list]
@@ -276,7 +323,7 @@ class LSHInductiveEmbedder(_FeatureEmbedder):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k == "_lsh_tables":
+            if k in ("_lsh_tables", "_hot"):
                 continue
             setattr(new, k, copy.deepcopy(v, memo))
         return new
@@ -285,8 +332,8 @@ class LSHInductiveEmbedder(_FeatureEmbedder):
     def score_item_ids(self, item_ids, model, user_e):
         if self.training:
             _strip_prime_pad_(item_ids, self.prime_pad)
-        return ops.lsh_embed_score(item_ids, self.item_feature_mat, self.item_lsh.uniform_planes[0].data,
-                                   model.item_oov_buckets.weight, user_e)
+        feat, planes = self.hot_operands("item")
+        return ops.lsh_embed_score(item_ids, feat, planes, model.item_oov_buckets.weight, user_e)
 
 
 class SingleLSHInductiveEmbedder(_FeatureEmbedder):
@@ -312,9 +359,13 @@ class SingleLSHInductiveEmbedder(_FeatureEmbedder):
         self.item_lsh = TorchLSHash(hash_size=self.item_bits_req, input_dim=self.item_feature_mat.size(1),
                                     device=device)
 
+    def _hot_dims(self):
+        return self.embedding_size in (64, 128)  # slsh64_kernel: F = 64, D = 64 / 128
+
     def _hash_node(self, nodes, lsh, feature_mat, n_buckets):
         assert lsh.uniform_planes is not None
-        return ops.slsh_index(nodes, feature_mat, lsh.uniform_planes[0].data, n_buckets)
+        feat, planes = self._operands_of(lsh, feature_mat)
+        return ops.slsh_index(nodes, feat, planes, n_buckets)
 
     def _hash_users(self, users):
         return self._hash_node(users, self.user_lsh, self.user_feature_mat, self.n_user_oov_buckets)
@@ -325,14 +376,14 @@ class SingleLSHInductiveEmbedder(_FeatureEmbedder):
     def embed_user_ids(self, user_ids, model):
         if self.training:
             _strip_prime_pad_(user_ids, self.prime_pad)
-        return ops.slsh_embed(user_ids, self.user_feature_mat, self.user_lsh.uniform_planes[0].data,
-                              model.user_oov_buckets.weight)
+        feat, planes = self.hot_operands("user")
+        return ops.slsh_embed(user_ids, feat, planes, model.user_oov_buckets.weight)
 
     def embed_item_ids(self, item_ids, model):
         if self.training:
             _strip_prime_pad_(item_ids, self.prime_pad)
-        return ops.slsh_embed(item_ids, self.item_feature_mat, self.item_lsh.uniform_planes[0].data,
-                              model.item_oov_buckets.weight)
+        feat, planes = self.hot_operands("item")
+        return ops.slsh_embed(item_ids, feat, planes, model.item_oov_buckets.weight)
 
 
 def _hash_mlp(in_features, hidden, out_features, device):

@@ -117,14 +117,12 @@ class BPR(InductiveGeneralRecommender):
         emb = self.inductive_embedder
         if self._fused_lsh_inference():
             # one launch: in-vocabulary rows and lsh rows spliced inside the kernel
-            feat = emb.user_feature_mat if user else emb.item_feature_mat
-            planes = (emb.user_lsh if user else emb.item_lsh).uniform_planes[0].data
+            feat, planes = emb.hot_operands(side)
             buckets = (self.user_oov_buckets if user else self.item_oov_buckets).weight
             return ops.lsh_lookup(ids, table, feat, planes, buckets)
         if isinstance(emb, LSHInductiveEmbedder) and torch.is_grad_enabled() and _SYNC_FREE_TRAIN:
             # training with the lsh plugin: one sync-free path (no boolean-mask indexing), same values and gradients
-            feat = emb.user_feature_mat if user else emb.item_feature_mat
-            planes = (emb.user_lsh if user else emb.item_lsh).uniform_planes[0].data
+            feat, planes = emb.hot_operands(side)
             buckets = (self.user_oov_buckets if user else self.item_oov_buckets).weight
             feat_ids = torch.where(ids >= emb.prime_pad, ids - emb.prime_pad, ids) if emb.training else ids
             return ops.lsh_train_lookup(ids, feat_ids, table, feat, planes, buckets)
@@ -133,8 +131,7 @@ class BPR(InductiveGeneralRecommender):
             if emb is None:  # mapper only: the mapped id itself addresses the bucket table (bpr.py:75,122)
                 idx = ids - n_vocab
             else:
-                feat = emb.user_feature_mat if user else emb.item_feature_mat
-                planes = (emb.user_lsh if user else emb.item_lsh).uniform_planes[0].data
+                feat, planes = emb.hot_operands(side)
                 feat_ids = torch.where(ids >= emb.prime_pad, ids - emb.prime_pad, ids) if emb.training else ids
                 idx = ops.slsh_index(feat_ids, feat, planes, buckets.shape[0])
             idx = torch.where(ids >= n_vocab, idx, torch.full_like(idx, -1))
@@ -195,8 +192,8 @@ class BPR(InductiveGeneralRecommender):
             emb = self.inductive_embedder
             if self.inductive_mapper is not None:
                 item = self.inductive_mapper.map_item_ids(item)
-            return ops.lsh_lookup_score(item, self.item_embedding.weight, emb.item_feature_mat,
-                                        emb.item_lsh.uniform_planes[0].data, self.item_oov_buckets.weight, user_e)
+            feat, planes = emb.hot_operands("item")
+            return ops.lsh_lookup_score(item, self.item_embedding.weight, feat, planes, self.item_oov_buckets.weight, user_e)
         user_e, item_e = self.forward(user, item)
         return ops.rowdot(user_e, item_e)
 
@@ -216,11 +213,10 @@ class BPR(InductiveGeneralRecommender):
         if self.inductive_mapper is not None:
             users = [self.inductive_mapper.map_user_ids(u) for u in users]
             items = [self.inductive_mapper.map_item_ids(t) for t in items]
-        user_rows = ops.lsh_lookup_multi(users, self.user_embedding.weight, emb.user_feature_mat,
-                                         emb.user_lsh.uniform_planes[0].data, self.user_oov_buckets.weight,
+        (ufeat, uplanes), (ifeat, iplanes) = emb.hot_operands("user"), emb.hot_operands("item")
+        user_rows = ops.lsh_lookup_multi(users, self.user_embedding.weight, ufeat, uplanes, self.user_oov_buckets.weight,
                                          lsh_table=emb.lsh_table("user", self))
-        return ops.lsh_lookup_multi(items, self.item_embedding.weight, emb.item_feature_mat,
-                                    emb.item_lsh.uniform_planes[0].data, self.item_oov_buckets.weight,
+        return ops.lsh_lookup_multi(items, self.item_embedding.weight, ifeat, iplanes, self.item_oov_buckets.weight,
                                     other_list=user_rows, lsh_table=emb.lsh_table("item", self))
 
     def ind_full_sort_predict(self, interaction, item_ids):

@@ -748,6 +748,83 @@ def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkey
             assert np.abs(out.cpu().numpy() - z[f"{mode}_{side}_out"]).max() <= 1e-5, (mode, side)
 
 
+@pytest.mark.parametrize("width", [3, 21, 40])
+def test_narrow_feature_matrices_ride_the_hot_tile_with_the_same_bits(mi, oracle, dev, monkeypatch, width):
+    """Feature matrices narrower than the hot kernels' 64 floats are kept zero-padded beside the original
+    (`_FeatureEmbedder.hot_operands`): bits, rows, bucket ids, BPR's fused lookups and the queued launches equal what the
+    unpadded operands give through the generic kernels (MI_OOV_PAD_FEATURES=0) and what the oracle gives on the
+    reference-shaped operands; widths that are not a multiple of 4, zero rows and -0 entries included; the public
+    attributes keep the reference's shapes; a re-loaded hyperplane Parameter is seen."""
+    from mi_oov import embedders, ops
+    g = torch.Generator().manual_seed(width)
+    n_u, n_i, n_vocab = 700, 900, 500
+    # (the first column of a feature table is the id field: lsh_embedder.py:83 skips it)
+    ucols = {"user_id": torch.arange(n_u), "a": torch.randn((n_u, width - 1), generator=g), "b": torch.randn((n_u,), generator=g)}
+    icols = {"item_id": torch.arange(n_i), "c": torch.randn((n_i, 1), generator=g), "d": torch.randn((n_i, width - 1), generator=g)}
+    icols["d"][5] = 0.0
+    icols["c"][5] = -0.0
+    icols["d"][7, : width // 2] = -0.0
+    uf, itf = mi.FeatureTable(ucols), mi.FeatureTable(icols)
+
+    def lsh():
+        return mi.LSHInductiveEmbedder(uf, itf, n_vocab, n_vocab, 8, 8, 64, dev, PRIME_PAD, "none", mi.InductiveFeatureCache())
+
+    def slsh(D):
+        return mi.SingleLSHInductiveEmbedder(uf, itf, n_vocab, n_vocab, 300, 300, D, dev, PRIME_PAD, "none")
+
+    class M(torch.nn.Module):
+        def __init__(self, nb, D):
+            super().__init__()
+            gg = torch.Generator().manual_seed(nb + D)
+            self.user_oov_buckets = torch.nn.Embedding.from_pretrained(torch.randn((nb, D), generator=gg).to(dev), freeze=True)
+            self.item_oov_buckets = torch.nn.Embedding.from_pretrained(torch.randn((nb, D), generator=gg).to(dev), freeze=True)
+
+    def same(a, b):
+        return torch.equal(torch.nan_to_num(a.float(), 7.0), torch.nan_to_num(b.float(), 7.0))
+
+    ids = torch.randint(0, n_i, (4, 333), generator=g).to(dev)
+    ids[0, :8] = torch.arange(8)
+    uids = torch.randint(0, n_u, (4, 333), generator=g).to(dev)
+    emb, model = lsh(), M(8, 64)
+    assert emb.item_feature_mat.shape == (n_i, width) and emb.item_lsh.uniform_planes[0].shape == (8, width)
+    feat_hot, planes_hot = emb.hot_operands("item")
+    assert feat_hot.shape == (n_i, 64) and planes_hot.shape == (8, 64) and emb.hot_operands("item")[0] is feat_hot
+    with torch.no_grad():
+        got = {"bits": emb._hash_items(ids[0]), "rows": emb.embed_item_ids(ids[0].clone(), model),
+               "urows": emb.embed_user_ids(uids[0].clone(), model),
+               "multi": torch.stack(emb.embed_item_ids_multi([i.clone() for i in ids], model)),
+               "score": emb.score_item_ids(ids[0].clone(), model, emb.embed_user_ids(uids[0].clone(), model))}
+        want_rows, want_bits = oracle.lsh_embed(ids[0].cpu().numpy(), emb.item_feature_mat.cpu().numpy(),
+                                                emb.item_lsh.uniform_planes[0].data.cpu().numpy(),
+                                                model.item_oov_buckets.weight.cpu().numpy(), want_bits=True)
+        assert bits_equal(got["rows"].cpu().numpy(), want_rows) and np.array_equal(got["bits"].cpu().numpy(), want_bits)
+        monkeypatch.setattr(embedders, "_PAD_FEATURES", False)
+        assert emb.hot_operands("item")[0] is emb.item_feature_mat
+        ref = {"bits": emb._hash_items(ids[0]), "rows": emb.embed_item_ids(ids[0].clone(), model),
+               "urows": emb.embed_user_ids(uids[0].clone(), model),
+               "multi": torch.stack(emb.embed_item_ids_multi([i.clone() for i in ids], model)),
+               "score": emb.score_item_ids(ids[0].clone(), model, emb.embed_user_ids(uids[0].clone(), model))}
+        monkeypatch.setattr(embedders, "_PAD_FEATURES", True)
+        for k in got:
+            assert same(got[k], ref[k]), k
+        # a checkpoint load writes the hyperplane Parameter in place: the padded copy follows
+        emb.load_state_dict({"user_lsh.uniform_planes.0": torch.randn((8, width), generator=g).to(dev),
+                             "item_lsh.uniform_planes.0": torch.randn((8, width), generator=g).to(dev)})
+        again = emb._hash_items(ids[0])
+        assert np.array_equal(again.cpu().numpy(), oracle.lsh_embed(ids[0].cpu().numpy(), emb.item_feature_mat.cpu().numpy(),
+                                                                     emb.item_lsh.uniform_planes[0].data.cpu().numpy(),
+                                                                     model.item_oov_buckets.weight.cpu().numpy(), want_bits=True)[1])
+        assert not torch.equal(again, got["bits"])
+        for D in (64, 128):
+            s_emb, s_model = slsh(D), M(300, D)
+            rows, idx = s_emb.embed_item_ids(ids[0].clone(), s_model), s_emb._hash_items(ids[0])
+            assert s_emb.hot_operands("item")[0].shape == (n_i, 64)
+            o_rows, o_idx = oracle.slsh_embed(ids[0].cpu().numpy(), s_emb.item_feature_mat.cpu().numpy(),
+                                              s_emb.item_lsh.uniform_planes[0].data.cpu().numpy(), s_model.item_oov_buckets.weight.cpu().numpy())
+            assert bits_equal(rows.cpu().numpy(), o_rows) and np.array_equal(idx.cpu().numpy(), o_idx)
+        assert slsh(32).hot_operands("item")[0].shape == (n_i, width)  # no hot tile for that width: operands as they are
+
+
 def test_full_size_queued_batches_equal_single_launches(mi, dev):
     """BASELINE's headline sizes (10 M-item x 64-feature table, 8 hashes, batches of 65536): every K-batch entry point of
     round 3 against the single launches it replaces -- a size-independent property (the single launches are pinned on the
