@@ -39,6 +39,7 @@ struct LshParams {
   float* out;
   uint8_t* bits;
   int64_t* idx;  // slsh only
+  int h_chunk;   // lsh_fused_kernel<..., CHUNK>: planes (and bucket rows) resident in LDS at a time
 };
 
 // Stage a [rows, L] matrix into LDS with row stride LP (zero padded).
@@ -54,7 +55,13 @@ __device__ __forceinline__ void stage_padded(float* dst, const float* src, int64
 // ------------------------------------------------------------------------------------------
 // lsh: F <= 256 (FC chunks of 64 floats in registers), D <= 256 (DC chunks)
 // ------------------------------------------------------------------------------------------
-template <int FC, int DC, bool VEC, int R>
+// CHUNK (round 4): a model with hundreds or thousands of OOV buckets has as many hyperplanes (lsh_embedder.py:108-114), and
+// H x (F + D) floats no longer fit the LDS (H = 1000 at F = D = 64: 512 KB).  The planes and bucket rows are then staged
+// h_chunk at a time: the gathered rows, the bit count and the bucket-row chain acc = fma(bit_h, W[h], acc) stay in
+// registers across the chunks, h still runs 0 .. H-1 in order, so the results are those of the unchunked kernel bit for
+// bit.  The workgroup's four waves walk their tiles in lock step (two barriers per chunk): a wave past the last tile
+// works on clamped rows and stores nothing.
+template <int FC, int DC, bool VEC, int R, bool CHUNK = false>
 __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int FP = FC * 64, DP = DC * 64;
@@ -71,16 +78,19 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
     const int64_t row = tile0 * (4 * R) + r * 4 + grp;
     idn[r] = p.ids[row < p.B ? row : p.B - 1];
   }
-  float* sP = smem;
-  float* sW = smem + p.H * FP;
-  stage_padded(sP, p.planes, p.H, p.F, FP);
-  if (p.buckets) stage_padded(sW, p.buckets, p.H, p.D, DP);
-  __syncthreads();
-
   const int H = static_cast<int>(p.H);
+  const int HC = CHUNK ? p.h_chunk : H;  // planes resident at a time
+  float* sP = smem;
+  float* sW = smem + HC * FP;
+  if constexpr (!CHUNK) {
+    stage_padded(sP, p.planes, p.H, p.F, FP);
+    if (p.buckets) stage_padded(sW, p.buckets, p.H, p.D, DP);
+    __syncthreads();
+  }
   const bool want_emb = (p.out != nullptr) || (p.score != nullptr);
 
-  for (int64_t tile = tile0; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
+  // CHUNK: the loop bound is the workgroup's (wave 0's) tile, so that all four waves meet at the barriers
+  for (int64_t tile = tile0; (CHUNK ? tile - wv : tile) < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
     int64_t row[R];
     int64_t id[R];
     bool live[R], valid[R], oov[R];
@@ -116,16 +126,25 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
       for (int c = 0; c < DC; ++c) acc[r][c] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    for (int h = 0; h < H; ++h) {
+    for (int h0 = 0; h0 < H; h0 += HC) {
+    const int hn = (H - h0 < HC) ? H - h0 : HC;
+    if constexpr (CHUNK) {
+      __syncthreads();  // every wave is done with the previous chunk (or tile)
+      stage_padded(sP, p.planes + static_cast<int64_t>(h0) * p.F, hn, p.F, FP);
+      if (p.buckets) stage_padded(sW, p.buckets + static_cast<int64_t>(h0) * p.D, hn, p.D, DP);
+      __syncthreads();
+    }
+    for (int hl = 0; hl < hn; ++hl) {
+      const int h = h0 + hl;
       float4 pw[FC];
 #pragma unroll
       for (int c = 0; c < FC; ++c)
-        pw[c] = *reinterpret_cast<const float4*>(sP + h * FP + (c * 16 + l16) * 4);
+        pw[c] = *reinterpret_cast<const float4*>(sP + hl * FP + (c * 16 + l16) * 4);
       float4 bw[DC];
       if (want_emb) {
 #pragma unroll
         for (int c = 0; c < DC; ++c)
-          bw[c] = *reinterpret_cast<const float4*>(sW + h * DP + (c * 16 + l16) * 4);
+          bw[c] = *reinterpret_cast<const float4*>(sW + hl * DP + (c * 16 + l16) * 4);
       }
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -148,6 +167,7 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
           p.bits[row[r] * p.H + h] = valid[r] ? static_cast<uint8_t>(bit) : static_cast<uint8_t>(0xFF);
       }
     }
+    }  // chunks
 
     if (want_emb) {
 #pragma unroll
@@ -409,13 +429,30 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
   }
 }
 
+// planes per LDS chunk of the chunked form: 64 (32 KB at F = D = 64: four workgroups per CU); developer knob
+static int lsh_h_chunk() {
+  static const int v = static_cast<int>(env_knob("MI_OOV_LSH_HCHUNK", 64, 8, 1024));
+  return v;
+}
+
 template <int FC, int DC, bool VEC>
-static int launch_fused(const LshParams& p, hipStream_t st) {
+static int launch_fused(const LshParams& p, hipStream_t st, bool chunked) {
   constexpr int R = (FC >= 4 || DC >= 4) ? 2 : 4;
+  const int grid = grid_for(p.B, 16 * R);
+  if (chunked) {
+    LshParams q = p;
+    int hc = lsh_h_chunk();
+    while (hc > 8 && static_cast<int64_t>(hc) * (FC * 64 + DC * 64) * 4 > 64 * 1024) hc /= 2;  // <= 64 KB per workgroup
+    q.h_chunk = hc;
+    const size_t lds = static_cast<size_t>(hc) * (FC * 64 + DC * 64) * sizeof(float);
+    auto k = lsh_fused_kernel<FC, DC, VEC, R, true>;
+    if (int rc = set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, q);
+    return check_launch();
+  }
   const size_t lds = static_cast<size_t>(p.H) * (FC * 64 + DC * 64) * sizeof(float);
   auto k = lsh_fused_kernel<FC, DC, VEC, R>;
   if (int rc = set_lds(k, lds)) return rc;
-  const int grid = grid_for(p.B, 16 * R);
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p);
   return check_launch();
 }
@@ -438,9 +475,13 @@ static int dispatch_lsh(const LshParams& p, hipStream_t st) {
   const int dcq = dc <= 1 ? 1 : (dc <= 2 ? 2 : 4);
   const int FPw = fc * 64;
   const int64_t lds = p.H * ((fcq ? fcq * 64 : FPw) + dcq * 64) * static_cast<int64_t>(sizeof(float));
-  if (lds > kLdsLimit) return MI_OOV_ERR_SHAPE;  // H x (F+D) does not fit the 160 KiB LDS
+  // All planes and bucket rows resident up to 32 KB (four workgroups per CU); more planes than that are
+  // staged a chunk at a time (F <= 256).  Wider rows with more planes than fit: no kernel.
+  static const int64_t chunk_from = env_knob("MI_OOV_LSH_CHUNK_FROM_BYTES", 32 * 1024, 0, kLdsLimit);
+  const bool chunked = fcq != 0 && lds > chunk_from;
+  if (!chunked && lds > kLdsLimit) return MI_OOV_ERR_SHAPE;  // F > 256 and H x (F+D) does not fit the 160 KiB LDS
 #define MI_FUSED(FCV, DCV) \
-  if (fcq == FCV && dcq == DCV) return launch_fused<FCV, DCV, VEC>(p, st);
+  if (fcq == FCV && dcq == DCV) return launch_fused<FCV, DCV, VEC>(p, st, chunked);
   MI_FUSED(1, 1) MI_FUSED(1, 2) MI_FUSED(1, 4)
   MI_FUSED(2, 1) MI_FUSED(2, 2) MI_FUSED(2, 4)
   MI_FUSED(4, 1) MI_FUSED(4, 2) MI_FUSED(4, 4)

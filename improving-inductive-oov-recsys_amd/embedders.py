@@ -198,7 +198,7 @@ class _FeatureEmbedder(AbstractInductiveEmbedder):
         feat = self.user_feature_mat if user else self.item_feature_mat
         planes = (self.user_lsh if user else self.item_lsh).uniform_planes[0].data
         width = feat.size(1)
-        if (not _PAD_FEATURES or width >= _HOT_F or planes.size(0) > 32 or not self._hot_dims()
+        if (not _PAD_FEATURES or width >= _HOT_F or planes.size(0) > self._hot_planes() or not self._hot_dims()
                 or feat.size(0) * _HOT_F * 4 > _PAD_MAX_BYTES or not feat.is_cuda):
             return feat, planes
         cache = self.__dict__.setdefault("_hot", {})
@@ -211,6 +211,9 @@ class _FeatureEmbedder(AbstractInductiveEmbedder):
 
     def _hot_dims(self):
         return False  # which embedding widths have a hot tile: per embedder
+
+    def _hot_planes(self):
+        return 32  # most hyperplanes the 64-wide kernels take (slsh64_kernel: 32; lsh64g_kernel: 64)
 
     def _operands_of(self, lsh, feature_mat):
         """hot_operands for the reference's private `_hash_node(nodes, lsh, feature_mat)` signature."""
@@ -262,6 +265,9 @@ class LSHInductiveEmbedder(_FeatureEmbedder):
 
     def _hot_dims(self):
         return self.embedding_size == 64  # lsh64 / lsh64g / the persistent kernel: F = D = 64
+
+    def _hot_planes(self):
+        return 64
 
     def _hash_node(self, nodes, lsh, feature_mat):
         assert lsh.uniform_planes is not None

@@ -129,6 +129,38 @@ def test_bpr_golden(golden, oracle, ops, dev):
     assert np.allclose(fs, ref, rtol=RTOL, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,N,F,H,D", [(1000, 700, 64, 100, 64), (777, 500, 64, 333, 64), (300, 200, 64, 1000, 64), (130, 99, 20, 1000, 32),
+                                       (65, 50, 130, 700, 200), (4100, 900, 64, 129, 64), (50, 40, 64, 65, 128)])
+def test_lsh_with_as_many_planes_as_oov_buckets_vs_oracle(B, N, F, H, D, oracle, ops, dev):
+    """The lsh plugin has one hyperplane per OOV bucket (lsh_embedder.py:108-114): a model with hundreds or thousands of
+    buckets has as many planes, more than the LDS holds at once.  Rows, codes, fused scores and the in-vocabulary splice
+    against the oracle with the planes staged a chunk at a time (lsh_fused_kernel<..., CHUNK>): the bucket-row chain runs
+    over all H planes in order whatever the chunking, so the bits are the oracle's."""
+    rng = np.random.default_rng(B + H)
+    feat = rng.standard_normal((N, F), dtype=np.float32)
+    feat[0] = 0
+    planes = rng.standard_normal((H, F), dtype=np.float32)
+    buckets = rng.standard_normal((H, D), dtype=np.float32)
+    other = rng.standard_normal((B, D), dtype=np.float32)
+    table = rng.standard_normal((N // 2, D), dtype=np.float32)
+    ids = rng.integers(0, N, size=B, dtype=np.int64)
+    ids[0] = 0
+    ids[3], ids[4] = N + 5, -1
+    d = lambda a: T(a, dev)  # noqa: E731
+    o_emb, o_bits = oracle.lsh_embed(ids, feat, planes, buckets, want_bits=True)
+    assert bits_equal(ops.lsh_embed(d(ids), d(feat), d(planes), d(buckets)).cpu().numpy(), o_emb)
+    assert np.array_equal(ops.lsh_bits(d(ids), d(feat), d(planes)).cpu().numpy(), o_bits)
+    emb_b, bits_b = ops._lsh_forward(d(ids), d(feat), d(planes), d(buckets), want_bits=True)
+    assert np.array_equal(bits_b.cpu().numpy(), o_bits) and bits_equal(emb_b.cpu().numpy(), o_emb)
+    o_score, _ = oracle.lsh_embed_score(ids, feat, planes, buckets, other)
+    assert bits_equal(ops.lsh_embed_score(d(ids), d(feat), d(planes), d(buckets), d(other)).cpu().numpy(), o_score)
+    o_look = oracle.lsh_lookup(ids, table, feat, planes, buckets)
+    assert bits_equal(ops.lsh_lookup(d(ids), d(table), d(feat), d(planes), d(buckets)).cpu().numpy(), o_look)
+    # queued batches of a shape the persistent kernel does not take: K single launches, same rows
+    multi = ops.lsh_embed_multi([d(ids), d(ids[::-1].copy())], d(feat), d(planes), d(buckets))
+    assert bits_equal(multi[0].cpu().numpy(), o_emb) and bits_equal(multi[1].cpu().numpy(), o_emb[::-1])
+
+
 @pytest.mark.parametrize("B,N,F,H,D", [(1, 7, 64, 8, 64), (63, 100, 64, 8, 64), (4097, 3000, 64, 8, 64), (16, 9, 64, 8, 64),
                                        (500, 400, 22, 8, 64), (333, 200, 4, 3, 1), (257, 150, 128, 16, 128),
                                        (4099, 3000, 64, 16, 64), (1000, 500, 64, 27, 64), (77, 60, 64, 32, 64),

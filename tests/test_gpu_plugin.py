@@ -748,6 +748,51 @@ def test_fdhe_embedder_class_matches_reference(mi, golden, dev, tmp_path, monkey
             assert np.abs(out.cpu().numpy() - z[f"{mode}_{side}_out"]).max() <= 1e-5, (mode, side)
 
 
+def test_bpr_with_hundreds_of_oov_buckets(mi, dev):
+    """`--item_oov_buckets 300`: the lsh plugin then has 300 hyperplanes per side (lsh_embedder.py:108-114), more than one
+    LDS load of planes + bucket rows.  BPR's fused inference, its queued form and one training step run on the chunked
+    kernel and agree with a float64 restatement of the reference's op sequence (bits from the library's own codes, which
+    tests/test_gpu_parity.py pins on the oracle)."""
+    from mi_oov import ops
+    g = torch.Generator().manual_seed(5)
+    n_users, n_items, n_new, D, nb = 400, 500, 900, 64, 300
+    cfg = Cfg(USER_ID_FIELD="user_id", ITEM_ID_FIELD="item_id", NEG_PREFIX="neg_", device=dev, embedding_size=D,
+              add_oov_buckets=True, user_oov_buckets=nb, item_oov_buckets=nb, oov_freeze_embedding=False)
+    ft_u = mi.FeatureTable({"id": torch.arange(n_new), "f": torch.randn((n_new, 12), generator=g)})
+    ft_i = mi.FeatureTable({"id": torch.arange(n_new), "f": torch.randn((n_new, 30), generator=g)})
+    emb = mi.LSHInductiveEmbedder(ft_u, ft_i, n_users, n_items, nb, nb, D, dev, PRIME_PAD, "none", mi.InductiveFeatureCache())
+    bpr = mi.BPR(cfg, DS(n_users, n_items), None, emb).to(dev)
+    users = torch.randint(0, n_new, (700,), generator=g).to(dev)
+    items = torch.randint(0, n_new, (700,), generator=g).to(dev)
+    negs = torch.randint(0, n_new, (700,), generator=g).to(dev)
+
+    def rows64(ids, side):
+        table = (bpr.user_embedding if side == "user" else bpr.item_embedding).weight.double()
+        feat, planes = emb.hot_operands(side)
+        W = (bpr.user_oov_buckets if side == "user" else bpr.item_oov_buckets).weight.double()
+        bits = ops.lsh_bits(ids, feat, planes).double()
+        oov = (bits @ W) / bits.sum(1, keepdim=True)
+        n_vocab = n_users if side == "user" else n_items
+        return torch.where((ids < n_vocab)[:, None], table[ids.clamp(max=n_vocab - 1)], oov)
+
+    bpr.eval()
+    emb.set_eval()
+    with torch.no_grad():
+        want = (rows64(users, "user") * rows64(items, "item")).sum(1)
+        got = bpr.predict({"user_id": users, "item_id": items})
+        ok = ~torch.isnan(want)
+        assert torch.equal(torch.isnan(got), ~ok) and int(ok.sum()) > 600
+        assert float((got[ok].double() - want[ok]).abs().max()) <= 1e-5 * float(want[ok].abs().max())
+        halves = bpr.predict_multi([{"user_id": users[:350], "item_id": items[:350]}, {"user_id": users[350:], "item_id": items[350:]}])
+        assert torch.equal(torch.nan_to_num(torch.cat(halves), 7.0), torch.nan_to_num(got, 7.0))
+    bpr.train()
+    emb.set_train()
+    loss = bpr.calculate_loss({"user_id": users.clone(), "item_id": items.clone(), "neg_item_id": negs.clone()})
+    loss.backward()
+    gW = bpr.item_oov_buckets.weight.grad
+    assert gW is not None and gW.shape == (nb, D) and bool(torch.isfinite(gW).all()) and float(gW.abs().sum()) > 0
+
+
 @pytest.mark.parametrize("width", [3, 21, 40])
 def test_narrow_feature_matrices_ride_the_hot_tile_with_the_same_bits(mi, oracle, dev, monkeypatch, width):
     """Feature matrices narrower than the hot kernels' 64 floats are kept zero-padded beside the original
