@@ -40,16 +40,21 @@ struct LshParams {
   uint8_t* bits;
   int64_t* idx;  // slsh only
   int h_chunk;   // lsh_fused_kernel<..., CHUNK>: planes (and bucket rows) resident in LDS at a time
+  int64_t d0, Dw;  // lsh: the window of output columns [d0, d0 + Dw) this launch writes (rows wider than 256 floats take
+                   // one launch per 256 columns; D stays the row stride of buckets / table / out)
 };
 
-// Stage a [rows, L] matrix into LDS with row stride LP (zero padded).
-__device__ __forceinline__ void stage_padded(float* dst, const float* src, int64_t rows, int64_t L, int LP) {
+// Stage a [rows, L] matrix (row stride ld in memory) into LDS with row stride LP (zero padded).
+__device__ __forceinline__ void stage_padded(float* dst, const float* src, int64_t rows, int64_t L, int LP, int64_t ld) {
   const int64_t total = rows * LP;
   for (int64_t i = threadIdx.x; i < total; i += kBlock) {
     const int64_t r = i / LP;
     const int e = static_cast<int>(i - r * LP);
-    dst[i] = (e < L) ? src[r * L + e] : 0.f;
+    dst[i] = (e < L) ? src[r * ld + e] : 0.f;
   }
+}
+__device__ __forceinline__ void stage_padded(float* dst, const float* src, int64_t rows, int64_t L, int LP) {
+  stage_padded(dst, src, rows, L, LP, L);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
   float* sW = smem + HC * FP;
   if constexpr (!CHUNK) {
     stage_padded(sP, p.planes, p.H, p.F, FP);
-    if (p.buckets) stage_padded(sW, p.buckets, p.H, p.D, DP);
+    if (p.buckets) stage_padded(sW, p.buckets + p.d0, p.H, p.Dw, DP, p.D);
     __syncthreads();
   }
   const bool want_emb = (p.out != nullptr) || (p.score != nullptr);
@@ -131,7 +136,7 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
     if constexpr (CHUNK) {
       __syncthreads();  // every wave is done with the previous chunk (or tile)
       stage_padded(sP, p.planes + static_cast<int64_t>(h0) * p.F, hn, p.F, FP);
-      if (p.buckets) stage_padded(sW, p.buckets + static_cast<int64_t>(h0) * p.D, hn, p.D, DP);
+      if (p.buckets) stage_padded(sW, p.buckets + static_cast<int64_t>(h0) * p.D + p.d0, hn, p.Dw, DP, p.D);
       __syncthreads();
     }
     for (int hl = 0; hl < hn; ++hl) {
@@ -182,10 +187,10 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
             emb[c].z = acc[r][c].z / cnt[r];
             emb[c].w = acc[r][c].w / cnt[r];
           } else {
-            emb[c] = valid[r] ? load4<VEC>(p.table + id[r] * p.D, e, p.D) : make_float4(0.f, 0.f, 0.f, 0.f);
+            emb[c] = valid[r] ? load4<VEC>(p.table + id[r] * p.D + p.d0, e, p.Dw) : make_float4(0.f, 0.f, 0.f, 0.f);
           }
           if (!valid[r]) emb[c] = make_float4(qnan(), qnan(), qnan(), qnan());
-          if (p.out && live[r]) store4<VEC>(p.out + row[r] * p.D, e, p.D, emb[c]);
+          if (p.out && live[r]) store4<VEC>(p.out + row[r] * p.D + p.d0, e, p.Dw, emb[c]);
         }
         if (p.score) {
           float sp = 0.f;
@@ -214,27 +219,33 @@ __global__ __launch_bounds__(kBlock) void lsh_fused_kernel(LshParams p) {
 // lsh, wide feature rows (F > 256): chunks streamed per block of 8 planes, the row is re-read
 // from L1/L2 for every plane block.  Same canonical order (lane chain over increasing chunk).
 // ------------------------------------------------------------------------------------------
-template <int DC, bool VEC>
+// CHUNK: as lsh_fused_kernel<..., CHUNK> -- h_chunk (a multiple of 8) planes and bucket rows in LDS at a time, the four
+// waves in lock step (item features from a text or image encoder are hundreds of floats wide, and the model may have a
+// thousand OOV buckets: 768 x 1000 planes are 3 MB).
+template <int DC, bool VEC, bool CHUNK = false>
 __global__ __launch_bounds__(kBlock) void lsh_wide_kernel(LshParams p, int FP) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int DP = DC * 64;
   constexpr int HB = 8;
+  const int H = static_cast<int>(p.H);
+  const int HC = CHUNK ? p.h_chunk : H;
   float* sP = smem;
-  float* sW = smem + p.H * FP;
-  stage_padded(sP, p.planes, p.H, p.F, FP);
-  if (p.buckets) stage_padded(sW, p.buckets, p.H, p.D, DP);
-  __syncthreads();
+  float* sW = smem + HC * FP;
+  if constexpr (!CHUNK) {
+    stage_padded(sP, p.planes, p.H, p.F, FP);
+    if (p.buckets) stage_padded(sW, p.buckets + p.d0, p.H, p.Dw, DP, p.D);
+    __syncthreads();
+  }
 
   const int lane = threadIdx.x & 63;
   const int l16 = lane & 15;
   const int grp = lane >> 4;
   const int wv = threadIdx.x >> 6;
   const int64_t ntiles = (p.B + 3) / 4;
-  const int H = static_cast<int>(p.H);
   const int nchunk = FP / 64;
   const bool want_emb = (p.out != nullptr) || (p.score != nullptr);
 
-  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; tile < ntiles;
+  for (int64_t tile = static_cast<int64_t>(blockIdx.x) * 4 + wv; (CHUNK ? tile - wv : tile) < ntiles;
        tile += static_cast<int64_t>(gridDim.x) * 4) {
     const int64_t row = tile * 4 + grp;
     const bool live = row < p.B;
@@ -250,6 +261,16 @@ __global__ __launch_bounds__(kBlock) void lsh_wide_kernel(LshParams p, int FP) {
     for (int c = 0; c < DC; ++c) acc[c] = make_float4(0.f, 0.f, 0.f, 0.f);
 
     for (int h0 = 0; h0 < H; h0 += HB) {
+      if constexpr (CHUNK) {
+        if (h0 % HC == 0) {  // (uniform) the next h_chunk planes and bucket rows
+          const int hn = (H - h0 < HC) ? H - h0 : HC;
+          __syncthreads();
+          stage_padded(sP, p.planes + static_cast<int64_t>(h0) * p.F, hn, p.F, FP);
+          if (p.buckets) stage_padded(sW, p.buckets + static_cast<int64_t>(h0) * p.D + p.d0, hn, p.Dw, DP, p.D);
+          __syncthreads();
+        }
+      }
+      const int hb = CHUNK ? h0 % HC : h0;  // LDS row of plane h0
       float part[HB];
 #pragma unroll
       for (int j = 0; j < HB; ++j) part[j] = 0.f;
@@ -259,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void lsh_wide_kernel(LshParams p, int FP) {
 #pragma unroll
         for (int j = 0; j < HB; ++j) {
           if (h0 + j < H) {
-            const float4 pw = *reinterpret_cast<const float4*>(sP + (h0 + j) * FP + e);
+            const float4 pw = *reinterpret_cast<const float4*>(sP + (hb + j) * FP + e);
             part[j] = dot4_fma(xv, pw, part[j]);
           }
         }
@@ -274,7 +295,7 @@ __global__ __launch_bounds__(kBlock) void lsh_wide_kernel(LshParams p, int FP) {
           if (want_emb) {
 #pragma unroll
             for (int c = 0; c < DC; ++c) {
-              const float4 bw = *reinterpret_cast<const float4*>(sW + h * DP + (c * 16 + l16) * 4);
+              const float4 bw = *reinterpret_cast<const float4*>(sW + (hb + j) * DP + (c * 16 + l16) * 4);
               acc[c].x = __builtin_fmaf(bit, bw.x, acc[c].x);
               acc[c].y = __builtin_fmaf(bit, bw.y, acc[c].y);
               acc[c].z = __builtin_fmaf(bit, bw.z, acc[c].z);
@@ -300,10 +321,10 @@ __global__ __launch_bounds__(kBlock) void lsh_wide_kernel(LshParams p, int FP) {
           emb[c].z = acc[c].z / cnt;
           emb[c].w = acc[c].w / cnt;
         } else {
-          emb[c] = valid ? load4<VEC>(p.table + id * p.D, e, p.D) : make_float4(0.f, 0.f, 0.f, 0.f);
+          emb[c] = valid ? load4<VEC>(p.table + id * p.D + p.d0, e, p.Dw) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         if (!valid) emb[c] = make_float4(qnan(), qnan(), qnan(), qnan());
-        if (p.out && live) store4<VEC>(p.out + row * p.D, e, p.D, emb[c]);
+        if (p.out && live) store4<VEC>(p.out + row * p.D + p.d0, e, p.Dw, emb[c]);
         if (p.score) {
           float4 o = live ? load4<VEC>(orow, e, p.D) : make_float4(0.f, 0.f, 0.f, 0.f);
           float4 m = emb[c];
@@ -327,7 +348,7 @@ __global__ __launch_bounds__(kBlock) void lsh_wide_kernel(LshParams p, int FP) {
 // Planes in LDS; bucket rows come from HBM (n_buckets may be as large as the catalogue).
 // Chunks of the feature row are streamed (any F).
 // ------------------------------------------------------------------------------------------
-template <bool VEC>
+template <bool VEC, bool CHUNK = false>
 __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int HB = 8;
@@ -347,14 +368,16 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
     idn[r] = p.ids[row < p.B ? row : p.B - 1];
   }
   float* sP = smem;
-  stage_padded(sP, p.planes, p.H, p.F, FP);
-  __syncthreads();
-
   const int H = static_cast<int>(p.H);
+  const int HC = CHUNK ? p.h_chunk : H;  // CHUNK: h_chunk (a multiple of 8) planes in LDS at a time, waves in lock step
+  if constexpr (!CHUNK) {
+    stage_padded(sP, p.planes, p.H, p.F, FP);
+    __syncthreads();
+  }
   const int nchunk = FP / 64;
   const int dchunks = static_cast<int>((p.D + 63) / 64);
 
-  for (int64_t tile = tile0; tile < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
+  for (int64_t tile = tile0; (CHUNK ? tile - wv : tile) < ntiles; tile += static_cast<int64_t>(gridDim.x) * 4) {
     int64_t row[R], id[R];
     bool live[R], valid[R];
     int pop[R];
@@ -368,6 +391,14 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
       pop[r] = 0;
     }
     for (int h0 = 0; h0 < H; h0 += HB) {
+      if constexpr (CHUNK) {
+        if (h0 % HC == 0) {  // (uniform)
+          __syncthreads();
+          stage_padded(sP, p.planes + static_cast<int64_t>(h0) * p.F, (H - h0 < HC) ? H - h0 : HC, p.F, FP);
+          __syncthreads();
+        }
+      }
+      const int hb = CHUNK ? h0 % HC : h0;  // LDS row of plane h0
       float part[R][HB];
 #pragma unroll
       for (int r = 0; r < R; ++r)
@@ -382,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void slsh_kernel(LshParams p, int FP) {
 #pragma unroll
         for (int j = 0; j < HB; ++j) {
           if (h0 + j < H) {
-            const float4 pw = *reinterpret_cast<const float4*>(sP + (h0 + j) * FP + e);
+            const float4 pw = *reinterpret_cast<const float4*>(sP + (hb + j) * FP + e);
 #pragma unroll
             for (int r = 0; r < R; ++r) part[r][j] = dot4_fma(xv[r], pw, part[r][j]);
           }
@@ -457,20 +488,36 @@ static int launch_fused(const LshParams& p, hipStream_t st, bool chunked) {
   return check_launch();
 }
 
+// planes per chunk of the wide / slsh chunked forms: the largest multiple of 8 that keeps the chunk within `budget` bytes
+static int planes_per_chunk(int64_t floats_per_plane, int64_t budget) {
+  int64_t hc = budget / (floats_per_plane * 4) / 8 * 8;
+  return static_cast<int>(hc < 8 ? 8 : hc);
+}
+
 template <int DC, bool VEC>
-static int launch_wide(const LshParams& p, int FP, hipStream_t st) {
+static int launch_wide(const LshParams& p, int FP, hipStream_t st, bool chunked) {
+  const int grid = grid_for(p.B, 16);
+  if (chunked) {
+    LshParams q = p;
+    q.h_chunk = planes_per_chunk(FP + DC * 64, 48 * 1024);
+    const size_t lds = static_cast<size_t>(q.h_chunk) * (FP + DC * 64) * sizeof(float);
+    if (static_cast<int64_t>(lds) > kLdsLimit) return MI_OOV_ERR_SHAPE;  // eight planes do not fit: F beyond ~5000 floats
+    auto k = lsh_wide_kernel<DC, VEC, true>;
+    if (int rc = set_lds(k, lds)) return rc;
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, q, FP);
+    return check_launch();
+  }
   const size_t lds = static_cast<size_t>(p.H) * (FP + DC * 64) * sizeof(float);
   auto k = lsh_wide_kernel<DC, VEC>;
   if (int rc = set_lds(k, lds)) return rc;
-  const int grid = grid_for(p.B, 16);
   hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p, FP);
   return check_launch();
 }
 
 template <bool VEC>
-static int dispatch_lsh(const LshParams& p, hipStream_t st) {
+static int dispatch_lsh_window(const LshParams& p, hipStream_t st) {
   const int fc = static_cast<int>((p.F + 63) / 64);
-  const int dc = static_cast<int>((p.D + 63) / 64);
+  const int dc = static_cast<int>((p.Dw + 63) / 64);
   const int fcq = fc <= 1 ? 1 : (fc <= 2 ? 2 : (fc <= 4 ? 4 : 0));
   const int dcq = dc <= 1 ? 1 : (dc <= 2 ? 2 : 4);
   const int FPw = fc * 64;
@@ -478,17 +525,38 @@ static int dispatch_lsh(const LshParams& p, hipStream_t st) {
   // All planes and bucket rows resident up to 32 KB (four workgroups per CU); more planes than that are
   // staged a chunk at a time (F <= 256).  Wider rows with more planes than fit: no kernel.
   static const int64_t chunk_from = env_knob("MI_OOV_LSH_CHUNK_FROM_BYTES", 32 * 1024, 0, kLdsLimit);
-  const bool chunked = fcq != 0 && lds > chunk_from;
-  if (!chunked && lds > kLdsLimit) return MI_OOV_ERR_SHAPE;  // F > 256 and H x (F+D) does not fit the 160 KiB LDS
+  const bool chunked = fcq != 0 ? lds > chunk_from : lds > kLdsLimit;  // (wide rows: chunked only when they must be)
 #define MI_FUSED(FCV, DCV) \
   if (fcq == FCV && dcq == DCV) return launch_fused<FCV, DCV, VEC>(p, st, chunked);
   MI_FUSED(1, 1) MI_FUSED(1, 2) MI_FUSED(1, 4)
   MI_FUSED(2, 1) MI_FUSED(2, 2) MI_FUSED(2, 4)
   MI_FUSED(4, 1) MI_FUSED(4, 2) MI_FUSED(4, 4)
 #undef MI_FUSED
-  if (dcq == 1) return launch_wide<1, VEC>(p, FPw, st);
-  if (dcq == 2) return launch_wide<2, VEC>(p, FPw, st);
-  return launch_wide<4, VEC>(p, FPw, st);
+  if (dcq == 1) return launch_wide<1, VEC>(p, FPw, st, chunked);
+  if (dcq == 2) return launch_wide<2, VEC>(p, FPw, st, chunked);
+  return launch_wide<4, VEC>(p, FPw, st, chunked);
+}
+
+// Embedding rows wider than the 256 floats a lane group keeps in registers (embedding_size 300, 512, ...): one launch per
+// window of 256 output columns -- the projections are recomputed per window, the bucket-row chain of a column does not
+// depend on the other columns, so every window holds the bits a single launch would.  The fused score needs the whole
+// row in one launch: refused here (MI_OOV_ERR_SHAPE), the host composes rows + mi_oov_rowdot.
+template <bool VEC>
+static int dispatch_lsh(LshParams p, hipStream_t st) {
+  if (p.D <= 256) {
+    p.d0 = 0;
+    p.Dw = p.D;
+    return dispatch_lsh_window<VEC>(p, st);
+  }
+  if (p.score) return MI_OOV_ERR_SHAPE;
+  for (int64_t d0 = 0; d0 < p.D; d0 += 256) {
+    LshParams q = p;
+    q.d0 = d0;
+    q.Dw = (p.D - d0 < 256) ? p.D - d0 : 256;
+    if (d0) q.bits = nullptr;  // the codes leave with the first window
+    if (int rc = dispatch_lsh_window<VEC>(q, st)) return rc;
+  }
+  return MI_OOV_OK;
 }
 
 // lsh64.hip: lane-owns-lookup kernel for the hot shape F = D = 64
@@ -513,7 +581,6 @@ static int run_lsh(LshParams p, void* stream) {
   if (!want_emb && !p.bits) return MI_OOV_ERR_NULL;
   if (p.score && !p.other) return MI_OOV_ERR_NULL;
   if (p.table && p.n_vocab < 0) return MI_OOV_ERR_SHAPE;
-  if (p.D > 256) return MI_OOV_ERR_SHAPE;
   if (p.D <= 0) p.D = 1;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = (p.F % 4 == 0) && (!want_emb || p.D % 4 == 0) && aligned16(p.feat) && (!p.out || aligned16(p.out)) &&
@@ -578,31 +645,40 @@ extern "C" int mi_oov_slsh_embed(const int64_t* ids, int64_t B, const float* fea
                                  const float* planes, int64_t H, const float* buckets, int64_t n_buckets,
                                  int64_t D, float* out, int64_t* idx, void* stream) {
   using namespace mi_oov;
-  if (B < 0 || N <= 0 || F <= 0 || H <= 0 || n_buckets <= 0) return MI_OOV_ERR_SHAPE;
+  // H == 0: n_buckets == 1 gives bits_req = ceil(log2(1)) = 0 planes (single_lsh_embedder.py:77-80); every lookup then
+  // lands in bucket (0 + 0) % n_buckets = 0.  `planes` may be NULL then (an empty tensor has no storage).
+  if (B < 0 || N <= 0 || F <= 0 || H < 0 || n_buckets <= 0) return MI_OOV_ERR_SHAPE;
   if (B == 0) return MI_OOV_OK;
-  if (!ids || !feat || !planes) return MI_OOV_ERR_NULL;
+  if (!ids || !feat || (!planes && H > 0)) return MI_OOV_ERR_NULL;
   if (!out && !idx) return MI_OOV_ERR_NULL;
   if (out && (!buckets || D <= 0)) return MI_OOV_ERR_NULL;
   LshParams p{};
   p.ids = ids; p.B = B; p.feat = feat; p.N = N; p.F = F; p.planes = planes; p.H = H;
   p.buckets = buckets; p.n_buckets = n_buckets; p.D = D > 0 ? D : 1; p.out = out; p.idx = idx;
   const int FP = static_cast<int>((F + 63) / 64) * 64;
-  const size_t lds = static_cast<size_t>(H) * FP * sizeof(float);
-  if (static_cast<int64_t>(lds) > kLdsLimit) return MI_OOV_ERR_SHAPE;
+  size_t lds = static_cast<size_t>(H) * FP * sizeof(float);
+  const bool chunked = static_cast<int64_t>(lds) > kLdsLimit;  // wide rows x many planes: the planes a chunk at a time
+  if (chunked) {
+    p.h_chunk = planes_per_chunk(FP, 48 * 1024);
+    lds = static_cast<size_t>(p.h_chunk) * FP * sizeof(float);
+    if (static_cast<int64_t>(lds) > kLdsLimit) return MI_OOV_ERR_SHAPE;  // eight planes do not fit: F beyond ~5000 floats
+  }
   hipStream_t st = static_cast<hipStream_t>(stream);
   const bool vec = (F % 4 == 0) && aligned16(feat) && (!out || (p.D % 4 == 0 && aligned16(out) && aligned16(buckets)));
-  if (vec && F == 64 && H <= 32 && (!out || D == 64 || D == 128) && aligned16(planes) && lsh64_enabled())
+  if (vec && F == 64 && H >= 1 && H <= 32 && (!out || D == 64 || D == 128) && aligned16(planes) && lsh64_enabled())
     return launch_slsh64(ids, B, 1, false, feat, N, planes, static_cast<int>(H), buckets, n_buckets, D, out, idx, st);
   const int grid = grid_for(B, 64);
-  if (vec) {
-    auto k = slsh_kernel<true>;
-    if (int rc = set_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p, FP);
-  } else {
-    auto k = slsh_kernel<false>;
-    if (int rc = set_lds(k, lds)) return rc;
-    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p, FP);
-  }
+#define MI_SLSH_GO(V, C) \
+  do { \
+    auto k = slsh_kernel<V, C>; \
+    if (int rc = set_lds(k, lds)) return rc; \
+    hipLaunchKernelGGL(k, dim3(grid), dim3(kBlock), lds, st, p, FP); \
+  } while (0)
+  if (vec && chunked) MI_SLSH_GO(true, true);
+  else if (vec) MI_SLSH_GO(true, false);
+  else if (chunked) MI_SLSH_GO(false, true);
+  else MI_SLSH_GO(false, false);
+#undef MI_SLSH_GO
   return check_launch();
 }
 

@@ -148,6 +148,12 @@ def lsh_embed_score(ids, feat, planes, buckets, other, want_emb=False, score_out
         score = C.dev_tensor(score_out, torch.float32, "score_out")
         if score.shape != (B,) or score.data_ptr() != score_out.data_ptr():
             raise ValueError(f"score_out must be a contiguous f32[{B}] tensor on the device")
+    if D > 256:
+        # rows wider than the 256 floats one launch keeps per lookup: the library writes them a window of columns at a
+        # time (csrc/lsh.hip, dispatch_lsh) and the row dot is a launch of its own -- the same values in the same order
+        out = lsh_embed(ids, feat, planes, buckets)
+        score.copy_(_rowdot_forward(other, out))
+        return (score, out) if want_emb else score
     out = torch.empty((B, D), dtype=torch.float32, device=ids.device) if want_emb else None
     with C.on_device(ids):
         rc = C.lib().mi_oov_lsh_embed_score(C.ptr(ids), B, C.ptr(feat), N, F, C.ptr(planes), H, C.ptr(buckets), D,
@@ -304,8 +310,8 @@ class LshBatchQueue:
             if i.numel() != B or (o is not None and o.shape != (B, D)) or s.shape != ((B, D) if rows else (B,)):
                 raise ValueError(f"batch {k}: need int64[{B}] ids" + ("" if rows else f", f32[{B},{D}] rows") +
                                  (f", f32[{B},{D}] output rows" if rows else f", f32[{B}] scores"))
-            if (o is not None and o.data_ptr() % 16) or (rows and s.data_ptr() % 16):
-                raise ValueError(f"rows of batch {k} are not 16-byte aligned")
+            if D % 4 == 0 and ((o is not None and o.data_ptr() % 16) or (rows and s.data_ptr() % 16)):
+                raise ValueError(f"rows of batch {k} are not 16-byte aligned")  # (D % 4 != 0: the scalar kernels, any address)
         self.ids, self.other, self.scores = list(ids_list), (None if rows else list(other_list)), list(score_list)
         self.K, self.B, self.D, self.device, self.rows = K, B, D, dev, bool(rows)
         self.tab = _ptr_table(self.ids, self.other, self.scores)  # [3, K] device pointers
@@ -531,7 +537,7 @@ def slsh_embed_multi(ids_list, feat, planes, buckets, want_idx=False, out=None):
     feat, planes, buckets = _f32(feat, "feat"), _f32(planes, "planes"), _f32(buckets, "buckets")
     ids = _batch_list(ids_list, torch.int64, "ids")
     K, B, (N, F), H, (nb, D) = len(ids), ids[0].numel(), feat.shape, planes.shape[0], buckets.shape
-    hot = F == 64 and H <= 32 and D in (64, 128) and not (feat.data_ptr() % 16 or planes.data_ptr() % 16 or buckets.data_ptr() % 16)
+    hot = F == 64 and 1 <= H <= 32 and D in (64, 128) and not (feat.data_ptr() % 16 or planes.data_ptr() % 16 or buckets.data_ptr() % 16)
     if not hot or B > (1 << 22):
         res = [_slsh_forward(i, feat, planes, buckets, nb) for i in ids]
         return ([r[0] for r in res], [r[1] for r in res]) if want_idx else [r[0] for r in res]
@@ -705,6 +711,10 @@ def lsh_lookup_score(ids, table, feat, planes, buckets, other, want_emb=False):
     B, (N, F), H, D = ids.numel(), feat.shape, planes.shape[0], buckets.shape[1]
     if other.shape != (B, D):
         raise ValueError(f"other must be [{B},{D}], got {tuple(other.shape)}")
+    if D > 256:  # as lsh_embed_score: rows by windows of columns, then the row dot
+        out = lsh_lookup(ids, table, feat, planes, buckets)
+        score = _rowdot_forward(other, out)
+        return (score, out) if want_emb else score
     score = torch.empty((B,), dtype=torch.float32, device=ids.device)
     out = torch.empty((B, D), dtype=torch.float32, device=ids.device) if want_emb else None
     with C.on_device(ids):

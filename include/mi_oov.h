@@ -69,6 +69,12 @@ int mi_oov_last_hip_error(void);
  *   ids    i64[B]        feat    f32[N,F]      planes  f32[H,F]    buckets f32[H,D]
  *   out    f32[B,D] or NULL (hash only; buckets may then be NULL)
  *   bits   u8[B,H] or NULL  (0/1; 0xFF for invalid ids)
+ * Shapes: any F, H >= 1 and D the reference takes.  F = D = 64 with H <= 64 are the hot tiles (a feature matrix
+ * narrower than 64 columns can be given zero-padded to 64 with planes padded to match: same bits).
+ * H is the model's number of OOV buckets (lsh_embedder.py:108-114) and may be in the thousands: planes and bucket rows
+ * that do not fit the LDS are staged a chunk at a time.  D > 256: the rows are written one window of 256 columns per
+ * launch; the FUSED score entries return MI_OOV_ERR_SHAPE there (compose mi_oov_lsh_embed / _lookup + mi_oov_rowdot, as
+ * the Python mirror does).  Refused: F > ~5000 together with more planes than fit the LDS.
  * ------------------------------------------------------------------------------------------ */
 int mi_oov_lsh_embed(const int64_t* ids, int64_t B,
                      const float* feat, int64_t N, int64_t F,
@@ -244,6 +250,7 @@ int mi_oov_lsh_lookup_score(const int64_t* ids, int64_t B,
  *     bits as above with H = bits_req planes;  idx = (sum_h 2**bits[h]) % n_buckets
  *     = (H + popcount(bits)) % n_buckets  (reference quirk, :86);  out = buckets[idx]
  *   buckets f32[n_buckets,D];  idx i64[B] or NULL;  out f32[B,D] or NULL
+ *   H = 0 (n_buckets = 1: bits_req = ceil(log2(1)) = 0; planes may be NULL) puts every lookup in bucket 0.
  * ------------------------------------------------------------------------------------------ */
 int mi_oov_slsh_embed(const int64_t* ids, int64_t B,
                       const float* feat, int64_t N, int64_t F,

@@ -129,8 +129,32 @@ def test_bpr_golden(golden, oracle, ops, dev):
     assert np.allclose(fs, ref, rtol=RTOL, atol=1e-6)
 
 
+@pytest.mark.parametrize("B,N,F,H,D,nb", [(100, 50, 3000, 30, 16, 1000), (257, 99, 3000, 27, 64, 5), (64, 50, 5, 0, 7, 1), (100, 50, 64, 0, 64, 1),
+                                          (80, 50, 1100, 40, 300, 77)])
+def test_slsh_wide_rows_many_planes_and_no_planes_vs_oracle(B, N, F, H, D, nb, oracle, ops, dev):
+    """slsh keeps only its planes in LDS: feature rows of thousands of floats times ~30 planes (bits_req of a very large
+    bucket table) are staged a chunk of planes at a time (slsh_kernel<..., CHUNK>); n_buckets = 1 means bits_req = 0 planes
+    (single_lsh_embedder.py:77-80) and every lookup in bucket 0."""
+    rng = np.random.default_rng(B + F)
+    feat = rng.standard_normal((N, F), dtype=np.float32)
+    planes = rng.standard_normal((H, F), dtype=np.float32)
+    big = rng.standard_normal((nb, D), dtype=np.float32)
+    ids = rng.integers(0, N, size=B, dtype=np.int64)
+    ids[3], ids[4] = N + 5, -1
+    want, widx = oracle.slsh_embed(ids, feat, planes, big)
+    got = ops.slsh_embed(T(ids, dev), T(feat, dev), T(planes, dev), T(big, dev)).cpu().numpy()
+    assert bits_equal(got, want)
+    assert np.array_equal(ops.slsh_index(T(ids, dev), T(feat, dev), T(planes, dev), nb).cpu().numpy(), widx)
+    if H == 0:
+        assert set(widx.tolist()) == {0, -1}
+
+
 @pytest.mark.parametrize("B,N,F,H,D", [(1000, 700, 64, 100, 64), (777, 500, 64, 333, 64), (300, 200, 64, 1000, 64), (130, 99, 20, 1000, 32),
-                                       (65, 50, 130, 700, 200), (4100, 900, 64, 129, 64), (50, 40, 64, 65, 128)])
+                                       (65, 50, 130, 700, 200), (4100, 900, 64, 129, 64), (50, 40, 64, 65, 128),
+                                       # feature rows from an encoder (hundreds of floats) x many buckets: lsh_wide_kernel<..., CHUNK>
+                                       (90, 50, 768, 1000, 64), (65, 50, 770, 300, 300), (70, 40, 2000, 30, 16),
+                                       # embedding rows wider than 256 floats: one launch per window of 256 columns
+                                       (100, 50, 64, 8, 300), (64, 50, 64, 8, 512), (70, 40, 22, 40, 1030), (33, 20, 64, 8, 257)])
 def test_lsh_with_as_many_planes_as_oov_buckets_vs_oracle(B, N, F, H, D, oracle, ops, dev):
     """The lsh plugin has one hyperplane per OOV bucket (lsh_embedder.py:108-114): a model with hundreds or thousands of
     buckets has as many planes, more than the LDS holds at once.  Rows, codes, fused scores and the in-vocabulary splice
@@ -156,6 +180,8 @@ def test_lsh_with_as_many_planes_as_oov_buckets_vs_oracle(B, N, F, H, D, oracle,
     assert bits_equal(ops.lsh_embed_score(d(ids), d(feat), d(planes), d(buckets), d(other)).cpu().numpy(), o_score)
     o_look = oracle.lsh_lookup(ids, table, feat, planes, buckets)
     assert bits_equal(ops.lsh_lookup(d(ids), d(table), d(feat), d(planes), d(buckets)).cpu().numpy(), o_look)
+    assert bits_equal(ops.lsh_lookup_score(d(ids), d(table), d(feat), d(planes), d(buckets), d(other)).cpu().numpy(),
+                      oracle.rowdot(other, o_look))
     # queued batches of a shape the persistent kernel does not take: K single launches, same rows
     multi = ops.lsh_embed_multi([d(ids), d(ids[::-1].copy())], d(feat), d(planes), d(buckets))
     assert bits_equal(multi[0].cpu().numpy(), o_emb) and bits_equal(multi[1].cpu().numpy(), o_emb[::-1])
