@@ -112,6 +112,10 @@ def lsh_embed_backward(bits, grad_out):
     if g.shape[0] != B:
         raise ValueError(f"grad_out has {g.shape[0]} rows, bits {B}")
     lib = C.lib()
+    if D > 256:
+        # embedding rows wider than the 256 columns the reduction keeps per workgroup: one window of columns at a time (a
+        # column's sum does not depend on the other columns, so the bits are those of a single pass)
+        return torch.cat([lsh_embed_backward(bits, g[:, d0:d0 + 256].contiguous()) for d0 in range(0, D, 256)], dim=1)
     out = torch.empty((H, D), dtype=torch.float32, device=g.device)
     if _bwd_mode():
         ws = torch.empty((max(int(lib.mi_oov_lsh_backward_fused_workspace(B, H, D)), 1),), dtype=torch.float32, device=g.device)
@@ -768,6 +772,8 @@ def slsh_embed_backward(idx, grad_out, n_buckets):
     idx, g = _ids(idx, "idx"), _f32(grad_out, "grad_out")
     B, D = g.shape
     lib = C.lib()
+    if D > 256 and n_buckets <= 64:  # the deterministic reduction holds 256 columns: one window of columns at a time
+        return torch.cat([slsh_embed_backward(idx, g[:, d0:d0 + 256].contiguous(), n_buckets) for d0 in range(0, D, 256)], dim=1)
     out = torch.empty((n_buckets, D), dtype=torch.float32, device=g.device)
     if _bwd_mode():
         ws = torch.empty((max(int(lib.mi_oov_lsh_backward_fused_workspace(B, min(n_buckets, 64), D)), 1),), dtype=torch.float32, device=g.device)

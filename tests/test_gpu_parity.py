@@ -826,7 +826,8 @@ def test_gather_splice_vs_oracle(oracle, ops, dev):
 
 
 @pytest.mark.parametrize("fused", ["2", "1", "0"])  # round 4: all planes + coalesced final (default) / ONE launch, the last workgroups finish / round 3's launches
-@pytest.mark.parametrize("B,H,D", [(1, 8, 64), (300, 8, 64), (70000, 8, 64), (5000, 12, 64), (999, 3, 22), (4097, 40, 50), (1 << 20, 8, 64), (65536, 17, 128)])
+@pytest.mark.parametrize("B,H,D", [(1, 8, 64), (300, 8, 64), (70000, 8, 64), (5000, 12, 64), (999, 3, 22), (4097, 40, 50), (1 << 20, 8, 64), (65536, 17, 128),
+                                   (700, 8, 300), (333, 300, 512), (100, 1000, 64)])  # embedding_size > 256: windows of columns; hundreds of buckets
 def test_lsh_backward_vs_oracle(B, H, D, fused, oracle, ops, dev, monkeypatch):
     """grad of (bits @ W)/popcount w.r.t. W: bit-exact against the oracle (same two-pass order), within 1e-5
     of torch autograd on the reference's op sequence (lsh_embedder.py:158,178), NaN rows as in the reference."""
@@ -848,7 +849,7 @@ def test_lsh_backward_vs_oracle(B, H, D, fused, oracle, ops, dev, monkeypatch):
 
 
 @pytest.mark.parametrize("fused", ["2", "1", "0"])
-@pytest.mark.parametrize("B,nb,D", [(1, 8, 64), (3000, 9, 64), (70000, 64, 64), (5000, 777, 24), (4097, 65, 50), (65536, 9, 64), (300000, 33, 128)])
+@pytest.mark.parametrize("B,nb,D", [(1, 8, 64), (3000, 9, 64), (70000, 64, 64), (5000, 777, 24), (4097, 65, 50), (65536, 9, 64), (300000, 33, 128), (900, 9, 300)])
 def test_slsh_backward_and_scatter(B, nb, D, fused, oracle, ops, dev, monkeypatch):
     monkeypatch.setenv("MI_OOV_BWD_FUSED", fused)
     rng = np.random.default_rng(B + nb)
