@@ -112,6 +112,13 @@ def test_atomic_loader(tmp_path):
     ["--model=DirectAU", "--inductive_embedder=lsh", "--add_oov_buckets", "--train_oov", "--gamma=0.5"],
     ["--dataset=toy_ind", "--benchmark_filename=train,empty,test_filt", "--inductive_embedder=lsh", "--add_oov_buckets",
      "--train_oov"],
+    # the hot tile end to end: 64-d embeddings, the dataset's narrow feature matrices zero-padded to 64 columns
+    ["--inductive_embedder=lsh", "--add_oov_buckets", "--train_oov", "--embedding_size=64"],
+    ["--inductive_embedder=slsh", "--add_oov_buckets", "--train_oov", "--embedding_size=64", "--item_oov_buckets=1000",
+     "--user_oov_buckets=1000"],
+    # as many hyperplanes as OOV buckets (plane chunks) and embedding rows wider than 256 floats (column windows)
+    ["--inductive_embedder=lsh", "--add_oov_buckets", "--train_oov", "--embedding_size=300", "--item_oov_buckets=300",
+     "--user_oov_buckets=300"],
 ])
 def test_end_to_end(flags, tmp_path, monkeypatch, dev):
     from mi_oov import driver
