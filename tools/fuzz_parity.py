@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Random shapes for the path's kernels against the oracle (bit for bit), to catch a shape rule the fixed parity cases miss
 (the plane chunks, column windows, scalar tails, partial tiles).  Developer tool, GPU box:
-    python3 tools/fuzz_parity.py [--cases 300] [--seed 0]
+    python3 tools/fuzz_parity.py [--cases 300] [--seed 0] [--only multi]
 Prints one line per failing case with everything needed to repeat it, and a summary."""
 import argparse
 import os
@@ -124,12 +124,56 @@ def case_hash(rng):
         "mapper": same(ops.mapper_map(d(mids), kind, n_orig, nb).cpu().numpy(), oracle.mapper_map(mids, kind, n_orig, nb))}
 
 
+def case_multi(rng):
+    """K queued batches per launch (the persistent kernel's tile schedule: static part, ticket pool, odd tile counts, partial
+    last tiles) against the oracle, batch by batch."""
+    K = pick(rng, (1, 6), (7, 40))
+    B = pick(rng, (1, 300), (301, 20000), 0.4)
+    N = pick(rng, (1, 500), (501, 50000))
+    H = int(rng.integers(1, 9))
+    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    feat[0] = 0
+    planes, W = rng.standard_normal((H, 64), dtype=np.float32), rng.standard_normal((H, 64), dtype=np.float32)
+    ids = np.stack([ids_of(rng, B, N) for _ in range(K)])
+    users = rng.standard_normal((K, B, 64), dtype=np.float32)
+    vt = rng.standard_normal((max(1, N // 2), 64), dtype=np.float32)
+    idx2 = rng.integers(0, N, size=(K, 2 * B - int(rng.integers(0, 2))), dtype=np.int64)
+    planes24, big = rng.standard_normal((int(rng.integers(1, 33)), 64), dtype=np.float32), rng.standard_normal((int(rng.choice([5, 40, 1000])), int(rng.choice([64, 128]))), dtype=np.float32)
+    f, p, w, i, u, v = d(feat), d(planes), d(W), d(ids), d(users), d(vt)
+    il, ul = [i[k] for k in range(K)], [u[k] for k in range(K)]
+    tab = ops.LshTable(w) if rng.random() < 0.5 else None
+    sc = ops.lsh_embed_score_multi(il, f, p, w, ul)
+    rows = ops.lsh_embed_multi(il, f, p, w, table=tab)
+    look = ops.lsh_lookup_multi(il, v, f, p, w, lsh_table=tab)
+    looks = ops.lsh_lookup_multi(il, v, f, p, w, other_list=ul, lsh_table=tab)
+    gr = ops.gather_rows_multi(il, f)
+    gm = ops.gather_mean_multi([d(idx2[k]) for k in range(K)], f, 2)
+    sl, sidx = ops.slsh_embed_multi(il, f, d(planes24), d(big), want_idx=True)
+    ok = {n: True for n in ("score", "rows", "lookup", "lookup_score", "gather_rows", "gather_mean", "slsh", "slsh_idx")}
+    for k in range(K):
+        o_emb = oracle.lsh_embed(ids[k], feat, planes, W)
+        o_look = oracle.lsh_lookup(ids[k], vt, feat, planes, W)
+        o_sl, o_sidx = oracle.slsh_embed(ids[k], feat, planes24, big)
+        ok["score"] &= same(sc[k].cpu().numpy(), oracle.lsh_embed_score(ids[k], feat, planes, W, users[k])[0])
+        ok["rows"] &= same(rows[k].cpu().numpy(), o_emb)
+        ok["lookup"] &= same(look[k].cpu().numpy(), o_look)
+        ok["lookup_score"] &= same(looks[k].cpu().numpy(), oracle.rowdot(users[k], o_look))
+        ok["gather_rows"] &= same(gr[k].cpu().numpy(), oracle.gather_rows(ids[k], feat))
+        ok["gather_mean"] &= same(gm[k].cpu().numpy(), oracle.gather_mean(idx2[k], feat, 2))
+        ok["slsh"] &= same(sl[k].cpu().numpy(), o_sl)
+        ok["slsh_idx"] &= same(sidx[k].cpu().numpy(), o_sidx)
+    return f"multi K={K} B={B} N={N} H={H} slsh_planes={planes24.shape[0]} slsh_D={big.shape[1]} table={'prepared' if tab is not None else 'built'}", ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", default="", help="lsh / slsh / gather / topk / hash / multi")
     args = ap.parse_args()
-    makers = [case_lsh, case_lsh, case_slsh, case_gather, case_topk, case_hash]
+    makers = [case_lsh, case_lsh, case_slsh, case_gather, case_topk, case_hash, case_multi]
+    if args.only:
+        makers = [m for m in makers if m.__name__ == "case_" + args.only]
     bad = 0
     for c in range(args.cases):
         rng = np.random.default_rng([args.seed, c])
