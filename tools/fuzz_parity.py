@@ -165,13 +165,112 @@ def case_multi(rng):
     return f"multi K={K} B={B} N={N} H={H} slsh_planes={planes24.shape[0]} slsh_D={big.shape[1]} table={'prepared' if tab is not None else 'built'}", ok
 
 
+def case_eval(rng):
+    """The sampled-ranking evaluation's kernels: rows of a group of batches, duplicate handling, per-user top-k over column
+    ranges, hit blocks, the metric sums; and the full-sort route's top-k under a history mask."""
+    U = pick(rng, (1, 60), (61, 3000))
+    n_neg = int(rng.choice([0, 1, 3, 50, 250]))
+    n_items = pick(rng, (2, 300), (301, 100000))
+    npos = rng.integers(0 if U > 1 else 1, 5, size=U)
+    if npos.sum() == 0:
+        npos[0] = 1
+    pos_ptr = np.concatenate([[0], np.cumsum(npos)]).astype(np.int64)
+    P = int(pos_ptr[-1])
+    user_ids = rng.permutation(10 * U)[:U].astype(np.int64)
+    pos_items = rng.integers(0, n_items, size=P, dtype=np.int64)
+    neg_items = rng.integers(0, n_items, size=(P, n_neg), dtype=np.int64).reshape(-1)
+    o_ru, o_ri, o_seg, o_pu = oracle.eval_rows_build(pos_ptr, user_ids, pos_items, neg_items, n_neg)
+    ru, ri, seg, pu = ops.eval_rows_build(d(pos_ptr), d(user_ids), d(pos_items), d(neg_items), n_neg, want_pos_user=True)
+    ok = {"eval_rows": same(ru.cpu().numpy(), o_ru) and same(ri.cpu().numpy(), o_ri) and same(seg.cpu().numpy(), o_seg) and same(pu.cpu().numpy(), o_pu)}
+    o_dd = oracle.segment_dedup(o_ri, o_seg)
+    ok["dedup"] = same(ops.segment_dedup(d(o_ri), d(o_seg)).cpu().numpy(), o_dd)
+    scores = rng.standard_normal(len(o_ri)).astype(np.float32)
+    if rng.random() < 0.3:
+        scores[rng.integers(0, len(scores), size=max(1, len(scores) // 7))] = scores[0]
+    k = int(rng.choice([1, 5, 10, 20, 50, 256]))
+    lo = int(rng.integers(0, n_items // 2 + 1))
+    hi = int(rng.integers(lo + 1, n_items + 2))
+    # (the whole range reads only the winners' columns and takes item ids >= 0: the raw columns; the de-duplicated ones,
+    #  with their -1 entries, go with an explicit range -- the evaluator's "everything" is [0, 2^62 - 1))
+    for name, cols_, (a, b) in (("whole", o_ri, (0, 2 ** 62)), ("all", o_dd, (0, 2 ** 62 - 1)), ("range", o_dd, (lo, hi))):
+        ov, oi = oracle.segment_topk(scores, cols_, o_seg, k, a, b)
+        v, i = ops.segment_topk(d(scores), d(cols_), d(o_seg), k, a, b)
+        ok["segment_topk_" + name] = same(v.cpu().numpy(), ov) and same(i.cpu().numpy(), oi)
+        ok["hits_" + name] = same(ops.topk_hits(d(oi), d(pos_ptr), d(pos_items), a, b).cpu().numpy(), oracle.topk_hits_range(oi, pos_ptr, pos_items, a, b))
+    rec = oracle.topk_hits(oracle.segment_topk(scores, o_dd, o_seg, k)[1], pos_ptr, pos_items)
+    disc = 1.0 / np.log2(np.arange(2, k + 2, dtype=np.float64))
+    idcg = np.cumsum(disc)
+    n_old = int(rng.integers(0, 10 * U + 1))
+    for uids in (None, user_ids):
+        os_, oc = oracle.topk_metric_sums(rec, disc, idcg, uids, n_old)
+        s_, c_ = ops.topk_metric_sums(d(rec), d(disc), d(idcg), None if uids is None else d(uids), n_old)
+        ok["metric_sums" + ("" if uids is None else "_sides")] = bool(np.array_equal(s_.cpu().numpy().view(np.uint64), os_.view(np.uint64))) and same(c_.cpu().numpy(), oc)
+    # full-sort route: top-k with excluded (history) columns
+    B, N, D = pick(rng, (1, 40), (41, 300)), pick(rng, (30, 3000), (3001, 40000)), int(rng.choice([8, 64, 100, 128, 200]))
+    kk = min(N // 2, int(rng.choice([1, 10, 20, 100])))
+    Uq, E = rng.standard_normal((B, D), dtype=np.float32), rng.standard_normal((N, D), dtype=np.float32)
+    cnt = rng.integers(0, int(rng.choice([2, 30, 400])), size=B)
+    cnt = np.minimum(cnt, N - kk - 1)
+    eptr = np.concatenate([[0], np.cumsum(cnt)]).astype(np.int64)
+    ecols = np.concatenate([np.sort(rng.choice(N, size=int(c), replace=False)) for c in cnt] + [np.empty(0, np.int64)]).astype(np.int64)
+    skip = int(rng.integers(0, 2))
+    ov, oi = oracle.score_topk_excl(Uq, E, kk, eptr, ecols, skip)
+    v, i = ops.score_topk_excl(d(Uq), d(E), kk, d(eptr), d(ecols), skip, h_max=int(cnt.max()) if B else 0)
+    ok["topk_excl"] = same(i.cpu().numpy(), oi) and same(v.cpu().numpy(), ov)
+    return f"eval U={U} n_neg={n_neg} items={n_items} k={k} range=[{lo},{hi}) | excl B={B} N={N} D={D} k={kk} hist<={int(cnt.max())}", ok
+
+
+def case_misc(rng):
+    """Exchange bucketing, codes -> rows, the row splice, column mean / broadcast, the materialised full sort, an f32 layer."""
+    B, world = pick(rng, (1, 500), (501, 70000)), int(rng.choice([1, 2, 3, 8, 16, 20]))
+    n_rows = pick(rng, (world, 5000), (5001, 10 ** 7))
+    per = -(-n_rows // world)
+    cap = max(1, int(B / world * rng.choice([0.5, 1.3, 4.0])) + int(rng.integers(0, 3)))
+    ids = rng.integers(-2, n_rows + 2, size=B, dtype=np.int64)
+    o_send, o_slot, o_cnt = oracle.bucket_by_owner(ids, n_rows, per, world, cap)
+    send, slot, cnt = ops.bucket_by_owner(d(ids), n_rows, per, world, cap)[:3]
+    fits = bool((o_cnt <= cap).all())  # beyond the capacity WHICH lookups are dropped is not defined: counts only
+    ok = {"bucket_counts": same(cnt.cpu().numpy(), o_cnt)}
+    if fits:
+        # the order inside a segment is the oracle's choice (stable), not the kernel's (atomic reservations): what must hold is
+        # that slot[b] is where lookup b's owner-local row sits, every slot taken once, invalid ids coded as the oracle codes them
+        got, gs = send.cpu().numpy(), slot.cpu().numpy()
+        valid = o_slot >= 0
+        ok["bucket_slots"] = bool(np.array_equal(gs[~valid], o_slot[~valid]) and (gs[valid] >= 0).all() and
+                                  len(np.unique(gs[valid])) == int(valid.sum()) and
+                                  np.array_equal(got.reshape(-1)[gs[valid]], o_send.reshape(-1)[o_slot[valid]]) and
+                                  np.array_equal(gs[valid] // cap, o_slot[valid] // cap))
+        ok["bucket_send"] = all(same(np.sort(got[r, :o_cnt[r]]), np.sort(o_send[r, :o_cnt[r]])) and (got[r, o_cnt[r]:] == -1).all() for r in range(world))
+    M, H, D = pick(rng, (1, 400), (401, 5000)), int(rng.integers(1, 41)), int(rng.choice([1, 7, 64, 65, 128, 256]))
+    codes = (rng.random((M, H)) < 0.5).astype(np.uint8)
+    codes[rng.integers(0, M)] = 0xFF
+    sl = rng.integers(-2, M, size=B if B < 3000 else 3000).astype(np.int32)
+    W, other = rng.standard_normal((H, D), dtype=np.float32), rng.standard_normal((len(sl), D), dtype=np.float32)
+    o_sc, o_emb = oracle.lsh_codes_embed(codes, sl, W, other)
+    sc, emb = ops.lsh_codes_embed(d(codes), d(sl), d(W), d(other), want_emb=True)
+    ok["codes_embed"] = same(emb.cpu().numpy(), o_emb) and same(sc.cpu().numpy(), o_sc)
+    n_vocab = int(rng.integers(1, 300))
+    table = rng.standard_normal((n_vocab, D), dtype=np.float32)
+    sid = rng.integers(0, 2 * n_vocab, size=min(B, 2000), dtype=np.int64)
+    oov_rows = rng.standard_normal((int((sid >= n_vocab).sum()), D), dtype=np.float32)
+    if len(oov_rows):
+        ok["splice"] = same(ops.splice_rows(d(sid), d(table), d(oov_rows)).cpu().numpy(), oracle.splice_rows(sid, table, oov_rows))
+    ok["col_mean"] = same(ops.col_mean(d(table)).cpu().numpy(), oracle.col_mean(table))
+    Uq, E = rng.standard_normal((int(rng.integers(1, 70)), D), dtype=np.float32), rng.standard_normal((int(rng.integers(1, 700)), D), dtype=np.float32)
+    ok["full_sort"] = same(ops.full_sort_scores(d(Uq), d(E)).cpu().numpy(), oracle.full_sort_scores(Uq, E))
+    Kin, Nout = int(rng.choice([1, 5, 16, 40, 64, 130])), int(rng.choice([1, 7, 64, 96, 200]))
+    X, Wl, bl = rng.standard_normal((Uq.shape[0] * 3, Kin), dtype=np.float32), rng.standard_normal((Nout, Kin), dtype=np.float32), rng.standard_normal(Nout).astype(np.float32)
+    ok["linear_f32"] = same(ops.linear_act(d(X), d(Wl), d(bl), None).cpu().numpy(), oracle.linear_act(X, Wl, bl, 0))
+    return f"misc B={B} world={world} n_rows={n_rows} cap={cap} | codes M={M} H={H} D={D} | linear {Kin}->{Nout}", ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--only", default="", help="lsh / slsh / gather / topk / hash / multi")
+    ap.add_argument("--only", default="", help="lsh / slsh / gather / topk / hash / multi / eval / misc")
     args = ap.parse_args()
-    makers = [case_lsh, case_lsh, case_slsh, case_gather, case_topk, case_hash, case_multi]
+    makers = [case_lsh, case_lsh, case_slsh, case_gather, case_topk, case_hash, case_multi, case_eval, case_misc]
     if args.only:
         makers = [m for m in makers if m.__name__ == "case_" + args.only]
     bad = 0
