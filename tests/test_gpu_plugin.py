@@ -801,6 +801,7 @@ def test_narrow_feature_matrices_ride_the_hot_tile_with_the_same_bits(mi, oracle
     reference-shaped operands; widths that are not a multiple of 4, zero rows and -0 entries included; the public
     attributes keep the reference's shapes; a re-loaded hyperplane Parameter is seen."""
     from mi_oov import embedders, ops
+    monkeypatch.setattr(embedders, "_PAD_FEATURES", True)  # (whatever MI_OOV_PAD_FEATURES says in this environment)
     g = torch.Generator().manual_seed(width)
     n_u, n_i, n_vocab = 700, 900, 500
     # (the first column of a feature table is the id field: lsh_embedder.py:83 skips it)
