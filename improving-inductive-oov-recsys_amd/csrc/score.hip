@@ -443,6 +443,20 @@ struct MaskedKeys {  // ... with a row of exclusion bits: an excluded column get
   }
 };
 
+// The finalize kernel's (rare) exact fallback, all four forms behind ONE type: select_topk_row keeps ~11 KB of static LDS
+// per instantiation, and four of them left that kernel two workgroups per CU -- 4096 rows in two rounds of its latency chain
+// instead of one (round 4: 17.2 -> see topk_finalize_exact_kernel).
+struct AnyDotKeys {
+  const float* u;
+  const float* E;
+  int64_t D;
+  const uint64_t* mrow;  // or null
+  __device__ __forceinline__ uint32_t operator()(int64_t c) const {
+    if (mrow && ((mrow[c >> 6] >> (c & 63)) & 1ull)) return 0u;
+    return D == 64 ? Dot64Keys{u, E}(c) : DotKeys{u, E, D}(c);
+  }
+};
+
 __device__ __forceinline__ int block_excl_scan(int v, int* wave_tot, int& total) {
   // exclusive prefix of v over the 256 threads of the block (shuffles + LDS)
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -669,7 +683,9 @@ __global__ __launch_bounds__(kBlock) void tile_kth_kernel(const uint32_t* __rest
 // workgroup-per-row kernel above ranks by counting, NT^2 compares per row: 12.5 us for 4096 rows of 98 keys, nearly all
 // of it launch and barrier latency, and 85 us at 262 keys.
 constexpr int kKthRegs = 16;
-template <int REGS>  // 64 REGS >= NT (4 for the common shapes: the unused slots of 16 doubled the kernel's time)
+// PAIRS: the row holds 2 NT maxima of 32-column tiles (bf16_tilemax_direct_kernel) and the key of a 64-column tile is the
+// larger of a pair -- the same NT keys as the LDS-staged pass 1 leaves, read 8 bytes at a time.
+template <int REGS, bool PAIRS = false>  // 64 REGS >= NT (4 for the common shapes: the unused slots of 16 doubled the kernel's time)
 __global__ __launch_bounds__(kBlock) void tile_kth_wave_kernel(const uint32_t* __restrict__ tilemax, int64_t B, int NT, int k,
                                                                uint32_t* __restrict__ tau, float* __restrict__ tauf, Bf16Bound bb) {
   const int lane = threadIdx.x & 63;
@@ -677,7 +693,14 @@ __global__ __launch_bounds__(kBlock) void tile_kth_wave_kernel(const uint32_t* _
   if (row >= B) return;
   uint32_t key[REGS];
 #pragma unroll
-  for (int q = 0; q < REGS; ++q) key[q] = (q * 64 + lane < NT) ? tilemax[row * NT + q * 64 + lane] : 0u;
+  for (int q = 0; q < REGS; ++q) {
+    if constexpr (PAIRS) {
+      const uint2 p2 = (q * 64 + lane < NT) ? reinterpret_cast<const uint2*>(tilemax + row * (2 * NT))[q * 64 + lane] : make_uint2(0u, 0u);
+      key[q] = p2.x > p2.y ? p2.x : p2.y;
+    } else {
+      key[q] = (q * 64 + lane < NT) ? tilemax[row * NT + q * 64 + lane] : 0u;
+    }
+  }
   uint32_t T = 0u;  // (fewer than k keys > 0: T stays 0 = "no bound", as the rank-counting kernel returns)
   for (int bit = 31; bit >= 0; --bit) {
     const uint32_t c = T | (1u << bit);
@@ -1546,8 +1569,18 @@ __device__ __forceinline__ uint32_t bf16_bits_rne(float v) {  // finite v
 // some lane passes.  Vector and scalar instructions do not hide behind the matrix pipe in this kernel (MI_FD_PAD above), so
 // ~40 fewer of them per block is time: 6.46 -> 6.33 ms for 4096 x 10 M, k = 2 with 64-row workgroups -- little: that search is bound by the L2s feeding B, see the rows-per-workgroup choice in score_topk_impl.  Chosen by the host from the expected number of
 // passing scores per wave and block.
+// Round 4: the user fragments of a 64-row workgroup (MT = 2) live in LDS, ONE copy per workgroup, instead of 32 (D <= 64) or 64
+// (D <= 128) registers in every lane of every wave -- all four waves hold the same rows.  A matrix instruction's A operand is
+// then a conflict-free ds_read_b128 (consecutive lanes, consecutive 16 bytes), the kernel needs 117 registers instead of 173 at
+// D = 128 and runs four waves per SIMD instead of two, which is what hides the B loads: filter pass at 4096 x 50 000, k = 20,
+// D = 128: 75.8 -> 64.8 us (the call 136.6 -> 129.0); D = 64 (already four waves): 41.4 -> 39.3 (82.4 -> 80.0).  The 128-row
+// workgroups of the large-catalogue searches (MT = 4) keep their fragments in registers: there the extra waves only add
+// pressure on the L2s that feed B (4096 x 10 M, k = 2: 6.3 ms against 7.7 with the LDS copy).  MI_FD_ALDS=0: rounds 2-3.
+#ifndef MI_FD_ALDS
+#define MI_FD_ALDS 1
+#endif
 template <bool MASKED, int MT, int KH = 1, bool RARE = false>  // MT 32-row tiles = the workgroup's user rows (every wave holds all of them)
-__global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
+__global__ __launch_bounds__(kBlock, (MI_FD_ALDS && MT == 2) ? 4 : ((MT == 4 || KH == 2) ? 2 : 4)) void bf16_filter_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
                                                                        const __bf16* __restrict__ Eb, int64_t N,
                                                                        const float* __restrict__ thr, TopkArgs ta, StripLists sl,
                                                                        int nvisit) {
@@ -1577,14 +1610,22 @@ __global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_fil
 #pragma unroll
     for (int ks = 0; ks < NKS; ++ks) bq[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n0 + ccol, ks * 2 + hh));
   }
-  u32x4 aq[MT][NKS];
+  constexpr bool kALds = MI_FD_ALDS != 0 && MT == 2;
+  u32x4 aq[kALds ? 1 : MT][NKS];
+  u32x4* sA = reinterpret_cast<u32x4*>(rowcnt + RM) + 4 * (kDirectQueue + 1);  // (kALds) [MT][NKS][64 lanes] behind the four queues
   s16x4 at[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     const int r = m * 32 + i32;
     const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
+    if constexpr (kALds) {  // every wave would hold the same fragments: wave w stages k-steps w, w + 4, ...
 #pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) aq[m][ks] = *reinterpret_cast<const u32x4*>(Ub + ra * (64 * KH) + ks * 16 + hh * 8);
+      for (int ks = 0; ks < NKS; ++ks)
+        if ((ks & 3) == wv) sA[(m * NKS + ks) * 64 + lane] = *reinterpret_cast<const u32x4*>(Ub + ra * (64 * KH) + ks * 16 + hh * 8);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) aq[m][ks] = *reinterpret_cast<const u32x4*>(Ub + ra * (64 * KH) + ks * 16 + hh * 8);
+    }
     float nt = (r < rows_here) ? 0.f - thr[b0 + r] : -__builtin_inff();
     if (nt != nt) nt = __builtin_inff();
     uint32_t p0, p1 = 0u, p2 = 0u;
@@ -1668,8 +1709,10 @@ __global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_fil
       for (int r = 0; r < 16; ++r) c[r] = 0.f;
       c = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(at[m], ones, c, 0, 0, 0);
 #pragma unroll
-      for (int ks = 0; ks < NKS; ++ks)
-        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, aq[m][ks]), __builtin_bit_cast(bf16x8, bq[ks]), c, 0, 0, 0);
+      for (int ks = 0; ks < NKS; ++ks) {
+        const u32x4 af = kALds ? sA[(m * NKS + ks) * 64 + lane] : aq[kALds ? 0 : m][ks];
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af), __builtin_bit_cast(bf16x8, bq[ks]), c, 0, 0, 0);
+      }
       acc[m] = c;
     }
     // acc[m][r]: row m 32 + (r & 3) + 8 (r >> 2) + 4 hh, column n0 + ccol
@@ -1792,6 +1835,179 @@ __global__ __launch_bounds__(kBlock, (MT == 4 || KH == 2) ? 2 : 4) void bf16_fil
     const int n = rowcnt[tid];
     sl.cnt[(b0 + tid) * sl.ns + strip] = n < sl.cap ? n : sl.cap;
     if (n & kRowLost) atomicAdd(&sl.ovf_cnt[b0 + tid], kOvfCap + 1);  // candidates of this row were dropped: exact fallback
+  }
+}
+
+// ---- pass 1 in the direct layout (round 4) -------------------------------------------------------------------------------
+// The sampled tile maxima on the structure of bf16_filter_direct_kernel instead of the LDS-staged bf16_tile_kernel: a
+// 64-row workgroup keeps ONE copy of its user fragments in LDS, each of its four waves takes a 32-column slice of a
+// 128-column block with its E fragments straight from global memory one block ahead, no barrier inside the strip loop.
+// The product is taken transposed (E slice x U^T), so a lane holds 16 columns of ONE user row per accumulator and the
+// maximum of a (row, 32-column tile) is 8 in-lane operations and one exchange with lane ^ 32 -- the tiles are 32 columns
+// wide here (NT = 4 per visited block; bf16_tile_kernel: 2), which also makes the k-th best tile maximum a tighter bound.
+// Per full product this structure costs ~27 us at D = 64 where the LDS-staged kernel costs ~48: pass 1 (every fourth
+// block) 16.8 -> see DESIGN.md section 5d.1.  F32A / FoldU as in bf16_tile_kernel: the user rows are converted while they
+// are staged, and the workgroups of strip 0 leave the bf16 copy, the squared norms and the zeroed overflow counters.
+template <bool MASKED, int KH, bool F32A>
+__global__ __launch_bounds__(kBlock, 4) void bf16_tilemax_direct_kernel(const __bf16* __restrict__ Ub, int64_t B,
+                                                                        const __bf16* __restrict__ Eb, int64_t N, TopkArgs ta,
+                                                                        StripLists sl, int nvisit, FoldU fold) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int RM = 64, NKS = 4 * KH;
+  u32x4* sA = reinterpret_cast<u32x4*>(smem);  // [2 tiles of 32 rows][NKS][64 lanes]: the A operand's fragments
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int i32 = lane & 31, hh = lane >> 5;
+  const int stride = ta.col_stride > 1 ? ta.col_stride : 1;
+  const int64_t b0 = static_cast<int64_t>(blockIdx.y) * RM;
+  const int strip = blockIdx.x, nstrip = gridDim.x;
+  if (strip >= nvisit) return;
+  const int rows_here = (B - b0 < RM) ? static_cast<int>(B - b0) : RM;
+  const uint32_t n_cols = static_cast<uint32_t>(N);
+  const uint32_t skip = ta.n_skip_low < N ? static_cast<uint32_t>(ta.n_skip_low) : n_cols;
+
+  const int ccol = wv * 32 + i32;  // this lane's column inside a block
+  u32x4 bq[NKS], bn[NKS];
+  {
+    const int64_t n0 = static_cast<int64_t>(strip) * stride * BN;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) bq[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n0 + ccol, ks * 2 + hh));
+  }
+#pragma unroll
+  for (int m = 0; m < 2; ++m) {
+    const int r = m * 32 + i32;
+    const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks)
+      if ((ks & 3) == wv) {  // every wave would hold the same fragments: wave w stages k-steps w, w + 4
+        u32x4 pk;
+        if constexpr (F32A) {
+          const float4* src = reinterpret_cast<const float4*>(fold.U + ra * (64 * KH) + ks * 16 + hh * 8);
+          const float4 x0 = src[0], x1 = src[1];
+          pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x0.x), static_cast<__bf16>(x0.y)});
+          pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x0.z), static_cast<__bf16>(x0.w)});
+          pk.z = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x1.x), static_cast<__bf16>(x1.y)});
+          pk.w = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x1.z), static_cast<__bf16>(x1.w)});
+        } else {
+          pk = *reinterpret_cast<const u32x4*>(Ub + ra * (64 * KH) + ks * 16 + hh * 8);
+        }
+        sA[(m * NKS + ks) * 64 + lane] = pk;
+      }
+  }
+  if constexpr (F32A) {
+    if (strip == 0) {
+      // what the later kernels read, exactly as bf16_tile_kernel<..., F32A> leaves it: thread (erow, eoff) takes eight
+      // consecutive floats of a row per half, the eight threads of a row add their squares up for the norm
+      const int erow = tid >> 3, eoff = (tid & 7) * 8;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int r = erow + 32 * q;
+        const int64_t ra = (r < rows_here) ? b0 + r : B - 1;
+        float sq = 0.f;
+#pragma unroll
+        for (int h = 0; h < KH; ++h) {
+          const float4* src = reinterpret_cast<const float4*>(fold.U + ra * (64 * KH) + h * 64 + eoff);
+          const float4 x0 = src[0], x1 = src[1];
+          u32x4 pk;
+          pk.x = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x0.x), static_cast<__bf16>(x0.y)});
+          pk.y = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x0.z), static_cast<__bf16>(x0.w)});
+          pk.z = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x1.x), static_cast<__bf16>(x1.y)});
+          pk.w = __builtin_bit_cast(uint32_t, bf16x2{static_cast<__bf16>(x1.z), static_cast<__bf16>(x1.w)});
+          if (r < rows_here) *reinterpret_cast<u32x4*>(fold.Ub_out + ra * (64 * KH) + h * 64 + eoff) = pk;
+          sq = __builtin_fmaf(x0.x, x0.x, sq); sq = __builtin_fmaf(x0.y, x0.y, sq);
+          sq = __builtin_fmaf(x0.z, x0.z, sq); sq = __builtin_fmaf(x0.w, x0.w, sq);
+          sq = __builtin_fmaf(x1.x, x1.x, sq); sq = __builtin_fmaf(x1.y, x1.y, sq);
+          sq = __builtin_fmaf(x1.z, x1.z, sq); sq = __builtin_fmaf(x1.w, x1.w, sq);
+        }
+        sq = sq + __shfl_xor(sq, 1, 64);
+        sq = sq + __shfl_xor(sq, 2, 64);
+        sq = sq + __shfl_xor(sq, 4, 64);
+        if (r < rows_here && (tid & 7) == 0) {
+          fold.u2[ra] = sq;
+          fold.zero_rows[ra] = 0;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  for (int j = strip; j < nvisit; j += nstrip) {
+    const int64_t n0 = static_cast<int64_t>(j) * stride * BN;
+    {
+      const int64_t n1 = static_cast<int64_t>(j + nstrip < nvisit ? j + nstrip : j) * stride * BN;  // (the last block re-reads itself)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) bn[ks] = *reinterpret_cast<const u32x4*>(Eb + eb_chunk<KH>(n1 + ccol, ks * 2 + hh));
+    }
+    uint64_t mw[2] = {0ull, 0ull};  // MASKED: the exclusion bits of this lane's two user rows for the 64 columns its slice lies in
+    if constexpr (MASKED) {
+      const int64_t tw = (n0 >> 6) + (wv >> 1);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const int lr = m * 32 + i32;
+        if (lr < rows_here && tw < sl.mask_words) mw[m] = sl.mask[(b0 + lr) * sl.mask_words + tw];
+      }
+    }
+    f32x16 acc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      f32x16 c;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) c[r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[ks]), __builtin_bit_cast(bf16x8, sA[(m * NKS + ks) * 64 + lane]), c, 0, 0, 0);
+      acc[m] = c;
+    }
+    // acc[m][r]: column n0 + wv 32 + (r & 3) + 8 (r >> 2) + 4 hh, user row m 32 + i32.  NaN sorts first (torch.topk): max
+    // drops NaNs, so they are tracked through the largest |bits| seen (as bf16_tile_kernel does).
+    const int64_t c_lo = n0 + wv * 32, c_hi = c_lo + 32;
+    const bool all_cols = c_hi <= N && c_lo >= ta.n_skip_low;  // uniform; false only at the two ends of the catalogue
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+      float best = -__builtin_inff();
+      uint32_t amax = 0u;
+      bool any = false;
+      if (all_cols) {
+        const uint32_t w32 = static_cast<uint32_t>(mw[m] >> ((wv & 1) * 32 + 4 * hh));  // bit (r & 3) + 8 (r >> 2) = this lane's column r
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          float v0 = acc[m][r], v1 = acc[m][r + 1];
+          if constexpr (MASKED) {  // an excluded column counts as -inf: sign-extended bit, bit-field insert
+            const int b0_ = (r & 3) + 8 * (r >> 2), b1_ = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
+            const uint32_t e0 = static_cast<uint32_t>(static_cast<int>(w32 << (31 - b0_)) >> 31);
+            const uint32_t e1 = static_cast<uint32_t>(static_cast<int>(w32 << (31 - b1_)) >> 31);
+            v0 = __uint_as_float((__float_as_uint(v0) & ~e0) | (0xFF800000u & e0));
+            v1 = __uint_as_float((__float_as_uint(v1) & ~e1) | (0xFF800000u & e1));
+          }
+          best = __builtin_fmaxf(__builtin_fmaxf(best, v0), v1);
+          const uint32_t a0 = __float_as_uint(v0) & 0x7FFFFFFFu, a1 = __float_as_uint(v1) & 0x7FFFFFFFu;
+          amax = a0 > amax ? a0 : amax;
+          amax = a1 > amax ? a1 : amax;
+        }
+        any = true;
+      } else {
+        uint32_t cbase = static_cast<uint32_t>(c_lo) + 4 * hh;
+        asm volatile("" : "+v"(cbase));  // (not hoisted out of the rare branch)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const uint32_t col = cbase + (r & 3) + 8 * (r >> 2);
+          const bool excluded = MASKED && ((mw[m] >> (col & 63u)) & 1ull);
+          if (col < n_cols && col >= skip && !excluded) {
+            best = __builtin_fmaxf(best, acc[m][r]);
+            const uint32_t a0 = __float_as_uint(acc[m][r]) & 0x7FFFFFFFu;
+            amax = a0 > amax ? a0 : amax;
+            any = true;
+          }
+        }
+      }
+      uint32_t key = !any ? 0u : (amax > 0x7F800000u ? 0xFFFFFFFFu : order_key(best));
+      const uint32_t other = __shfl_xor(key, 32, 64);
+      key = other > key ? other : key;
+      const int lrow = m * 32 + i32;
+      if (hh == 0 && lrow < rows_here) ta.tilemax[(b0 + lrow) * ta.NT + j * 4 + wv] = key;
+    }
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) bq[ks] = bn[ks];
   }
 }
 
@@ -2005,10 +2221,9 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
   for (int w = 0; w < kFinRows; ++w) {
     if (!ovf_row[w]) continue;
     const int64_t r = static_cast<int64_t>(blockIdx.x) * kFinRows + w;
-    if (sl.mask) {  // excluded columns rank below every real key and are blanked afterwards (never returned)
-      const uint64_t* mrow = sl.mask + r * sl.mask_words;
-      if (D == 64) select_topk_row(MaskedKeys<Dot64Keys>{Dot64Keys{U + r * 64, E}, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
-      else select_topk_row(MaskedKeys<DotKeys>{DotKeys{U + r * D, E, D}, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
+    const uint64_t* mrow = sl.mask ? sl.mask + r * sl.mask_words : nullptr;
+    select_topk_row(AnyDotKeys{U + r * D, E, D, mrow}, N, k, n_skip_low, vals + r * k, idx + r * k);
+    if (mrow) {  // excluded columns rank below every real key and are blanked afterwards (never returned)
       __syncthreads();
       for (int t = threadIdx.x; t < k; t += kBlock) {
         const int64_t c = idx[r * k + t];
@@ -2017,9 +2232,6 @@ __global__ __launch_bounds__(kBlock) void topk_finalize_exact_kernel(const float
           vals[r * k + t] = -__builtin_inff();
         }
       }
-    } else {
-      if (D == 64) select_topk_row(Dot64Keys{U + r * 64, E}, N, k, n_skip_low, vals + r * k, idx + r * k);
-      else select_topk_row(DotKeys{U + r * D, E, D}, N, k, n_skip_low, vals + r * k, idx + r * k);
     }
     __syncthreads();
   }
@@ -2120,7 +2332,7 @@ static FusedLayout fused_layout(int64_t B, int64_t N, int64_t k, bool bf16, int 
   if (stride > nblk / k) stride = nblk / k;  // sampled 64-column tiles: 2 * nblk / stride >= 2k
   if (stride < 1) stride = 1;
   L.stride = stride;
-  L.NT = 2 * ((nblk + stride - 1) / stride);
+  L.NT = (bf16 ? 4 : 2) * ((nblk + stride - 1) / stride);  // (bf16: room for the direct pass 1's 32-column tiles; the LDS-staged one fills half)
   L.cap = kSeg * kSegCap;
   L.seg_width = (nblk + kSeg - 1) / kSeg;
   L.off_tilemax = 0;
@@ -2244,6 +2456,13 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
       const int64_t target_d = target_env > 0 ? target_env : (mt == 2 ? 1024 : 512);
       const int64_t rbd = (B + mt * 32 - 1) / (mt * 32);
       const int64_t ns1 = strips(nvisit1, target1, rb), ns2 = direct ? strips(nblk, target_d, rbd) : strips(nblk, target, rb);
+      // pass 1 in the direct layout (64-row workgroups, 32-column tiles: bf16_tilemax_direct_kernel) wherever the filter
+      // pass runs its 64-row form; the large-catalogue searches keep the LDS-staged kernel (MI_OOV_TOPK_DIRECT1=0: everywhere)
+      static const bool direct1_on = env_knob("MI_OOV_TOPK_DIRECT1", 1, 0, 1) != 0;
+      static const int64_t target_d1 = env_knob("MI_OOV_STRIP_WGS1D", 512, 1, 65536);  // (512 / 1024 / 2048: 26.2 / 28.3 / 35.4 us at D = 128)
+      const bool direct1 = direct1_on && direct && mt == 2 && kh == 2;  // (D <= 64: the LDS-staged kernel is as fast -- 16.8 against 18.4 us)
+      const int64_t ns1d = strips(nvisit1, target_d1, rbd);
+      ta.NT = direct1 ? L.NT : L.NT / 2;
       StripLists sl{};
       sl.ns = static_cast<int>(ns2);
       {  // list capacity: a power of two >= `MI_OOV_LIST_SLACK` (2) x the expected share of ~1.3 k stride candidates per
@@ -2293,7 +2512,18 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
                            static_cast<int>(nvisit), fold);
         return MI_OOV_OK;
       };
-      if (fold_u) {
+      if (direct1) {
+        const size_t lds1 = static_cast<size_t>(2) * 4 * kh * 64 * 16;
+        auto launch1 = [&](auto kern) {
+          hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(ns1d), static_cast<unsigned>(rbd)), dim3(kBlock), lds1, st, Ub, B, Eb, N, ta, sl,
+                             static_cast<int>(nvisit1), fold);
+        };
+#define MI_P1(M, K2, F) launch1(bf16_tilemax_direct_kernel<M, K2, F>)
+        if (kh == 2) { if (mask) { if (fold_u) MI_P1(true, 2, true); else MI_P1(true, 2, false); } else { if (fold_u) MI_P1(false, 2, true); else MI_P1(false, 2, false); } }
+        else { if (mask) { if (fold_u) MI_P1(true, 1, true); else MI_P1(true, 1, false); } else { if (fold_u) MI_P1(false, 1, true); else MI_P1(false, 1, false); } }
+#undef MI_P1
+        rc = check_launch();
+      } else if (fold_u) {
         if (kh == 2) rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 2, true>, lds_ops, ns1, nullptr, nvisit1)
                                : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 2, true>, lds_ops, ns1, nullptr, nvisit1);
         else rc = mask ? launch_tile(bf16_tile_kernel<EPI_TILEMAX, true, 1, true>, lds_ops, ns1, nullptr, nvisit1)
@@ -2304,19 +2534,24 @@ static int score_topk_impl(const float* U, int64_t B, const float* E, int64_t N,
                      : launch_tile(bf16_tile_kernel<EPI_TILEMAX, false, 1>, lds_ops, ns1, nullptr, nvisit1);
       if (rc) return rc;
       Bf16Bound bb{u2, e2max, static_cast<int>(ge), thr, eps};
-      if (L.NT <= 256)
-        hipLaunchKernelGGL(tile_kth_wave_kernel<4>, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
-                           static_cast<int>(L.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
+      if (direct1 && ta.NT <= 512)  // (the direct pass 1 leaves 32-column tiles: pairs of them are the 64-column tiles' keys)
+        hipLaunchKernelGGL((tile_kth_wave_kernel<4, true>), dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
+                           static_cast<int>(ta.NT / 2), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
                            reinterpret_cast<float*>(ws + L.off_tauf), bb);
-      else if (L.NT <= 64 * kKthRegs)
+      else if (ta.NT <= 256)
+        hipLaunchKernelGGL(tile_kth_wave_kernel<4>, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
+                           static_cast<int>(ta.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
+                           reinterpret_cast<float*>(ws + L.off_tauf), bb);
+      else if (ta.NT <= 64 * kKthRegs)
         hipLaunchKernelGGL(tile_kth_wave_kernel<kKthRegs>, dim3(static_cast<unsigned>((B + kBlock / 64 - 1) / (kBlock / 64))), dim3(kBlock), 0, st, ta.tilemax, B,
-                           static_cast<int>(L.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
+                           static_cast<int>(ta.NT), static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau),
                            reinterpret_cast<float*>(ws + L.off_tauf), bb);
       else
-        hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, L.NT,
+        hipLaunchKernelGGL(tile_kth_kernel, dim3(static_cast<unsigned>(B)), dim3(kBlock), 0, st, ta.tilemax, B, ta.NT,
                            static_cast<int>(k), reinterpret_cast<uint32_t*>(ws + L.off_tau), reinterpret_cast<float*>(ws + L.off_tauf), bb);
       if ((rc = check_launch())) return rc;
-      const size_t lds_direct = BM * sizeof(int) + 4 * (kDirectQueue + 1) * 16;
+      // row counters, the four waves' queues, and (MI_FD_ALDS) the user fragments: [32-row tiles][k-steps][64 lanes] x 16 B
+      const size_t lds_direct = BM * sizeof(int) + 4 * (kDirectQueue + 1) * 16 + ((MI_FD_ALDS && (kh == 2 || mt == 2)) ? static_cast<size_t>(2) * 4 * kh * 64 * 16 : 0);
       auto launch_direct = [&](auto kern) {
         hipLaunchKernelGGL(kern, dim3(static_cast<unsigned>(ns2), static_cast<unsigned>(rbd)), dim3(kBlock), lds_direct, st, Ub, B, Eb, N, thr, ta, sl,
                            static_cast<int>(nblk));
