@@ -1575,7 +1575,9 @@ __device__ __forceinline__ uint32_t bf16_bits_rne(float v) {  // finite v
 // D = 128 and runs four waves per SIMD instead of two, which is what hides the B loads: filter pass at 4096 x 50 000, k = 20,
 // D = 128: 75.8 -> 64.8 us (the call 136.6 -> 129.0); D = 64 (already four waves): 41.4 -> 39.3 (82.4 -> 80.0).  The 128-row
 // workgroups of the large-catalogue searches (MT = 4) keep their fragments in registers: there the extra waves only add
-// pressure on the L2s that feed B (4096 x 10 M, k = 2: 6.3 ms against 7.7 with the LDS copy).  MI_FD_ALDS=0: rounds 2-3.
+// pressure on the L2s that feed B (4096 x 10 M, k = 2: 6.3 ms against 7.7 with the LDS copy).  Half of the fragments in registers
+// and half in LDS (D = 128, three waves per SIMD): 83.6 us -- it is the occupancy, not the LDS operand reads, that this kernel lives
+// on.  MI_FD_ALDS=0: rounds 2-3.
 #ifndef MI_FD_ALDS
 #define MI_FD_ALDS 1
 #endif
