@@ -403,6 +403,13 @@ class LshMultiScorer:
 
     def _single(self, q, j):
         lib, ids, out = C.lib(), q.ids[j], q.scores[j]
+        if not q.rows and self.D > 256:
+            # the fused score entries take rows of up to 256 floats (one launch holds the whole row): wider rows are written
+            # a window of columns at a time and the row dot is a launch of its own -- what lsh_embed_score does
+            emb = (lsh_embed(ids, self.feat, self.planes, self.buckets) if self.vtable is None
+                   else lsh_lookup(ids, self.vtable, self.feat, self.planes, self.buckets))
+            out.copy_(_rowdot_forward(q.other[j], emb))
+            return
         vt, nv = (self.vtable.data_ptr(), self.vtable.shape[0]) if self.vtable is not None else (None, 0)
         with C.on_device(ids):
             st = C.stream_of(ids)

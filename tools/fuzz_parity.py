@@ -131,14 +131,18 @@ def case_multi(rng):
     B = pick(rng, (1, 300), (301, 20000), 0.4)
     N = pick(rng, (1, 500), (501, 50000))
     H = int(rng.integers(1, 9))
-    feat = rng.standard_normal((N, 64), dtype=np.float32)
+    F = D = 64
+    if rng.random() < 0.3:  # shapes the persistent kernel does not take: the wrappers' K single launches
+        F, D, H = int(rng.choice([3, 20, 64, 65, 130])), int(rng.choice([1, 50, 64, 65, 128, 257])), int(rng.choice([1, 8, 9, 40, 70]))
+        B = min(B, 3000)
+    feat = rng.standard_normal((N, F), dtype=np.float32)
     feat[0] = 0
-    planes, W = rng.standard_normal((H, 64), dtype=np.float32), rng.standard_normal((H, 64), dtype=np.float32)
+    planes, W = rng.standard_normal((H, F), dtype=np.float32), rng.standard_normal((H, D), dtype=np.float32)
     ids = np.stack([ids_of(rng, B, N) for _ in range(K)])
-    users = rng.standard_normal((K, B, 64), dtype=np.float32)
-    vt = rng.standard_normal((max(1, N // 2), 64), dtype=np.float32)
+    users = rng.standard_normal((K, B, D), dtype=np.float32)
+    vt = rng.standard_normal((max(1, N // 2), D), dtype=np.float32)
     idx2 = rng.integers(0, N, size=(K, 2 * B - int(rng.integers(0, 2))), dtype=np.int64)
-    planes24, big = rng.standard_normal((int(rng.integers(1, 33)), 64), dtype=np.float32), rng.standard_normal((int(rng.choice([5, 40, 1000])), int(rng.choice([64, 128]))), dtype=np.float32)
+    planes24, big = rng.standard_normal((int(rng.integers(1, 33)), F), dtype=np.float32), rng.standard_normal((int(rng.choice([5, 40, 1000])), int(rng.choice([64, 128]) if F == 64 else D)), dtype=np.float32)
     f, p, w, i, u, v = d(feat), d(planes), d(W), d(ids), d(users), d(vt)
     il, ul = [i[k] for k in range(K)], [u[k] for k in range(K)]
     tab = ops.LshTable(w) if rng.random() < 0.5 else None
@@ -162,7 +166,7 @@ def case_multi(rng):
         ok["gather_mean"] &= same(gm[k].cpu().numpy(), oracle.gather_mean(idx2[k], feat, 2))
         ok["slsh"] &= same(sl[k].cpu().numpy(), o_sl)
         ok["slsh_idx"] &= same(sidx[k].cpu().numpy(), o_sidx)
-    return f"multi K={K} B={B} N={N} H={H} slsh_planes={planes24.shape[0]} slsh_D={big.shape[1]} table={'prepared' if tab is not None else 'built'}", ok
+    return f"multi K={K} B={B} N={N} F={F} D={D} H={H} slsh_planes={planes24.shape[0]} slsh_D={big.shape[1]} table={'prepared' if tab is not None else 'built'}", ok
 
 
 def case_eval(rng):
