@@ -268,13 +268,63 @@ def case_misc(rng):
     return f"misc B={B} world={world} n_rows={n_rows} cap={cap} | codes M={M} H={H} D={D} | linear {Kin}->{Nout}", ok
 
 
+def case_plugin(rng):
+    """The lsh / slsh plugin CLASSES on random feature widths, embedding sizes and bucket counts (zero-padded hot operands,
+    plane chunks, column windows all at once) against the oracle on the reference-shaped operands; train mode strips the
+    prime pad in place."""
+    import mi_oov as mi
+    n_new, n_orig = int(rng.integers(50, 800)), int(rng.integers(10, 50))
+    widths = [int(rng.choice([0, 1, 3, 17, 40, 64, 70])) for _ in range(int(rng.integers(1, 4)))]
+    D = int(rng.choice([1, 16, 50, 64, 64, 64, 128, 130, 300]))
+    nb = int(rng.choice([1, 2, 8, 8, 9, 33, 100, 400]))
+    g = torch.Generator().manual_seed(int(rng.integers(0, 2 ** 31)))
+
+    def feats():
+        cols = {"id": torch.arange(n_new)}
+        for j, w in enumerate(widths):
+            cols[f"f{j}"] = torch.randn((n_new,) if w == 0 else (n_new, w), generator=g)
+        return mi.FeatureTable(cols)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.user_oov_buckets = torch.nn.Embedding.from_pretrained(torch.randn((nb, D), generator=g).to(dev), freeze=True)
+            self.item_oov_buckets = torch.nn.Embedding.from_pretrained(torch.randn((nb, D), generator=g).to(dev), freeze=True)
+
+    prime = 112062759511
+    norm = str(rng.choice(["per-feature", "global", "none"]))
+    model = M()
+    ids = torch.from_numpy(rng.integers(0, n_new, size=int(rng.integers(1, 600)), dtype=np.int64)).to(dev)
+    ok = {}
+    for name, emb in (("lsh", mi.LSHInductiveEmbedder(feats(), feats(), n_orig, n_orig, nb, nb, D, dev, prime, norm, mi.InductiveFeatureCache())),
+                      ("slsh", mi.SingleLSHInductiveEmbedder(feats(), feats(), n_orig, n_orig, nb, nb, D, dev, prime, norm))):
+        feat = emb.item_feature_mat.cpu().numpy()
+        planes = emb.item_lsh.uniform_planes[0].data.cpu().numpy()
+        W = model.item_oov_buckets.weight.cpu().numpy()
+        emb.set_eval()
+        rows = emb.embed_item_ids(ids.clone(), model).cpu().numpy()
+        codes = emb._hash_items(ids).cpu().numpy()
+        emb.set_train()
+        padded = ids.clone() + prime * (torch.arange(ids.numel(), device=dev) % 2)
+        rows_t = emb.embed_item_ids(padded, model).cpu().numpy()
+        if name == "lsh":
+            o_rows, o_codes = oracle.lsh_embed(ids.cpu().numpy(), feat, planes, W, want_bits=True)
+            ok["lsh_codes"] = same(codes.astype(np.uint8), o_codes)
+        else:
+            o_rows, o_codes = oracle.slsh_embed(ids.cpu().numpy(), feat, planes, W)
+            ok["slsh_idx"] = same(codes, o_codes)
+        ok[name + "_rows"] = same(rows, o_rows)
+        ok[name + "_train_rows"] = same(rows_t, o_rows) and bool(torch.equal(padded, ids))
+    return f"plugin widths={widths} D={D} buckets={nb} norm={norm} n_new={n_new} B={ids.numel()}", ok
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=300)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--only", default="", help="lsh / slsh / gather / topk / hash / multi / eval / misc")
+    ap.add_argument("--only", default="", help="lsh / slsh / gather / topk / hash / multi / eval / misc / plugin")
     args = ap.parse_args()
-    makers = [case_lsh, case_lsh, case_slsh, case_gather, case_topk, case_hash, case_multi, case_eval, case_misc]
+    makers = [case_lsh, case_lsh, case_slsh, case_gather, case_topk, case_hash, case_multi, case_eval, case_misc, case_plugin]
     if args.only:
         makers = [m for m in makers if m.__name__ == "case_" + args.only]
     bad = 0
