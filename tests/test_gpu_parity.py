@@ -571,6 +571,7 @@ def test_hash_net_forward_runs_the_split_layers_whatever_the_batch(ops, dev, mon
     """Inference runs on mi_oov_linear_x3 at every batch size, and a row's result does not depend on the batch it sits in
     (1500 rows: 128 x 128 tiles; the same rows inside a 40000-row batch: the pipelined 256 x 256 kernel for the wide layer);
     MI_OOV_LINEAR_X3=0 selects the f32 kernel."""
+    monkeypatch.delenv("MI_OOV_LINEAR_X3", raising=False)  # (the default route, whatever this environment sets)
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Linear(48, 512), torch.nn.GELU(), torch.nn.Linear(512, 64), torch.nn.Sigmoid()).to(dev)
     calls = {"x3": 0, "f32": 0}
