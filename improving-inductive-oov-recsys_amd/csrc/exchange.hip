@@ -264,23 +264,31 @@ __global__ __launch_bounds__(256) void fill_segment_tails_kernel(int64_t* __rest
 // A 16-lane row owns a lookup; lane l holds 4-float chunks l, l+16, ... of the output row (the canonical order of
 // DESIGN.md section 4): acc = fmaf(bit_h, W[h][d], acc) for h = 0..H-1 from +0, one IEEE division by the exact count,
 // score = 16-lane tree over the lanes' multiply-then-add chains.  Same operations as lsh_fused_kernel (lsh.hip).
-template <int DC>
+// CHUNK (round 4): more bucket rows than the LDS holds (a model with thousands of OOV buckets) are staged hc at a time, the
+// four waves in lock step; the chain over h runs on in order, so the bits are those of the resident form.
+template <int DC, bool CHUNK = false>
 __global__ __launch_bounds__(256) void lsh_codes_embed_kernel(const uint8_t* __restrict__ codes, int64_t M,
                                                              const int32_t* __restrict__ slot, int64_t B, int H,
                                                              const float* __restrict__ buckets, int D,
                                                              const float* __restrict__ other, float* __restrict__ score,
-                                                             float* __restrict__ out) {
-  extern __shared__ __attribute__((aligned(16))) float sW[];  // [H][DC*64], zero padded
+                                                             float* __restrict__ out, int hc) {
+  extern __shared__ __attribute__((aligned(16))) float sW[];  // [H or hc][DC*64], zero padded
   constexpr int DP = DC * 64;
-  for (int i = threadIdx.x; i < H * DP; i += 256) {
-    const int h = i / DP, e = i - h * DP;
-    sW[i] = (e < D) ? buckets[h * D + e] : 0.f;
+  auto stage = [&](int h0, int hn) {
+    for (int i = threadIdx.x; i < hn * DP; i += 256) {
+      const int h = i / DP, e = i - h * DP;
+      sW[i] = (e < D) ? buckets[static_cast<int64_t>(h0 + h) * D + e] : 0.f;
+    }
+  };
+  if constexpr (!CHUNK) {
+    stage(0, H);
+    __syncthreads();
   }
-  __syncthreads();
+  const int HC = CHUNK ? hc : H;
   const int lane = threadIdx.x & 63, l16 = lane & 15, grp = lane >> 4, wv = threadIdx.x >> 6;
   const bool vec = (D % 4) == 0;
   const int64_t ngroups = (B + 3) / 4;  // a wave takes 4 lookups per pass
-  for (int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wv; g < ngroups; g += static_cast<int64_t>(gridDim.x) * 4) {
+  for (int64_t g = static_cast<int64_t>(blockIdx.x) * 4 + wv; (CHUNK ? g - wv : g) < ngroups; g += static_cast<int64_t>(gridDim.x) * 4) {
     const int64_t b = g * 4 + grp;
     const bool live = b < B;
     const int32_t s = live ? slot[b] : -1;
@@ -292,13 +300,20 @@ __global__ __launch_bounds__(256) void lsh_codes_embed_kernel(const uint8_t* __r
     float cnt = 0.f;
     bool ok = have;
     for (int h = 0; h < H; ++h) {
+      if constexpr (CHUNK) {
+        if (h % HC == 0) {  // (uniform)
+          __syncthreads();
+          stage(h, (H - h < HC) ? H - h : HC);
+          __syncthreads();
+        }
+      }
       const uint8_t cb = crow[h];
       if (cb > 1) ok = false;  // 0xFF: the owner saw an id outside its shard
       const float bit = (cb == 1) ? 1.f : 0.f;
       cnt = cnt + bit;
 #pragma unroll
       for (int c = 0; c < DC; ++c) {
-        const float4 w = *reinterpret_cast<const float4*>(sW + h * DP + (c * 16 + l16) * 4);
+        const float4 w = *reinterpret_cast<const float4*>(sW + (CHUNK ? h % HC : h) * DP + (c * 16 + l16) * 4);
         acc[c].x = __builtin_fmaf(bit, w.x, acc[c].x);
         acc[c].y = __builtin_fmaf(bit, w.y, acc[c].y);
         acc[c].z = __builtin_fmaf(bit, w.z, acc[c].z);
@@ -421,19 +436,29 @@ extern "C" int mi_oov_lsh_codes_embed(const uint8_t* codes, int64_t M, const int
     return launch_lsh64_from_codes(codes, M, slot, B, buckets, other, score, st);
   const int dc = static_cast<int>((D + 63) / 64);
   const int dcq = dc <= 1 ? 1 : (dc <= 2 ? 2 : 4);
-  const size_t lds = static_cast<size_t>(H) * dcq * 64 * sizeof(float);
-  if (static_cast<int64_t>(lds) > kLdsLimit) return MI_OOV_ERR_SHAPE;
+  size_t lds = static_cast<size_t>(H) * dcq * 64 * sizeof(float);
+  const bool chunked = static_cast<int64_t>(lds) > 64 * 1024;  // (beyond two workgroups per CU: bucket rows a chunk at a time)
+  int hc = 0;
+  if (chunked) {
+    hc = static_cast<int>(32 * 1024 / (dcq * 64 * sizeof(float)));  // 32 KB per chunk
+    lds = static_cast<size_t>(hc) * dcq * 64 * sizeof(float);
+  }
   const int grid = grid_for(B, 16);
-#define MI_GO(DCV)                                                                                                    \
+#define MI_GO(DCV, CH)                                                                                                \
   {                                                                                                                   \
-    auto k = lsh_codes_embed_kernel<DCV>;                                                                             \
+    auto k = lsh_codes_embed_kernel<DCV, CH>;                                                                         \
     if (int rc = set_lds(k, lds)) return rc;                                                                          \
     hipLaunchKernelGGL(k, dim3(grid), dim3(256), lds, st, codes, M, slot, B, static_cast<int>(H), buckets,            \
-                       static_cast<int>(D), other, score, out);                                                       \
+                       static_cast<int>(D), other, score, out, hc);                                                   \
     return check_launch();                                                                                            \
   }
-  if (dcq == 1) MI_GO(1)
-  if (dcq == 2) MI_GO(2)
-  MI_GO(4)
+  if (chunked) {
+    if (dcq == 1) MI_GO(1, true)
+    if (dcq == 2) MI_GO(2, true)
+    MI_GO(4, true)
+  }
+  if (dcq == 1) MI_GO(1, false)
+  if (dcq == 2) MI_GO(2, false)
+  MI_GO(4, false)
 #undef MI_GO
 }

@@ -124,7 +124,8 @@ def test_bucket_by_owner_one_launch_and_local_compaction(B, N, world, cap, me, o
 
 
 @pytest.mark.parametrize("B,H,D", [(1, 8, 64), (777, 8, 64), (4099, 3, 64), (500, 16, 36), (333, 27, 128), (129, 40, 50),
-                                   (64, 12, 256), (257, 5, 1)])
+                                   (64, 12, 256), (257, 5, 1),
+                                   (900, 300, 64), (333, 2000, 64), (257, 700, 130), (130, 257, 256)])  # bucket rows a chunk at a time
 def test_lsh_codes_embed_vs_oracle(B, H, D, oracle, ops, dev):
     rng = np.random.default_rng(B + H)
     M = B + 50
