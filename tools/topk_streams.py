@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Developer probe: the fused top-k of ONE user batch cut into P row chunks issued on P streams (the chains of 5 kernels
-then overlap: one chunk's kernel boundaries and ramps are another's work).  python3 tools/topk_streams.py [D] [B] [N] [k]"""
+then overlap: one chunk's kernel boundaries and ramps are another's work).  python3 tools/topk_streams.py [D] [B] [N] [k]
+Round 4, final kernels, 4096 x 50 000, k = 20, D = 64: 1 / 2 / 3 / 4 chunks = 78.3 / 87.4 / 91.8 / 100.6 us in a graph replay (eager: 101 / 141 /
+152 / 207, host-bound); D = 128: 117.2 / 121.0 / 135.1 / 142.3 -- the smaller launches keep their fixed costs and fill the chip worse: no gain."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -48,4 +50,25 @@ for P in (1, 2, 3, 4, 8):
         b.record()
         torch.cuda.synchronize()
         best = min(best, a.elapsed_time(b) * 1e3 / 20)
-    print(f"D={D} B={B} N={N} k={k}: {P} chunk(s) on {P} stream(s): {best:.1f} us per batch, identical results: {same}", flush=True)
+    # the same call captured ONCE into a HIP graph (fork / join inside the capture) and replayed: no host time between launches
+    gbest = float("nan")
+    try:
+        cap = torch.cuda.Stream(dev)
+        with torch.cuda.stream(cap):
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=cap):
+                for _ in range(10):
+                    keep = call()
+        torch.cuda.synchronize()
+        gr.replay()
+        torch.cuda.synchronize()
+        gbest = 1e9
+        for rep in range(3):
+            a.record()
+            gr.replay()
+            b.record()
+            torch.cuda.synchronize()
+            gbest = min(gbest, a.elapsed_time(b) * 1e3 / 10)
+    except Exception as e:  # noqa: BLE001
+        print("  (graph capture failed:", type(e).__name__, str(e)[:100], ")")
+    print(f"D={D} B={B} N={N} k={k}: {P} chunk(s) on {P} stream(s): {best:.1f} us per batch eager, {gbest:.1f} us in a graph replay, identical results: {same}", flush=True)
